@@ -1,0 +1,140 @@
+/* stark252_hip.h — C ABI of the MI355X (gfx950) STARK proving hot path for the lambdaworks Cairo prover.
+ *
+ * The reference (lambdaclass/lambdaworks_cairo_prover) has no FFI: `prove` (src/starks/prover.rs:532-766) calls
+ * the lambdaworks-math / lambdaworks-crypto traits directly.  This header is what a Rust `extern "C"` block in
+ * src/starks/prover.rs (or a replacement lambdaworks backend, like the existing `metal` feature, Cargo.toml:39)
+ * binds; INTEGRATION.md shows the binding.  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - return 0 (SP_OK) on success, a negative SP_E_* code otherwise; nothing aborts or throws across the ABI
+ *     (the reference `unwrap()`s; a shim maps non-zero to ProvingError::WrongParameter, prover.rs:40-43).
+ *   - field elements are contiguous 32-byte records in one of two encodings (sp_fe_encoding):
+ *       SP_FE_MONT_LIMBS  4 x u64, limb 0 MOST significant, Montgomery form R = 2^256 — the in-memory layout of
+ *                         lambdaworks `FieldElement<Stark252PrimeField>` (zero-copy from a Rust `&[FE]`);
+ *       SP_FE_CANON_BE    canonical 32-byte big-endian (`to_bytes_be`, the proof wire format).
+ *   - the caller owns every input/output buffer; a context owns its device memory; calls on one context are
+ *     serial (the round structure is sequential); different contexts may be used from different threads.
+ *   - host pointers unless a parameter is named *_dev.
+ */
+#ifndef STARK252_HIP_H
+#define STARK252_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    SP_OK = 0,
+    SP_E_INVALID_ARG = -1,   /* null pointer, non power-of-two size, unknown enum */
+    SP_E_NO_DEVICE = -2,     /* no gfx950 device visible / HIP runtime unusable */
+    SP_E_HIP = -3,           /* a HIP call failed; see sp_last_error() */
+    SP_E_ALLOC = -4,
+    SP_E_STATE = -5,         /* round called out of order */
+    SP_E_ZERO_INVERSE = -6,  /* batch inverse of a zero element (lambdaworks panics) */
+    SP_E_UNSUPPORTED = -7,
+    SP_E_PROGRAM = -8        /* Cairo front-end: undecodable instruction, missing memory cell, step limit */
+};
+
+typedef enum { SP_FE_MONT_LIMBS = 0, SP_FE_CANON_BE = 1 } sp_fe_encoding;
+
+/* ProofOptions — reference src/starks/proof/options.rs:21-26 */
+typedef struct {
+    uint8_t blowup_factor;
+    uint64_t fri_number_of_queries;
+    uint64_t coset_offset;
+    uint8_t grinding_factor;
+} sp_proof_options;
+
+typedef struct {
+    int device;        /* HIP device ordinal */
+    int fe_encoding;   /* sp_fe_encoding of every field-element buffer crossing the ABI on this context */
+} sp_config;
+
+typedef struct sp_ctx sp_ctx;
+
+const char* sp_version(void);
+const char* sp_last_error(void);          /* thread-local description of the last failure */
+int sp_device_count(int* count_out);      /* number of visible HIP devices (0 without a GPU) */
+
+int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
+void sp_ctx_destroy(sp_ctx* ctx);
+
+/* ---- fine-grained layer: the lambdaworks seam the reference calls ------------------------ */
+
+/* Natural-order DFT of n = 2^k elements, in place.
+ *   inverse == 0, coset == NULL : Polynomial::evaluate_fft                           (data = coefficients)
+ *   inverse == 0, coset != NULL : evaluate_offset_fft(1, None, coset)  (prover.rs:117, fri_commitment.rs:36)
+ *   inverse != 0, coset == NULL : Polynomial::interpolate_fft                         (trace.rs:107)
+ *   inverse != 0, coset != NULL : Polynomial::interpolate_offset_fft  (constraints/evaluation_table.rs:32)
+ * `coset` is one field element in the context's encoding. */
+int sp_ntt(sp_ctx* ctx, uint8_t* data, uint64_t n, int inverse, const uint8_t* coset);
+
+/* Batched variant on device memory: `batch` vectors of n elements each, vector v at data_dev + v*n*32,
+ * elements in the DEVICE layout (8 x u32 little-endian Montgomery, see sp_fe_to_device). Used by bench.py so the
+ * timed region starts with inputs resident in HBM. Asynchronous on the context stream; sp_sync() to wait. */
+int sp_ntt_dev(sp_ctx* ctx, void* data_dev, uint64_t n, uint32_t batch, int inverse, const uint8_t* coset);
+
+/* evaluate_polynomial_on_lde_domain (prover.rs:106-123) for `cols` polynomials of n coefficients each
+ * (column-major: column j at coeffs + j*n*32): out column j holds n*blowup evaluations p_j(coset * w_N^i). */
+int sp_lde(sp_ctx* ctx, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32_t blowup, const uint8_t* coset,
+           uint8_t* out);
+
+/* MerkleTree::<BatchKeccak256Tree|Keccak256Tree>::build (prover.rs:96-104, fri_commitment.rs:39; backends
+ * config.rs:10-20): n_leaves rows of fe_per_leaf elements (row-major); leaf = Keccak256(row as 32-byte BE
+ * elements), parent = Keccak256(left || right). nodes_out (nullable) receives all 2n-1 nodes, root first,
+ * children of i at 2i+1 and 2i+2 (the lambdaworks node order). */
+int sp_merkle_build(sp_ctx* ctx, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf,
+                    uint8_t root_out[32], uint8_t* nodes_out);
+
+/* FieldElement::inplace_batch_inverse (constraints/evaluator.rs:69,171; cairo/air.rs:540,561). */
+int sp_batch_inverse(sp_ctx* ctx, uint8_t* data, uint64_t n);
+
+/* Encoding helpers between the ABI encodings and the device layout (host side, no GPU needed). */
+int sp_fe_to_device(int fe_encoding, const uint8_t* in, uint64_t n, uint8_t* out_device_layout);
+int sp_fe_from_device(int fe_encoding, const uint8_t* in_device_layout, uint64_t n, uint8_t* out);
+
+int sp_sync(sp_ctx* ctx);
+/* Average duration in milliseconds of the kernels launched by the last sp_*_dev call, measured with HIP events
+ * on the context stream (bench.py roofline). */
+int sp_last_kernel_ms(sp_ctx* ctx, float* ms_out);
+
+/* ---- Cairo front-end on the host --------------------------------------------------- */
+
+/* PublicInputs — reference src/cairo/air.rs:163-181 (HashMaps flattened to arrays). Field elements in
+ * SP_FE_CANON_BE regardless of the context encoding. */
+typedef struct {
+    uint8_t pc_init[32], ap_init[32], fp_init[32], pc_final[32], ap_final[32];
+    uint16_t range_check_min, range_check_max;
+    uint32_t n_segments;
+    const uint8_t* segment_types;      /* 0 = RangeCheck, 1 = Output */
+    const uint64_t* segment_ranges;    /* (start, end) pairs */
+    uint64_t n_public_memory;
+    const uint8_t* public_memory;      /* (address, value) pairs, 64 bytes each */
+    uint64_t num_steps;
+} sp_cairo_public_inputs;
+
+typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public inputs + main trace */
+
+/* run_program + PublicInputs::from_regs_and_mem + build_main_trace for a hint-free, builtin-free program given as
+ * `n_words` canonical-BE field elements (reference src/cairo/runner/run.rs:242-263). */
+int sp_cairo_run_program(const uint8_t* program_words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out);
+/* The 22-word fibonacci program of benches/proofs/fibonacci_70000.proof with index `fib_index`. */
+int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out);
+/* From cairo-run's binary dumps: .trace (24 B/row LE, register_states.rs:51-78) and .memory (8+32 B/row LE,
+ * cairo_mem.rs:35-61), program occupying addresses 1..program_size. */
+int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint8_t* memory, uint64_t memory_len,
+                            uint64_t program_size, sp_cairo_run** out);
+void sp_cairo_run_free(sp_cairo_run* run);
+/* Shape of the main trace: n rows (power of two) x cols (34, or 43 with the range-check builtin). */
+int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_cols, uint64_t* num_steps);
+/* Copies the row-major main trace in `fe_encoding` (n*cols*32 bytes). */
+int sp_cairo_run_main_trace(const sp_cairo_run* run, int fe_encoding, uint8_t* out);
+/* Fills `pi`; the pointers inside stay valid until sp_cairo_run_free(run). */
+int sp_cairo_run_public_inputs(const sp_cairo_run* run, sp_cairo_public_inputs* pi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STARK252_HIP_H */

@@ -1,0 +1,203 @@
+"""Host-side mirror of the reference interface for the proving hot path, on top of the C ABI.
+
+Names follow the reference: `ProofOptions` (src/starks/proof/options.rs:21-26), `PublicInputs` (src/cairo/air.rs:163-181),
+`generate_prover_args` (src/cairo/runner/run.rs:242-263), `generate_cairo_proof` (src/cairo/air.rs:1165-1171), and the
+lambdaworks seam `interpolate_fft / evaluate_offset_fft / MerkleTree::build / inplace_batch_inverse`.
+Field elements cross this layer as canonical 32-byte big-endian records in numpy uint8 arrays of shape (..., 32).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import (SP_FE_CANON_BE, SP_FE_MONT_LIMBS, CairoPublicInputsC, ConfigC, ProofOptionsC, SpError, check)
+
+__all__ = ["ProofOptions", "Context", "CairoRun", "generate_prover_args_fibonacci", "SpError", "P", "felts_to_bytes",
+           "bytes_to_felts", "SP_FE_CANON_BE", "SP_FE_MONT_LIMBS"]
+
+P = 2**251 + 17 * 2**192 + 1
+
+
+def felts_to_bytes(values):
+    """list of python ints (< p) -> uint8 array (len, 32), canonical big-endian."""
+    return np.frombuffer(b"".join(int(v).to_bytes(32, "big") for v in values), dtype=np.uint8).reshape(-1, 32).copy()
+
+
+def bytes_to_felts(arr):
+    b = np.ascontiguousarray(arr, dtype=np.uint8).tobytes()
+    return [int.from_bytes(b[i:i + 32], "big") for i in range(0, len(b), 32)]
+
+
+@dataclass
+class ProofOptions:
+    """reference src/starks/proof/options.rs:21-26"""
+    blowup_factor: int = 4
+    fri_number_of_queries: int = 3
+    coset_offset: int = 3
+    grinding_factor: int = 1
+
+    @staticmethod
+    def default_test_options():  # options.rs:144-151
+        return ProofOptions(4, 3, 3, 1)
+
+    def to_c(self):
+        return ProofOptionsC(self.blowup_factor, self.fri_number_of_queries, self.coset_offset, self.grinding_factor)
+
+
+def _u8p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+
+
+class Context:
+    """One device context (sp_ctx): owns a HIP stream, twiddle tables and, during a proof, all device buffers."""
+
+    def __init__(self, device=0, fe_encoding=SP_FE_CANON_BE):
+        self._lib = _lib.load()
+        self._h = ctypes.c_void_p()
+        cfg = ConfigC(device, fe_encoding)
+        check(self._lib.sp_ctx_create(ctypes.byref(self._h), ctypes.byref(cfg)))
+        self.fe_encoding = fe_encoding
+
+    def close(self):
+        if self._h:
+            self._lib.sp_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- lambdaworks seam -------------------------------------------------------------------------------
+    def ntt(self, data, inverse=False, coset=None):
+        """evaluate_fft / interpolate_fft / evaluate_offset_fft / interpolate_offset_fft on a (n, 32) array."""
+        a = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32).copy()
+        c = None if coset is None else _u8p(np.ascontiguousarray(coset, dtype=np.uint8))
+        check(self._lib.sp_ntt(self._h, _u8p(a), ctypes.c_uint64(a.shape[0]), int(bool(inverse)), c))
+        return a
+
+    def lde(self, coeffs, blowup, coset):
+        """evaluate_polynomial_on_lde_domain for (cols, n, 32) coefficient columns -> (cols, n*blowup, 32)."""
+        a = np.ascontiguousarray(coeffs, dtype=np.uint8)
+        cols, n = a.shape[0], a.shape[1]
+        out = np.empty((cols, n * blowup, 32), dtype=np.uint8)
+        cs = np.ascontiguousarray(coset, dtype=np.uint8)
+        check(self._lib.sp_lde(self._h, _u8p(a), ctypes.c_uint64(n), ctypes.c_uint32(cols), ctypes.c_uint32(blowup), _u8p(cs), _u8p(out)))
+        return out
+
+    def merkle_build(self, rows, want_nodes=False):
+        """MerkleTree::build over (n_leaves, fe_per_leaf, 32) rows. Returns root bytes (and the (2n-1, 32) node array)."""
+        a = np.ascontiguousarray(rows, dtype=np.uint8)
+        n, w = a.shape[0], a.shape[1]
+        root = np.empty(32, dtype=np.uint8)
+        nodes = np.empty((2 * n - 1, 32), dtype=np.uint8) if want_nodes else None
+        check(self._lib.sp_merkle_build(self._h, _u8p(a), ctypes.c_uint64(n), ctypes.c_uint32(w), _u8p(root),
+                                        _u8p(nodes) if want_nodes else None))
+        return (root.tobytes(), nodes) if want_nodes else root.tobytes()
+
+    def batch_inverse(self, data):
+        a = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32).copy()
+        check(self._lib.sp_batch_inverse(self._h, _u8p(a), ctypes.c_uint64(a.shape[0])))
+        return a
+
+    # ---- device-resident variants used by bench.py -------------------------------------------------------
+    def ntt_dev(self, data_ptr, n, batch=1, inverse=False):
+        check(self._lib.sp_ntt_dev(self._h, ctypes.c_void_p(data_ptr), ctypes.c_uint64(n), ctypes.c_uint32(batch), int(bool(inverse)), None))
+
+    def last_kernel_ms(self):
+        ms = ctypes.c_float()
+        check(self._lib.sp_last_kernel_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        check(self._lib.sp_sync(self._h))
+
+
+def fe_to_device(values_be, fe_encoding=SP_FE_CANON_BE):
+    """ABI-encoded (n, 32) array -> device layout bytes (8 x u32 little-endian Montgomery), on the host."""
+    a = np.ascontiguousarray(values_be, dtype=np.uint8).reshape(-1, 32)
+    out = np.empty_like(a)
+    check(_lib.load().sp_fe_to_device(fe_encoding, _u8p(a), ctypes.c_uint64(a.shape[0]), _u8p(out)))
+    return out
+
+
+def fe_from_device(dev_bytes, fe_encoding=SP_FE_CANON_BE):
+    a = np.ascontiguousarray(dev_bytes, dtype=np.uint8).reshape(-1, 32)
+    out = np.empty_like(a)
+    check(_lib.load().sp_fe_from_device(fe_encoding, _u8p(a), ctypes.c_uint64(a.shape[0]), _u8p(out)))
+    return out
+
+
+class CairoRun:
+    """Register trace + memory + PublicInputs + main trace of one Cairo execution (host side).
+
+    Mirrors `generate_prover_args` (reference src/cairo/runner/run.rs:242-263): run -> PublicInputs::from_regs_and_mem
+    -> build_main_trace.  Only hint-free, builtin-free programs run in the built-in VM; dumps of cairo-run are also accepted.
+    """
+
+    def __init__(self, handle):
+        self._lib = _lib.load()
+        self._h = handle
+        n, c, s = ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint64()
+        check(self._lib.sp_cairo_run_shape(self._h, ctypes.byref(n), ctypes.byref(c), ctypes.byref(s)))
+        self.n_rows, self.n_cols, self.num_steps = n.value, c.value, s.value
+        self.public_inputs_c = CairoPublicInputsC()
+        check(self._lib.sp_cairo_run_public_inputs(self._h, ctypes.byref(self.public_inputs_c)))
+
+    @staticmethod
+    def fibonacci(fib_index):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(lib.sp_cairo_run_fibonacci(ctypes.c_uint64(fib_index), ctypes.byref(h)))
+        return CairoRun(h)
+
+    @staticmethod
+    def from_program(words, max_steps=1 << 26):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        a = felts_to_bytes(words)
+        check(lib.sp_cairo_run_program(_u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.c_uint64(max_steps), ctypes.byref(h)))
+        return CairoRun(h)
+
+    @staticmethod
+    def from_dumps(trace_bytes, memory_bytes, program_size):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        check(lib.sp_cairo_run_from_dumps(trace_bytes, ctypes.c_uint64(len(trace_bytes)), memory_bytes,
+                                          ctypes.c_uint64(len(memory_bytes)), ctypes.c_uint64(program_size), ctypes.byref(h)))
+        return CairoRun(h)
+
+    def main_trace(self, fe_encoding=SP_FE_CANON_BE):
+        out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
+        check(self._lib.sp_cairo_run_main_trace(self._h, fe_encoding, _u8p(out)))
+        return out
+
+    def public_memory(self):
+        pi = self.public_inputs_c
+        raw = ctypes.string_at(pi.public_memory, 64 * pi.n_public_memory)
+        return [(int.from_bytes(raw[64 * i:64 * i + 32], "big"), int.from_bytes(raw[64 * i + 32:64 * i + 64], "big"))
+                for i in range(pi.n_public_memory)]
+
+    def close(self):
+        if self._h:
+            self._lib.sp_cairo_run_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def generate_prover_args_fibonacci(fib_index):
+    """(main_trace, public_inputs) for fib(1, 1, fib_index), the shape of the reference's benches."""
+    return CairoRun.fibonacci(fib_index)

@@ -1,0 +1,220 @@
+// C ABI: context and the fine-grained device entry points (sp_ntt, sp_lde, sp_merkle_build, sp_batch_inverse).
+// See include/stark252_hip.h for the reference call sites each one replaces.
+#include "ctx.h"
+#include <cstring>
+#include <vector>
+
+using namespace sp;
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) { sp_set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)"); p = nullptr; return SP_E_ALLOC; }
+        return SP_OK;
+    }
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+}  // namespace
+
+extern "C" {
+
+int sp_device_count(int* count_out) {
+    if (!count_out) return SP_E_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *count_out = n;
+    return SP_OK;
+}
+
+int sp_ctx_create(sp_ctx** out, const sp_config* cfg) {
+    if (!out || !cfg) return SP_E_INVALID_ARG;
+    if (cfg->fe_encoding != SP_FE_MONT_LIMBS && cfg->fe_encoding != SP_FE_CANON_BE) return SP_E_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { sp_set_error("no HIP device visible: the stark252 HIP path requires an MI355X (gfx950)"); return SP_E_NO_DEVICE; }
+    if (cfg->device < 0 || cfg->device >= n) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(cfg->device));
+    sp_ctx* c = new sp_ctx();
+    c->device = cfg->device;
+    c->enc = cfg->fe_encoding;
+    if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; sp_set_error("hipStreamCreate failed"); return SP_E_HIP; }
+    c->ntt = new NttEngine(c->stream);
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { sp_ctx_destroy(c); return SP_E_HIP; }
+    if (hipMalloc(&c->d_flag, sizeof(int)) != hipSuccess) { sp_ctx_destroy(c); return SP_E_ALLOC; }
+    *out = c;
+    return SP_OK;
+}
+
+void sp_ctx_destroy(sp_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    delete c->prover_state_deleter_holder;
+    delete c->ntt;
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sp_sync(sp_ctx* c) {
+    if (!c) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+
+int sp_last_kernel_ms(sp_ctx* c, float* ms) {
+    if (!c || !ms) return SP_E_INVALID_ARG;
+    *ms = c->last_ms;
+    return SP_OK;
+}
+
+// upload `count` ABI-encoded elements and decode them into the device layout
+static int upload_decode(sp_ctx* c, const uint8_t* host, uint64_t count, fe* dst_dev) {
+    DevBuf raw;
+    SP_TRY(raw.alloc(count * 32));
+    SP_HIP_CHECK(hipMemcpyAsync(raw.p, host, count * 32, hipMemcpyHostToDevice, c->stream));
+    SP_TRY(decode_elements(c->stream, c->enc, raw.as<uint8_t>(), count, dst_dev));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+static int encode_download(sp_ctx* c, const fe* src_dev, uint64_t count, uint8_t* host) {
+    DevBuf raw;
+    SP_TRY(raw.alloc(count * 32));
+    SP_TRY(encode_elements(c->stream, c->enc, src_dev, count, raw.as<uint8_t>()));
+    SP_HIP_CHECK(hipMemcpyAsync(host, raw.p, count * 32, hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+static int decode_one(sp_ctx* c, const uint8_t* in, fe* out) {
+    return sp_fe_to_device(c->enc, in, 1, reinterpret_cast<uint8_t*>(out));
+}
+
+static int ntt_dev_impl(sp_ctx* c, fe* data, uint64_t n, uint32_t batch, int inverse, const uint8_t* coset, fe* tmp) {
+    int k = sp_log2_exact(n);
+    if (k < 0 || k > 30) { sp_set_error("ntt: size must be a power of two <= 2^30"); return SP_E_INVALID_ARG; }
+    NttEngine& e = *c->ntt;
+    fe h;
+    if (coset) SP_TRY(decode_one(c, coset, &h));
+    // the engine's natural->natural transforms are out of place: src = data, dst = tmp, then copy back
+    if (!inverse) {
+        if (coset) SP_TRY(e.scale_by_powers(data, n, batch, n, h, nullptr));
+        SP_TRY(e.forward_natural(data, tmp, k, batch, n, n));
+    } else {
+        SP_TRY(e.inverse_natural(data, tmp, k, batch, n, n));
+        if (coset) {
+            if (fe_is_zero(h)) return SP_E_ZERO_INVERSE;
+            SP_TRY(e.scale_by_powers(tmp, n, batch, n, fe_inv(h), nullptr));
+        }
+    }
+    SP_HIP_CHECK(hipMemcpyAsync(data, tmp, sizeof(fe) * n * batch, hipMemcpyDeviceToDevice, c->stream));
+    return SP_OK;
+}
+
+int sp_ntt(sp_ctx* c, uint8_t* data, uint64_t n, int inverse, const uint8_t* coset) {
+    if (!c || !data) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    if (sp_log2_exact(n) < 0) { sp_set_error("ntt: size must be a power of two"); return SP_E_INVALID_ARG; }
+    DevBuf a, b;
+    SP_TRY(a.alloc(n * sizeof(fe)));
+    SP_TRY(b.alloc(n * sizeof(fe)));
+    SP_TRY(upload_decode(c, data, n, a.as<fe>()));
+    SP_TRY(ntt_dev_impl(c, a.as<fe>(), n, 1, inverse, coset, b.as<fe>()));
+    SP_TRY(encode_download(c, a.as<fe>(), n, data));
+    return SP_OK;
+}
+
+int sp_ntt_dev(sp_ctx* c, void* data_dev, uint64_t n, uint32_t batch, int inverse, const uint8_t* coset) {
+    if (!c || !data_dev || batch == 0) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    int k = sp_log2_exact(n);
+    if (k < 0) return SP_E_INVALID_ARG;
+    size_t need = sizeof(fe) * n * batch;
+    if (c->scratch_bytes < need) {
+        if (c->scratch) (void)hipFree(c->scratch);
+        c->scratch = nullptr; c->scratch_bytes = 0;
+        if (hipMalloc(&c->scratch, need) != hipSuccess) { sp_set_error("hipMalloc scratch failed"); return SP_E_ALLOC; }
+        c->scratch_bytes = need;
+    }
+    // make sure twiddle tables exist before the timed region
+    const fe* t = nullptr;
+    SP_TRY(c->ntt->roots(k, &t));
+    SP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    int rc = ntt_dev_impl(c, reinterpret_cast<fe*>(data_dev), n, batch, inverse, coset, reinterpret_cast<fe*>(c->scratch));
+    SP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    if (rc != SP_OK) return rc;
+    SP_HIP_CHECK(hipEventSynchronize(c->ev1));
+    SP_HIP_CHECK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    return SP_OK;
+}
+
+int sp_lde(sp_ctx* c, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32_t blowup, const uint8_t* coset, uint8_t* out) {
+    if (!c || !coeffs || !coset || !out || cols == 0) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    int k = sp_log2_exact(n), lb = sp_log2_exact(blowup);
+    if (k < 0 || lb < 0 || k + lb > 30) { sp_set_error("lde: n and blowup must be powers of two"); return SP_E_INVALID_ARG; }
+    uint64_t N = n << lb;
+    fe h;
+    SP_TRY(decode_one(c, coset, &h));
+    DevBuf a, b, d;
+    SP_TRY(a.alloc(n * cols * sizeof(fe)));
+    SP_TRY(b.alloc(n * cols * sizeof(fe)));
+    SP_TRY(d.alloc(N * cols * sizeof(fe)));
+    SP_TRY(upload_decode(c, coeffs, n * cols, a.as<fe>()));
+    NttEngine& e = *c->ntt;
+    // natural coefficients -> h-scaled, bit-reversed: forward_natural's gather pass wants natural input, so go through
+    // evaluations: a (coefficients) --scale h^k--> --forward NTT (natural)--> evaluations on h<g>; then the engine's
+    // iNTT leaves them as bit-reversed h-scaled coefficients x n, fixed by the 1/n post scalar folded in scale_by_powers.
+    // Simpler and exact: bit-reverse by running DIF inverse on the forward transform.
+    SP_TRY(e.scale_by_powers(a.as<fe>(), n, cols, n, h, nullptr));
+    SP_TRY(e.forward_natural(a.as<fe>(), b.as<fe>(), k, cols, n, n));                // evaluations over <g> of p(h x)
+    SP_TRY(e.dif_natural_to_bitrev_inverse(b.as<fe>(), k, cols, n, nullptr));       // n * (c_j h^j), bit-reversed
+    fe ninv = fe_inv(fe_from_u64(n));
+    SP_TRY(e.scale_by_powers(b.as<fe>(), n, cols, n, fe_one(), &ninv));
+    SP_TRY(e.lde_from_bitrev(b.as<fe>(), d.as<fe>(), k, lb, cols, n, N));
+    SP_TRY(encode_download(c, d.as<fe>(), N * cols, out));
+    return SP_OK;
+}
+
+int sp_merkle_build(sp_ctx* c, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf, uint8_t root_out[32], uint8_t* nodes_out) {
+    if (!c || !leaves || !root_out || fe_per_leaf == 0) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    if (sp_log2_exact(n_leaves) < 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
+    DevBuf raw, cols, nodes;
+    uint64_t total = n_leaves * fe_per_leaf;
+    SP_TRY(raw.alloc(total * 32));
+    SP_TRY(cols.alloc(total * sizeof(fe)));
+    SP_TRY(nodes.alloc((2 * n_leaves - 1) * sizeof(digest32)));
+    SP_HIP_CHECK(hipMemcpyAsync(raw.p, leaves, total * 32, hipMemcpyHostToDevice, c->stream));
+    SP_TRY(rows_to_columns(c->stream, c->enc, raw.as<uint8_t>(), n_leaves, fe_per_leaf, cols.as<fe>(), n_leaves));
+    SP_TRY(merkle_hash_leaves(c->stream, cols.as<fe>(), n_leaves, fe_per_leaf, n_leaves, nodes.as<digest32>()));
+    SP_TRY(merkle_reduce(c->stream, nodes.as<digest32>(), n_leaves));
+    SP_HIP_CHECK(hipMemcpyAsync(root_out, nodes.p, 32, hipMemcpyDeviceToHost, c->stream));
+    if (nodes_out) SP_HIP_CHECK(hipMemcpyAsync(nodes_out, nodes.p, (2 * n_leaves - 1) * 32, hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+
+int sp_batch_inverse(sp_ctx* c, uint8_t* data, uint64_t n) {
+    if (!c || !data) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    if (n == 0) return SP_OK;
+    DevBuf a, s;
+    SP_TRY(a.alloc(n * sizeof(fe)));
+    SP_TRY(s.alloc(n * sizeof(fe)));
+    SP_TRY(upload_decode(c, data, n, a.as<fe>()));
+    SP_HIP_CHECK(hipMemsetAsync(c->d_flag, 0, sizeof(int), c->stream));
+    SP_TRY(batch_inverse(c->stream, a.as<fe>(), s.as<fe>(), n, c->d_flag));
+    int flag = 0;
+    SP_HIP_CHECK(hipMemcpyAsync(&flag, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (flag) { sp_set_error("batch inverse of a zero element"); return SP_E_ZERO_INVERSE; }
+    SP_TRY(encode_download(c, a.as<fe>(), n, data));
+    return SP_OK;
+}
+
+}  // extern "C"

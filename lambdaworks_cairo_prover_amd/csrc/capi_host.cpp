@@ -1,0 +1,127 @@
+// C ABI: host-only entry points (Cairo front-end, encoding helpers). See include/stark252_hip.h.
+#include "../../include/stark252_hip.h"
+#include "cairo_host.h"
+#include "common.h"
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+struct sp_cairo_run {
+    std::vector<sp::RegisterState> regs;
+    sp::CairoMemory mem;
+    sp::PublicInputs pub;
+    std::vector<fe> main_trace;
+    size_t n_rows = 0, n_cols = 0;
+    // flattened views handed out by sp_cairo_run_public_inputs
+    std::vector<uint8_t> seg_types;
+    std::vector<uint64_t> seg_ranges;
+    std::vector<uint8_t> pm_bytes;
+};
+
+static thread_local std::string g_last_error;
+void sp_set_error(const std::string& s) { g_last_error = s; }
+
+extern "C" {
+
+const char* sp_version(void) { return "stark252-hip 0.1 (gfx950)"; }
+const char* sp_last_error(void) { return g_last_error.c_str(); }
+
+int sp_fe_to_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
+    if (!in || !out) return SP_E_INVALID_ARG;
+    fe* o = reinterpret_cast<fe*>(out);
+    if (enc == SP_FE_CANON_BE) {
+        for (uint64_t i = 0; i < n; ++i) o[i] = fe_from_bytes_be(in + 32 * i);
+    } else if (enc == SP_FE_MONT_LIMBS) {
+        for (uint64_t i = 0; i < n; ++i) { uint64_t l[4]; std::memcpy(l, in + 32 * i, 32); o[i] = fe_from_lw_limbs(l); }
+    } else return SP_E_INVALID_ARG;
+    return SP_OK;
+}
+int sp_fe_from_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
+    if (!in || !out) return SP_E_INVALID_ARG;
+    const fe* a = reinterpret_cast<const fe*>(in);
+    if (enc == SP_FE_CANON_BE) {
+        for (uint64_t i = 0; i < n; ++i) fe_to_bytes_be(a[i], out + 32 * i);
+    } else if (enc == SP_FE_MONT_LIMBS) {
+        for (uint64_t i = 0; i < n; ++i) { uint64_t l[4]; fe_to_lw_limbs(a[i], l); std::memcpy(out + 32 * i, l, 32); }
+    } else return SP_E_INVALID_ARG;
+    return SP_OK;
+}
+
+static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out) {
+    r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, {});
+    r->main_trace = sp::build_main_trace(r->regs, r->mem, r->pub, &r->n_rows, &r->n_cols);
+    *out = r;
+    return SP_OK;
+}
+
+int sp_cairo_run_program(const uint8_t* words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out) {
+    if (!words || !out || n_words == 0) return SP_E_INVALID_ARG;
+    sp_cairo_run* r = new sp_cairo_run();
+    try {
+        std::vector<fe> prog(n_words);
+        for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
+        sp::run_program_plain(prog, r->regs, r->mem, max_steps);
+        return finish_run(r, n_words, out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out) {
+    if (!out) return SP_E_INVALID_ARG;
+    sp_cairo_run* r = new sp_cairo_run();
+    try {
+        std::vector<fe> prog = sp::fibonacci_program(fib_index);
+        sp::run_program_plain(prog, r->regs, r->mem, 7 * fib_index + 64);
+        return finish_run(r, prog.size(), out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint8_t* memory, uint64_t memory_len,
+                            uint64_t program_size, sp_cairo_run** out) {
+    if (!trace || !memory || !out) return SP_E_INVALID_ARG;
+    sp_cairo_run* r = new sp_cairo_run();
+    try {
+        if (!sp::parse_trace_le(trace, trace_len, r->regs) || r->regs.empty()) throw std::runtime_error("IncorrectNumberOfBytes (trace)");
+        if (!sp::parse_memory_le(memory, memory_len, r->mem)) throw std::runtime_error("IncorrectNumberOfBytes (memory)");
+        return finish_run(r, program_size, out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+void sp_cairo_run_free(sp_cairo_run* run) { delete run; }
+
+int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_cols, uint64_t* num_steps) {
+    if (!run) return SP_E_INVALID_ARG;
+    if (n_rows) *n_rows = run->n_rows;
+    if (n_cols) *n_cols = (uint32_t)run->n_cols;
+    if (num_steps) *num_steps = run->pub.num_steps;
+    return SP_OK;
+}
+
+int sp_cairo_run_main_trace(const sp_cairo_run* run, int enc, uint8_t* out) {
+    if (!run || !out) return SP_E_INVALID_ARG;
+    return sp_fe_from_device(enc, reinterpret_cast<const uint8_t*>(run->main_trace.data()), run->main_trace.size(), out);
+}
+
+int sp_cairo_run_public_inputs(const sp_cairo_run* crun, sp_cairo_public_inputs* pi) {
+    if (!crun || !pi) return SP_E_INVALID_ARG;
+    sp_cairo_run* run = const_cast<sp_cairo_run*>(crun);
+    const sp::PublicInputs& p = run->pub;
+    fe_to_bytes_be(p.pc_init, pi->pc_init); fe_to_bytes_be(p.ap_init, pi->ap_init); fe_to_bytes_be(p.fp_init, pi->fp_init);
+    fe_to_bytes_be(p.pc_final, pi->pc_final); fe_to_bytes_be(p.ap_final, pi->ap_final);
+    pi->range_check_min = p.range_check_min; pi->range_check_max = p.range_check_max;
+    run->seg_types.clear(); run->seg_ranges.clear();
+    for (auto& s : p.memory_segments) { run->seg_types.push_back(s.type); run->seg_ranges.push_back(s.start); run->seg_ranges.push_back(s.end); }
+    run->pm_bytes.resize(64 * p.public_memory.size());
+    for (size_t i = 0; i < p.public_memory.size(); ++i) {
+        fe_to_bytes_be(fe_from_u64(p.public_memory[i].first), &run->pm_bytes[64 * i]);
+        fe_to_bytes_be(p.public_memory[i].second, &run->pm_bytes[64 * i + 32]);
+    }
+    pi->n_segments = (uint32_t)p.memory_segments.size();
+    pi->segment_types = run->seg_types.data();
+    pi->segment_ranges = run->seg_ranges.data();
+    pi->n_public_memory = p.public_memory.size();
+    pi->public_memory = run->pm_bytes.data();
+    pi->num_steps = p.num_steps;
+    return SP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,30 @@
+// Shared host-side helpers for the stark252 HIP library.
+#pragma once
+#include "../../include/stark252_hip.h"
+#include "fp.h"
+#include <hip/hip_runtime.h>
+#include <string>
+
+void sp_set_error(const std::string& s);
+
+#define SP_HIP_CHECK(expr)                                                                              \
+    do {                                                                                                \
+        hipError_t _e = (expr);                                                                         \
+        if (_e != hipSuccess) {                                                                         \
+            sp_set_error(std::string(#expr) + ": " + hipGetErrorString(_e) + " (" __FILE__ ":" + std::to_string(__LINE__) + ")"); \
+            return SP_E_HIP;                                                                            \
+        }                                                                                               \
+    } while (0)
+
+#define SP_TRY(expr)                \
+    do {                            \
+        int _r = (expr);            \
+        if (_r != SP_OK) return _r; \
+    } while (0)
+
+static inline int sp_log2_exact(uint64_t n) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    int k = 0;
+    while ((1ULL << k) < n) ++k;
+    return k;
+}

@@ -1,0 +1,21 @@
+// Context object behind the C ABI (one per proof / per caller thread).
+#pragma once
+#include "common.h"
+#include "ntt.h"
+#include "merkle.h"
+#include "field_kernels.h"
+
+struct sp_deletable { virtual ~sp_deletable() {} };
+
+struct sp_ctx {
+    int device = 0;
+    int enc = SP_FE_CANON_BE;
+    hipStream_t stream = nullptr;
+    sp::NttEngine* ntt = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int* d_flag = nullptr;
+    void* scratch = nullptr;
+    size_t scratch_bytes = 0;
+    float last_ms = 0.f;
+    sp_deletable* prover_state_deleter_holder = nullptr;  // round-level prover state (prover.cpp)
+};

@@ -1,0 +1,14 @@
+// Element-wise field kernels (batch inversion, layout/encoding conversion). See field_kernels.hip.
+#pragma once
+#include "common.h"
+
+namespace sp {
+
+// In-place batch inverse of n device elements; scratch = n elements; *zero_flag_dev is set to 1 when an element is 0.
+int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_flag_dev);
+// rows_dev: n_rows x n_cols row-major in ABI encoding `enc` (device memory) -> cols[c*col_stride + r] device layout
+int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n_rows, uint32_t n_cols, fe* cols, uint64_t col_stride);
+int encode_elements(hipStream_t st, int enc, const fe* in, uint64_t n, uint8_t* out_dev);
+int decode_elements(hipStream_t st, int enc, const uint8_t* in_dev, uint64_t n, fe* out);
+
+}  // namespace sp

@@ -1,0 +1,155 @@
+// Element-wise field kernels: batch inversion, layout transposes.
+#include "field_kernels.h"
+
+namespace sp {
+
+__device__ __forceinline__ fe fk_ld(const fe* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void fk_st(fe* p, const fe& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+
+// FieldElement::inplace_batch_inverse (reference src/starks/constraints/evaluator.rs:69,171; lambdaworks-math):
+// Montgomery's trick per thread over the strided chunk {t, t+T, t+2T, ...} (T = total threads), so that every
+// global access of a wave is contiguous. scratch holds the running prefix products (n elements).
+__global__ void __launch_bounds__(256) batch_inverse_kernel(fe* data, fe* scratch, uint64_t n, int* zero_flag) {
+    const uint64_t T = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    fe acc = fe_one();
+    for (uint64_t i = t; i < n; i += T) {
+        fk_st(scratch + i, acc);
+        acc = fe_mul(acc, fk_ld(data + i));
+    }
+    if (fe_is_zero(acc)) { atomicExch(zero_flag, 1); return; }
+    fe inv = fe_inv(acc);
+    uint64_t cnt = (n - t + T - 1) / T;
+    for (uint64_t m = cnt; m-- > 0;) {
+        uint64_t i = t + m * T;
+        fe a = fk_ld(data + i);
+        fk_st(data + i, fe_mul(inv, fk_ld(scratch + i)));
+        inv = fe_mul(inv, a);
+    }
+}
+
+int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_flag_dev) {
+    if (n == 0) return SP_OK;
+    // chunk of ~64 elements per thread amortises the Fermat inversion (~300 mulmods) to < 5 mulmods/element
+    uint64_t threads = (n + 63) / 64;
+    unsigned blocks = (unsigned)((threads + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, n, zero_flag_dev);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// Row-major table (rows x cols, ABI encoding) -> column-major device layout. One thread per element; reads are
+// contiguous along the row, writes along the column (32-byte granules), tiled through LDS to coalesce both.
+template <int ENC>
+__global__ void __launch_bounds__(256) rows_to_columns_kernel(const uint8_t* rows, uint64_t n_rows, uint32_t n_cols, fe* cols, uint64_t col_stride) {
+    // tile: 32 rows x 8 cols
+    __shared__ fe tile[32][9];
+    uint32_t tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    uint64_t row0 = (uint64_t)blockIdx.x * 32;
+    uint32_t col0 = blockIdx.y * 8;
+    {
+        uint64_t rr = row0 + ty; uint32_t cc = col0 + tx;
+        if (rr < n_rows && cc < n_cols) {
+            const uint8_t* p = rows + (rr * n_cols + cc) * 32;
+            fe x;
+            if (ENC == SP_FE_MONT_LIMBS) {
+                const uint64_t* l = reinterpret_cast<const uint64_t*>(p);
+                uint64_t w[4] = {l[0], l[1], l[2], l[3]};
+                x = fe_from_lw_limbs(w);
+            } else {
+                const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+                fe raw;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) raw.v[k] = sp_bswap32(w[7 - k]);
+                x = fe_to_mont(raw);
+            }
+            tile[ty][tx] = x;
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t ry = threadIdx.x & 31, cx = threadIdx.x >> 5;
+        uint64_t rr = row0 + ry; uint32_t cc = col0 + cx;
+        if (rr < n_rows && cc < n_cols) fk_st(cols + (uint64_t)cc * col_stride + rr, tile[ry][cx]);
+    }
+}
+
+int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n_rows, uint32_t n_cols, fe* cols, uint64_t col_stride) {
+    dim3 grid((unsigned)((n_rows + 31) / 32), (n_cols + 7) / 8);
+    if (enc == SP_FE_MONT_LIMBS)
+        hipLaunchKernelGGL((rows_to_columns_kernel<SP_FE_MONT_LIMBS>), grid, dim3(256), 0, st, rows_dev, n_rows, n_cols, cols, col_stride);
+    else if (enc == SP_FE_CANON_BE)
+        hipLaunchKernelGGL((rows_to_columns_kernel<SP_FE_CANON_BE>), grid, dim3(256), 0, st, rows_dev, n_rows, n_cols, cols, col_stride);
+    else return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// column-major device layout -> column-major ABI encoding (one thread per element)
+template <int ENC>
+__global__ void __launch_bounds__(256) encode_kernel(const fe* in, uint64_t n, uint8_t* out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    fe x = fk_ld(in + i);
+    if (ENC == SP_FE_MONT_LIMBS) {
+        uint64_t l[4];
+        fe_to_lw_limbs(x, l);
+        uint64_t* o = reinterpret_cast<uint64_t*>(out + 32 * i);
+        o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
+    } else {
+        fe raw = fe_from_mont(x);
+        uint32_t* o = reinterpret_cast<uint32_t*>(out + 32 * i);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) o[k] = sp_bswap32(raw.v[7 - k]);
+    }
+}
+template <int ENC>
+__global__ void __launch_bounds__(256) decode_kernel(const uint8_t* in, uint64_t n, fe* out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    fe x;
+    if (ENC == SP_FE_MONT_LIMBS) {
+        const uint64_t* l = reinterpret_cast<const uint64_t*>(in + 32 * i);
+        uint64_t w[4] = {l[0], l[1], l[2], l[3]};
+        x = fe_from_lw_limbs(w);
+    } else {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(in + 32 * i);
+        fe raw;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) raw.v[k] = sp_bswap32(p[7 - k]);
+        x = fe_to_mont(raw);
+    }
+    fk_st(out + i, x);
+}
+
+int encode_elements(hipStream_t st, int enc, const fe* in, uint64_t n, uint8_t* out_dev) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (enc == SP_FE_MONT_LIMBS) hipLaunchKernelGGL((encode_kernel<SP_FE_MONT_LIMBS>), dim3(blocks), dim3(256), 0, st, in, n, out_dev);
+    else if (enc == SP_FE_CANON_BE) hipLaunchKernelGGL((encode_kernel<SP_FE_CANON_BE>), dim3(blocks), dim3(256), 0, st, in, n, out_dev);
+    else return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int decode_elements(hipStream_t st, int enc, const uint8_t* in_dev, uint64_t n, fe* out) {
+    unsigned blocks = (unsigned)((n + 255) / 256);
+    if (enc == SP_FE_MONT_LIMBS) hipLaunchKernelGGL((decode_kernel<SP_FE_MONT_LIMBS>), dim3(blocks), dim3(256), 0, st, in_dev, n, out);
+    else if (enc == SP_FE_CANON_BE) hipLaunchKernelGGL((decode_kernel<SP_FE_CANON_BE>), dim3(blocks), dim3(256), 0, st, in_dev, n, out);
+    else return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+}  // namespace sp

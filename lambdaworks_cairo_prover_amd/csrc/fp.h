@@ -1,0 +1,224 @@
+// Stark252 prime field for gfx950 (and the host side of the library).
+//
+// Replaces `FieldElement<Stark252PrimeField>` (reference src/lib.rs:12-13; arithmetic in lambdaworks-math
+// @ a17b951) on the device: p = 2^251 + 17*2^192 + 1, Montgomery form with R = 2^256, eight 32-bit limbs,
+// least-significant limb first (one element = one aligned 32-byte little-endian integer in HBM).
+//
+// gfx950 has no 64x64 multiplier: the 8x8-limb product is 64 v_mad_u64_u32 (quarter rate) and dominates;
+// the Montgomery reduction needs NO multiplier because p = 1 (mod 2^64):  -p^-1 = -1 (mod 2^32), so the
+// per-round quotient is m = -t_0 and m*p = m + 17*m*2^192 + m*2^251 is shifts and adds on the top limbs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define SP_HD __host__ __device__ __forceinline__
+
+struct alignas(16) fe {
+    uint32_t v[8];
+};
+
+// p, little-endian 32-bit limbs
+#define SP_P0 0x00000001u
+#define SP_P6 0x00000011u
+#define SP_P7 0x08000000u
+
+SP_HD fe fe_zero() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    return r;
+}
+// R mod p  (Montgomery one)
+SP_HD fe fe_one() {
+    fe r;
+    r.v[0] = 0xffffffe1u; r.v[1] = 0xffffffffu; r.v[2] = 0xffffffffu; r.v[3] = 0xffffffffu;
+    r.v[4] = 0xffffffffu; r.v[5] = 0xffffffffu; r.v[6] = 0xfffffdf0u; r.v[7] = 0x07ffffffu;
+    return r;
+}
+// R^2 mod p
+SP_HD fe fe_r2() {
+    fe r;
+    r.v[0] = 0x7e000401u; r.v[1] = 0xfffffd73u; r.v[2] = 0x330fffffu; r.v[3] = 0x00000001u;
+    r.v[4] = 0xff6f8000u; r.v[5] = 0xffffffffu; r.v[6] = 0x5e008810u; r.v[7] = 0x07ffd4abu;
+    return r;
+}
+
+SP_HD bool fe_is_zero(const fe& a) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i];
+    return o == 0;
+}
+SP_HD bool fe_eq(const fe& a, const fe& b) {
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o |= a.v[i] ^ b.v[i];
+    return o == 0;
+}
+
+// r = a - p if a >= p else a   (a < 2p)
+SP_HD fe fe_reduce_once(const fe& a) {
+    // d = a - p ; p = {1,0,0,0,0,0,0x11,0x08000000}
+    fe d;
+    uint64_t br;
+    uint64_t t = (uint64_t)a.v[0] - SP_P0; d.v[0] = (uint32_t)t; br = (t >> 32) & 1;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { t = (uint64_t)a.v[i] - br; d.v[i] = (uint32_t)t; br = (t >> 32) & 1; }
+    t = (uint64_t)a.v[6] - SP_P6 - br; d.v[6] = (uint32_t)t; br = (t >> 32) & 1;
+    t = (uint64_t)a.v[7] - SP_P7 - br; d.v[7] = (uint32_t)t; br = (t >> 32) & 1;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+
+SP_HD fe fe_add(const fe& a, const fe& b) {
+    fe s;
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { c += (uint64_t)a.v[i] + b.v[i]; s.v[i] = (uint32_t)c; c >>= 32; }
+    return fe_reduce_once(s);  // a+b < 2p < 2^256: no carry out
+}
+
+SP_HD fe fe_sub(const fe& a, const fe& b) {
+    fe d;
+    uint64_t t, br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t = (uint64_t)a.v[i] - b.v[i] - br; d.v[i] = (uint32_t)t; br = (t >> 32) & 1; }
+    // add p back when the subtraction borrowed
+    uint32_t m = (uint32_t)(0 - (uint32_t)br);
+    uint64_t c = 0;
+    fe r;
+    c = (uint64_t)d.v[0] + (m & SP_P0); r.v[0] = (uint32_t)c; c >>= 32;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { c += (uint64_t)d.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
+    c += (uint64_t)d.v[6] + (m & SP_P6); r.v[6] = (uint32_t)c; c >>= 32;
+    c += (uint64_t)d.v[7] + (m & SP_P7); r.v[7] = (uint32_t)c;
+    return r;
+}
+
+SP_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
+
+// Montgomery reduction of the 16-limb integer t (< p * 2^256): returns t / 2^256 mod p, canonical.
+SP_HD fe fe_mont_reduce(uint32_t t[16]) {
+    uint32_t top = 0;  // carry out of limb 15 never happens for t < p*2^256, kept for safety in debug
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint32_t m = 0u - t[i];
+        // t += m * p * 2^(32 i):   limb i   += m            (becomes 0, carry = (t[i] != 0))
+        //                          limb i+6 += 17 m          (two limbs)
+        //                          limb i+7 += m << 27       (two limbs)
+        uint64_t c = (t[i] != 0) ? 1 : 0;
+#pragma unroll
+        for (int j = i + 1; j < i + 6; ++j) { c += t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        c += (uint64_t)t[i + 6] + (uint64_t)m * 17u;
+        t[i + 6] = (uint32_t)c; c >>= 32;
+        c += (uint64_t)t[i + 7] + ((uint64_t)m << 27);
+        t[i + 7] = (uint32_t)c; c >>= 32;
+#pragma unroll
+        for (int j = i + 8; j < 16; ++j) { c += t[j]; t[j] = (uint32_t)c; c >>= 32; }
+        top += (uint32_t)c;
+    }
+    (void)top;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[8 + i];
+    return fe_reduce_once(r);
+}
+
+SP_HD fe fe_mul(const fe& a, const fe& b) {
+    uint32_t t[16];
+    // schoolbook 8x8: row i adds a_i * b into t[i..i+8]
+    {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[0] * b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
+        t[8] = (uint32_t)c;
+    }
+#pragma unroll
+    for (int i = 1; i < 8; ++i) {
+        uint64_t c = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
+            t[i + j] = (uint32_t)c;
+            c >>= 32;
+        }
+        t[i + 8] = (uint32_t)c;
+    }
+    return fe_mont_reduce(t);
+}
+
+SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
+
+// canonical integer (little-endian limbs, < p) -> Montgomery
+SP_HD fe fe_to_mont(const fe& raw) { return fe_mul(raw, fe_r2()); }
+// Montgomery -> canonical integer
+SP_HD fe fe_from_mont(const fe& a) {
+    uint32_t t[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { t[i] = a.v[i]; t[8 + i] = 0; }
+    return fe_mont_reduce(t);
+}
+
+SP_HD fe fe_from_u64(uint64_t x) {
+    fe r = fe_zero();
+    r.v[0] = (uint32_t)x; r.v[1] = (uint32_t)(x >> 32);
+    return fe_to_mont(r);
+}
+
+SP_HD fe fe_pow_u64(const fe& a, uint64_t e) {
+    fe r = fe_one(), b = a;
+    while (e) {
+        if (e & 1) r = fe_mul(r, b);
+        b = fe_sqr(b);
+        e >>= 1;
+    }
+    return r;
+}
+
+// a^(p-2); a must be non-zero (callers check, mirroring lambdaworks' panic on zero)
+SP_HD fe fe_inv(const fe& a) {
+    // p - 2 = 0x0800000000000010 ffffffffffffffff ffffffffffffffff ffffffffffffffff
+    fe r = fe_one();
+    // top limb: 0x08000000 (bit 27 set), then limb 6 = 0x00000010
+    const uint32_t e[8] = {0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0x00000010u, 0x08000000u};
+    for (int i = 251; i >= 0; --i) {
+        r = fe_sqr(r);
+        if ((e[i >> 5] >> (i & 31)) & 1) r = fe_mul(r, a);
+    }
+    return r;
+}
+
+// ---- byte codecs ---------------------------------------------------------------------------------------
+SP_HD uint32_t sp_bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
+
+// canonical 32-byte big-endian (reference wire format, `to_bytes_be`) -> Montgomery fe. Input must be < p.
+SP_HD fe fe_from_bytes_be(const uint8_t* b) {
+    fe raw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint8_t* q = b + 4 * (7 - i);
+        raw.v[i] = ((uint32_t)q[0] << 24) | ((uint32_t)q[1] << 16) | ((uint32_t)q[2] << 8) | q[3];
+    }
+    return fe_to_mont(raw);
+}
+SP_HD void fe_to_bytes_be(const fe& a, uint8_t* b) {
+    fe raw = fe_from_mont(a);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint8_t* q = b + 4 * (7 - i);
+        q[0] = (uint8_t)(raw.v[i] >> 24); q[1] = (uint8_t)(raw.v[i] >> 16); q[2] = (uint8_t)(raw.v[i] >> 8); q[3] = (uint8_t)raw.v[i];
+    }
+}
+// lambdaworks in-memory layout: 4 x u64, limb 0 MOST significant, Montgomery form (R = 2^256) -> zero-cost reorder
+SP_HD fe fe_from_lw_limbs(const uint64_t* l) {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r.v[2 * i] = (uint32_t)l[3 - i]; r.v[2 * i + 1] = (uint32_t)(l[3 - i] >> 32); }
+    return r;
+}
+SP_HD void fe_to_lw_limbs(const fe& a, uint64_t* l) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) l[3 - i] = (uint64_t)a.v[2 * i] | ((uint64_t)a.v[2 * i + 1] << 32);
+}

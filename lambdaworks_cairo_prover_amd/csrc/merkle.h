@@ -1,0 +1,23 @@
+// Keccak-256 Merkle commitments on gfx950.
+// Replaces MerkleTree::<BatchKeccak256Tree>::build / MerkleTree::<Keccak256Tree>::build of lambdaworks-crypto as
+// configured by reference src/starks/config.rs:10-20 and called at src/starks/prover.rs:96-104 and
+// src/starks/fri/fri_commitment.rs:39.  Node order is the lambdaworks one: nodes[0] = root, children of i at
+// 2i+1 / 2i+2, leaves at nodes[n-1 .. 2n-2]; a digest is 32 bytes.
+#pragma once
+#include "common.h"
+
+namespace sp {
+
+struct digest32 { uint64_t w[4]; };
+
+// Hash `n_leaves` leaves into nodes[n_leaves-1 ..]; leaf i = Keccak256(col_0[i] || col_1[i] || ...) with every
+// element as canonical 32-byte big-endian.  Columns are device arrays in the device fe layout:
+// column j starts at cols + j*col_stride, element i of a column at index i (natural LDE order).
+int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes);
+// Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
+int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves);
+// Gather authentication paths: for each of `q` leaf positions, `depth` sibling digests bottom-up (lambdaworks
+// get_proof_by_pos) into out[q][depth].
+int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out);
+
+}  // namespace sp

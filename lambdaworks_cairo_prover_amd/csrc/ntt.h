@@ -1,0 +1,86 @@
+// Stark252 NTT engine for gfx950: four-step passes through LDS, radix-2 stages inside a pass.
+//
+// Replaces the lambdaworks FFTPoly calls of the reference: Polynomial::interpolate_fft (src/starks/trace.rs:107),
+// interpolate_offset_fft (src/starks/constraints/evaluation_table.rs:32), evaluate_offset_fft
+// (src/starks/prover.rs:117, src/starks/fri/fri_commitment.rs:36).
+//
+// Two pass structures (DESIGN.md "NTT"):
+//   DIT pass  : [x w_M^E(pos)] -> radix-2 DIT stages over R = 2^r elements at stride 2^s   (bit-reversed in -> natural out)
+//   DIF pass  : radix-2 DIF stages -> [x w_M^-E(pos)]                                        (natural in -> bit-reversed out)
+// A size-2^k transform is a chain of passes with s = 0, r1, r1+r2, ... ; the s = 0 pass works on contiguous tiles,
+// the others on tiles of R strided rows x G adjacent elements (G*32 B contiguous per row -> coalesced).
+// All memory orders are chosen so the prover never needs a bit-reversal pass: iNTT leaves coefficients
+// bit-reversed, the LDE consumes them bit-reversed and emits natural order.
+#pragma once
+#include "common.h"
+#include <map>
+#include <vector>
+
+namespace sp {
+
+constexpr int NTT_TILE_LOG = 10;                 // elements per workgroup tile (2^10 x 32 B = 32 KiB of LDS)
+constexpr int NTT_THREADS = 256;
+constexpr int NTT_MAX_CONTIG_LOG = NTT_TILE_LOG; // s = 0 pass: one row of up to 2^10 contiguous elements
+constexpr int NTT_STRIDED_G_LOG = 2;             // strided passes: 4 adjacent elements (128 B) per row
+constexpr int NTT_MAX_STRIDED_LOG = NTT_TILE_LOG - NTT_STRIDED_G_LOG;
+
+struct NttPassArgs {
+    const fe* src;
+    fe* dst;
+    uint64_t src_vec_stride, dst_vec_stride;  // elements between consecutive vectors of the batch
+    const fe* small_tw;   // w_R^(+-e), e in [0, R/2)   (direction chosen by the host)
+    const fe* big_tw;     // w_M^e, e in [0, M/2)       (forward roots; inverse obtained by index negation)
+    const fe* post_table; // DIF only, nullable: multiply the element stored at position pos by post_table[pos]
+    const fe* scalar;     // nullable: multiply every stored element by *scalar (device pointer)
+    uint32_t logM;        // transform size (dst vector length 2^logM)
+    uint32_t s, r, g;     // this pass: stride 2^s, R = 2^r rows, G = 2^g adjacent elements per row
+    uint32_t s_prev;      // stride (log2) of the neighbouring lower pass (inter-pass twiddle), used when s > 0
+    uint32_t big_neg;     // 1: use w_M^(-E) (inverse transform)
+    uint32_t log_expand;  // EXPAND load: src index = pos >> log_expand (zero-padded/replicated LDE input)
+};
+
+enum NttLoadMode { NTT_LOAD_INPLACE = 0, NTT_LOAD_GATHER_BITREV = 1, NTT_LOAD_EXPAND = 2 };
+enum NttStoreMode { NTT_STORE_INPLACE = 0, NTT_STORE_SCATTER_BITREV = 1 };
+
+class NttEngine {
+  public:
+    explicit NttEngine(hipStream_t stream) : stream_(stream) {}
+    ~NttEngine();
+    // device table w_(2^k)^e, e in [0, 2^(k-1)); cached per k
+    int roots(int k, const fe** out);
+    // device table w_(2^k)^(-e), e in [0, 2^(k-1)); only for small k (pass twiddles)
+    int inv_roots_small(int k, const fe** out);
+
+    // bit-reversed input -> natural output, forward roots, in place.  batch vectors at `stride` elements.
+    int dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t stride);
+    // natural input -> bit-reversed output, inverse roots, UNSCALED (x 2^k), in place;
+    // post_table (nullable, device, 2^k entries indexed by output position) multiplies the result.
+    int dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table);
+    // natural -> natural forward DFT (evaluate_fft), out of place (src != dst).
+    int forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
+    // natural -> natural inverse DFT including the 1/2^k factor (interpolate_fft), out of place.
+    int inverse_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
+    // LDE: coeffs = n = 2^k "h-scaled" coefficients (c_j h^j) in bit-reversed order; dst = N = n*2^logb natural-order
+    // evaluations p(h w_N^i).  (zero-padded size-N DIT whose first log2(b) stages are replication.)
+    int lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
+
+    // dst[i] = src[i] * base^i * c  (natural index), c nullable. Used by the coset variants of sp_ntt.
+    int scale_by_powers(fe* data, uint64_t n, uint32_t batch, uint64_t stride, const fe& base, const fe* c);
+
+    // number of butterfly passes launched by the last call and their kernel time (hipEvent), for bench.py
+    float last_ms = 0.f;
+    hipStream_t stream() const { return stream_; }
+
+  private:
+    int launch_pass(bool dif, int load_mode, int store_mode, const NttPassArgs& a, uint32_t batch);
+    hipStream_t stream_;
+    std::map<int, fe*> roots_;
+    std::map<int, fe*> inv_small_;
+    fe* d_scalar_ = nullptr;
+};
+
+// host helpers
+fe host_primitive_root(int k);          // w of order 2^k (lambdaworks get_primitive_root_of_unity)
+std::vector<int> ntt_plan(int k, int first_stride_log);  // pass sizes r_1, r_2, ... (sum = k - first_stride_log)
+
+}  // namespace sp

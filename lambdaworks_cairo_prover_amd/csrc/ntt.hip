@@ -1,0 +1,428 @@
+// Stark252 NTT passes for gfx950. See ntt.h for the structure and DESIGN.md for the derivation of the
+// inter-pass twiddle exponent E(pos).
+#include "ntt.h"
+#include <algorithm>
+
+namespace sp {
+
+// ---------------------------------------------------------------------------------------------- device helpers
+__device__ __forceinline__ fe ld_fe(const fe* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void st_fe(fe* p, const fe& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+// LDS tile: two planes of 16-byte halves so that consecutive lanes touch consecutive 16-byte slots.
+__device__ __forceinline__ fe lds_ld(const uint4* lo, const uint4* hi, uint32_t i) {
+    uint4 a = lo[i], b = hi[i];
+    fe r;
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    return r;
+}
+__device__ __forceinline__ void lds_st(uint4* lo, uint4* hi, uint32_t i, const fe& a) {
+    lo[i] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    hi[i] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+__device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+// w_M^e from the half table (e in [0, M))
+__device__ __forceinline__ fe big_root(const fe* tw, uint32_t e, uint32_t logM) {
+    uint32_t half = 1u << (logM - 1);
+    fe w = ld_fe(tw + (e & (half - 1)));
+    return (e & half) ? fe_neg(w) : w;
+}
+
+// One four-step pass. Template flags are compile-time so each instantiation keeps only its own address math.
+template <bool DIF, int LOADM, int STOREM, bool CONTIG>
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+    const uint32_t r = a.r, g = a.g, s = a.s;
+    const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
+    uint4* Llo = smem;
+    uint4* Lhi = smem + TILE;
+    uint4* Twl = smem + 2 * TILE;            // small twiddles, R/2 entries (two planes)
+    uint4* Twh = Twl + (R >> 1);
+    const uint32_t tid = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const fe* src = a.src + (uint64_t)blockIdx.y * a.src_vec_stride;
+    fe* dst = a.dst + (uint64_t)blockIdx.y * a.dst_vec_stride;
+    const uint32_t logM = a.logM;
+
+    for (uint32_t i = tid; i < (R >> 1); i += NTT_THREADS) lds_st(Twl, Twh, i, ld_fe(a.small_tw + i));
+
+    // tile coordinates
+    uint32_t lo0 = 0, hi = 0;
+    if (!CONTIG) {
+        uint32_t lo_tiles = 1u << (s - g);
+        lo0 = (tile & (lo_tiles - 1)) << g;
+        hi = tile >> (s - g);
+    }
+    // position (in the 2^logM working array) of tile element (t, gl)
+    auto position = [&](uint32_t t, uint32_t gl) -> uint32_t {
+        if (CONTIG) {
+            if (LOADM == NTT_LOAD_GATHER_BITREV || STOREM == NTT_STORE_SCATTER_BITREV)
+                return (bitrev((tile << g) + gl, logM - r) << r) + t;   // row whose bit-reversed index is adjacent
+            return (tile << (r + g)) + (gl << r) + t;
+        }
+        return (hi << (s + r)) + (t << s) + lo0 + gl;
+    };
+    auto lidx = [&](uint32_t t, uint32_t gl) -> uint32_t { return CONTIG ? (gl << r) + t : (t << g) + gl; };
+    auto twiddle_exp = [&](uint32_t pos) -> uint32_t {
+        uint32_t e = (bitrev(pos >> s, logM - s) * ((pos >> a.s_prev) & ((1u << (s - a.s_prev)) - 1u))) << a.s_prev;
+        return a.big_neg ? ((0u - e) & ((1u << logM) - 1u)) : e;
+    };
+
+    // ------------------------------------------------------------------ load
+    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+        uint32_t t, gl;
+        fe x;
+        if (CONTIG && LOADM == NTT_LOAD_INPLACE) {
+            t = e & (R - 1); gl = e >> r;
+            x = ld_fe(src + position(t, gl));
+        } else if (CONTIG) {  // gather from the natural-order source: x[rev(pos)]
+            gl = e & (G - 1); t = e >> g;
+            uint32_t sidx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
+            x = ld_fe(src + sidx);
+        } else {
+            gl = e & (G - 1); t = e >> g;
+            uint32_t pos = position(t, gl);
+            if (LOADM == NTT_LOAD_EXPAND) x = ld_fe(src + (pos >> a.log_expand));
+            else x = ld_fe(src + pos);
+            if (!DIF) {
+                uint32_t ex = twiddle_exp(pos);
+                if (ex != 0) x = fe_mul(x, big_root(a.big_tw, ex, logM));
+            }
+        }
+        lds_st(Llo, Lhi, lidx(t, gl), x);
+    }
+    __syncthreads();
+
+    // ------------------------------------------------------------------ radix-2 stages
+    const uint32_t NB = TILE >> 1;
+    if (!DIF) {
+        for (uint32_t j = 1; j <= r; ++j) {
+            const uint32_t half = 1u << (j - 1);
+            for (uint32_t b = tid; b < NB; b += NTT_THREADS) {
+                uint32_t bf, gl;
+                if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
+                uint32_t i = bf & (half - 1);
+                uint32_t t0 = ((bf >> (j - 1)) << j) | i;
+                uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
+                fe u = lds_ld(Llo, Lhi, i0), v = lds_ld(Llo, Lhi, i1);
+                uint32_t twi = i << (r - j);
+                if (twi != 0) v = fe_mul(v, lds_ld(Twl, Twh, twi));
+                lds_st(Llo, Lhi, i0, fe_add(u, v));
+                lds_st(Llo, Lhi, i1, fe_sub(u, v));
+            }
+            __syncthreads();
+        }
+    } else {
+        for (uint32_t j = r; j >= 1; --j) {
+            const uint32_t half = 1u << (j - 1);
+            for (uint32_t b = tid; b < NB; b += NTT_THREADS) {
+                uint32_t bf, gl;
+                if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
+                uint32_t i = bf & (half - 1);
+                uint32_t t0 = ((bf >> (j - 1)) << j) | i;
+                uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
+                fe x = lds_ld(Llo, Lhi, i0), y = lds_ld(Llo, Lhi, i1);
+                fe d = fe_sub(x, y);
+                uint32_t twi = i << (r - j);
+                if (twi != 0) d = fe_mul(d, lds_ld(Twl, Twh, twi));
+                lds_st(Llo, Lhi, i0, fe_add(x, y));
+                lds_st(Llo, Lhi, i1, d);
+            }
+            __syncthreads();
+        }
+    }
+
+    // ------------------------------------------------------------------ store
+    fe scal;
+    const bool has_scalar = a.scalar != nullptr;
+    if (has_scalar) scal = ld_fe(a.scalar);
+    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
+        uint32_t t, gl;
+        if (CONTIG && STOREM == NTT_STORE_INPLACE) { t = e & (R - 1); gl = e >> r; }
+        else { gl = e & (G - 1); t = e >> g; }
+        fe x = lds_ld(Llo, Lhi, lidx(t, gl));
+        uint32_t pos = position(t, gl);
+        uint32_t didx = pos;
+        if (CONTIG && STOREM == NTT_STORE_SCATTER_BITREV) didx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
+        if (DIF && !CONTIG) {
+            uint32_t ex = twiddle_exp(pos);
+            if (ex != 0) x = fe_mul(x, big_root(a.big_tw, ex, logM));
+        }
+        if (DIF && a.post_table) x = fe_mul(x, ld_fe(a.post_table + didx));
+        if (has_scalar) x = fe_mul(x, scal);
+        st_fe(dst + didx, x);
+    }
+}
+
+// table[e] = w^e for e < count, from w^(2^i) (i < bits)
+struct RootGenArgs { fe pw[32]; };
+__global__ void gen_roots_kernel(fe* table, uint32_t count, uint32_t bits, RootGenArgs args) {
+    uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    fe acc = fe_one();
+    for (uint32_t i = 0; i < bits; ++i)
+        if ((e >> i) & 1) acc = fe_mul(acc, args.pw[i]);
+    st_fe(table + e, acc);
+}
+
+// data[i] *= base^i * c
+struct PowArgs { fe pw[40]; fe c; uint32_t has_c; };
+__global__ void scale_powers_kernel(fe* data, uint64_t n, uint64_t stride, PowArgs args) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe acc = args.has_c ? args.c : fe_one();
+    for (uint32_t b = 0; b < 40; ++b)
+        if ((i >> b) & 1) acc = fe_mul(acc, args.pw[b]);
+    fe* p = data + (uint64_t)blockIdx.y * stride + i;
+    st_fe(p, fe_mul(ld_fe(p), acc));
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+static const uint8_t TWO_ADIC_ROOT_BE[32] = {0x00, 0x52, 0x82, 0xdb, 0x87, 0x52, 0x9c, 0xfa, 0x3f, 0x04, 0x64, 0x51, 0x9c, 0x8b, 0x0f, 0xa5,
+                                             0xad, 0x18, 0x71, 0x48, 0xe1, 0x1a, 0x61, 0x61, 0x60, 0x70, 0x02, 0x4f, 0x42, 0xf8, 0xef, 0x94};
+
+fe host_primitive_root(int k) {
+    fe w = fe_from_bytes_be(TWO_ADIC_ROOT_BE);  // order 2^192
+    for (int i = k; i < 192; ++i) w = fe_sqr(w);
+    return w;
+}
+
+std::vector<int> ntt_plan(int k, int first_stride_log) {
+    // passes cover stages first_stride_log+1 .. k ; a pass at stride 0 may be NTT_MAX_CONTIG_LOG long, the others
+    // at most NTT_MAX_STRIDED_LOG; the strided remainder is split evenly.
+    std::vector<int> plan;
+    int rem = k - first_stride_log;
+    if (rem <= 0) return plan;
+    if (first_stride_log == 0) {
+        int r1 = std::min(rem, NTT_MAX_CONTIG_LOG);
+        plan.push_back(r1);
+        rem -= r1;
+    }
+    if (rem > 0) {
+        int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
+        for (int i = 0; i < np; ++i) {
+            int take = (rem + (np - i) - 1) / (np - i);
+            plan.push_back(take);
+            rem -= take;
+        }
+    }
+    return plan;
+}
+
+NttEngine::~NttEngine() {
+    for (auto& kv : roots_) (void)hipFree(kv.second);
+    for (auto& kv : inv_small_) (void)hipFree(kv.second);
+    if (d_scalar_) (void)hipFree(d_scalar_);
+}
+
+static int gen_table(hipStream_t st, fe w, int bits, uint32_t count, fe** out) {
+    fe* d = nullptr;
+    SP_HIP_CHECK(hipMalloc(&d, sizeof(fe) * (size_t)std::max<uint32_t>(count, 1)));
+    RootGenArgs args;
+    fe cur = w;
+    for (int i = 0; i < 32; ++i) { args.pw[i] = cur; cur = fe_sqr(cur); }
+    uint32_t blocks = (count + 255) / 256;
+    hipLaunchKernelGGL(gen_roots_kernel, dim3(blocks), dim3(256), 0, st, d, count, (uint32_t)bits, args);
+    SP_HIP_CHECK(hipGetLastError());
+    *out = d;
+    return SP_OK;
+}
+
+int NttEngine::roots(int k, const fe** out) {
+    auto it = roots_.find(k);
+    if (it == roots_.end()) {
+        fe* d = nullptr;
+        uint32_t count = k == 0 ? 1u : (1u << (k - 1));
+        SP_TRY(gen_table(stream_, host_primitive_root(k), k, count, &d));
+        it = roots_.emplace(k, d).first;
+    }
+    *out = it->second;
+    return SP_OK;
+}
+int NttEngine::inv_roots_small(int k, const fe** out) {
+    auto it = inv_small_.find(k);
+    if (it == inv_small_.end()) {
+        fe* d = nullptr;
+        uint32_t count = k == 0 ? 1u : (1u << (k - 1));
+        SP_TRY(gen_table(stream_, fe_inv(host_primitive_root(k)), k, count, &d));
+        it = inv_small_.emplace(k, d).first;
+    }
+    *out = it->second;
+    return SP_OK;
+}
+
+template <bool DIF, int LM, int SM, bool CONTIG>
+static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
+    uint32_t tile_log = a.r + a.g;
+    uint32_t tiles = 1u << (a.logM - tile_log);
+    size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
+    hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, a);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+int NttEngine::launch_pass(bool dif, int lm, int sm, const NttPassArgs& a, uint32_t batch) {
+    bool contig = a.s == 0;
+    if (!dif) {
+        if (contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true>(stream_, a, batch);
+        if (contig && lm == NTT_LOAD_GATHER_BITREV) return launch_t<false, NTT_LOAD_GATHER_BITREV, NTT_STORE_INPLACE, true>(stream_, a, batch);
+        if (!contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false>(stream_, a, batch);
+        if (!contig && lm == NTT_LOAD_EXPAND) return launch_t<false, NTT_LOAD_EXPAND, NTT_STORE_INPLACE, false>(stream_, a, batch);
+    } else {
+        if (contig && sm == NTT_STORE_INPLACE) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true>(stream_, a, batch);
+        if (contig && sm == NTT_STORE_SCATTER_BITREV) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_SCATTER_BITREV, true>(stream_, a, batch);
+        if (!contig) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false>(stream_, a, batch);
+    }
+    sp_set_error("ntt: unsupported pass mode");
+    return SP_E_UNSUPPORTED;
+}
+
+// Builds the pass list for a size-2^k transform. first_contig_max limits the s = 0 pass (gather/scatter passes
+// want G >= 4 rows per tile so that their strided side is coalesced).
+struct PassGeom { int s, r, g, s_prev; };
+static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max) {
+    std::vector<PassGeom> out;
+    int s = first_stride_log, s_prev = 0;
+    int rem = k - first_stride_log;
+    if (rem <= 0) return out;
+    if (s == 0) {
+        int r1 = std::min(rem, first_contig_max);
+        int g = std::min(NTT_TILE_LOG - r1, k - r1);
+        out.push_back({0, r1, g, 0});
+        s_prev = 0; s = r1; rem -= r1;
+    }
+    if (rem > 0) {
+        int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
+        for (int i = 0; i < np; ++i) {
+            int take = (rem + (np - i) - 1) / (np - i);
+            int g = std::min(NTT_STRIDED_G_LOG, s);
+            out.push_back({s, take, g, s_prev});
+            s_prev = s; s += take; rem -= take;
+        }
+    }
+    return out;
+}
+
+int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t stride) {
+    if (k == 0) return SP_OK;
+    const fe* big = nullptr;
+    SP_TRY(roots(k, &big));
+    for (const PassGeom& p : geometry(k, 0, NTT_MAX_CONTIG_LOG)) {
+        NttPassArgs a{};
+        a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
+        SP_TRY(roots(p.r, &a.small_tw));
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        SP_TRY(launch_pass(false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
+    }
+    return SP_OK;
+}
+
+int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table) {
+    const fe* big = nullptr;
+    SP_TRY(roots(k, &big));
+    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG);
+    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    for (size_t i = geo.size(); i-- > 0;) {
+        const PassGeom& p = geo[i];
+        NttPassArgs a{};
+        a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
+        SP_TRY(inv_roots_small(p.r, &a.small_tw));
+        a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        if (i == 0) a.post_table = post_table;
+        SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
+    }
+    return SP_OK;
+}
+
+int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds) {
+    const fe* big = nullptr;
+    SP_TRY(roots(k, &big));
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
+    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    bool first = true;
+    for (const PassGeom& p : geo) {
+        NttPassArgs a{};
+        a.src = first ? src : dst; a.dst = dst;
+        a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
+        SP_TRY(roots(p.r, &a.small_tw));
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        SP_TRY(launch_pass(false, first ? NTT_LOAD_GATHER_BITREV : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
+        first = false;
+    }
+    return SP_OK;
+}
+
+int NttEngine::inverse_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds) {
+    const fe* big = nullptr;
+    SP_TRY(roots(k, &big));
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
+    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    if (!d_scalar_) SP_HIP_CHECK(hipMalloc(&d_scalar_, sizeof(fe)));
+    fe ninv = fe_inv(fe_from_u64(1ULL << k));
+    SP_HIP_CHECK(hipMemcpyAsync(d_scalar_, &ninv, sizeof(fe), hipMemcpyHostToDevice, stream_));
+    for (size_t i = geo.size(); i-- > 0;) {
+        const PassGeom& p = geo[i];
+        bool firstpass = (i + 1 == geo.size());  // first executed pass reads the caller's source
+        NttPassArgs a{};
+        a.src = firstpass ? src : dst; a.dst = dst;
+        a.src_vec_stride = firstpass ? ss : ds; a.dst_vec_stride = ds;
+        SP_TRY(inv_roots_small(p.r, &a.small_tw));
+        a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        int sm = NTT_STORE_INPLACE;
+        if (i == 0) { sm = NTT_STORE_SCATTER_BITREV; a.scalar = d_scalar_; }
+        SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, sm, a, batch));
+    }
+    return SP_OK;
+}
+
+int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t ss, uint64_t ds) {
+    int K = k + logb;
+    if (logb == 0) {  // plain evaluation: copy then DIT in place
+        for (uint32_t v = 0; v < batch; ++v)
+            SP_HIP_CHECK(hipMemcpyAsync(dst + v * ds, coeffs + v * ss, sizeof(fe) << k, hipMemcpyDeviceToDevice, stream_));
+        return dit_bitrev_to_natural(dst, k, batch, ds);
+    }
+    const fe* big = nullptr;
+    SP_TRY(roots(K, &big));
+    std::vector<PassGeom> geo = geometry(K, logb, NTT_MAX_CONTIG_LOG);
+    if (geo.empty()) {  // k == 0: constant polynomial replicated
+        geo.push_back({logb, 0, std::min(logb, NTT_STRIDED_G_LOG), 0});
+    }
+    bool first = true;
+    for (const PassGeom& p : geo) {
+        NttPassArgs a{};
+        a.src = first ? coeffs : dst; a.dst = dst;
+        a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
+        SP_TRY(roots(p.r, &a.small_tw));
+        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev; a.log_expand = logb;
+        SP_TRY(launch_pass(false, first ? NTT_LOAD_EXPAND : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
+        first = false;
+    }
+    return SP_OK;
+}
+
+int NttEngine::scale_by_powers(fe* data, uint64_t n, uint32_t batch, uint64_t stride, const fe& base, const fe* c) {
+    PowArgs args;
+    fe cur = base;
+    for (int i = 0; i < 40; ++i) { args.pw[i] = cur; cur = fe_sqr(cur); }
+    args.has_c = c ? 1 : 0;
+    args.c = c ? *c : fe_one();
+    dim3 grid((unsigned)((n + 255) / 256), batch);
+    hipLaunchKernelGGL(scale_powers_kernel, grid, dim3(256), 0, stream_, data, n, stride, args);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+}  // namespace sp
