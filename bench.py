@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""bench.py — Stark252 NTT throughput (BASELINE.json configs[1]: NTT size 2^22 on one MI355X) with roofline and
+CPU-baseline objects.  One "step" = one forward natural-order NTT of 2^22 elements per GPU, inputs resident in HBM.
+
+python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU; the path
+shards by column with no data-path collective -> weak scaling, value = butterflies of all ranks / max time).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LOG_N = 22
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(log_n=20, reps=3):
+    """CPU oracle (faithful restatement of the reference's radix-2 FFT) timed on this host, 1 thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib as oracle
+    n = 1 << log_n
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
+    x[:, 0] &= 0x07
+    oracle.ntt(x[:1024])  # load + warm
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        oracle.ntt(x)
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": (n // 2) * log_n / dt, "unit": "butterflies/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} x forward NTT 2^{log_n} through oracle_ntt (includes 32-byte BE codec), single thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=LOG_N)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    from lambdaworks_cairo_prover_amd import api
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+
+    n = 1 << args.log_n
+    # synthetic input: uniformly random residues < 2^251 (< p), written directly in the device layout
+    # (8 x u32 little-endian Montgomery limbs) so that the timed region starts with the data resident in HBM.
+    g = torch.Generator(device="cpu").manual_seed(0x5EED0000 + rank)
+    host = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
+    host2 = torch.randint(0, 2, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
+    host = host | (host2 << 31)
+    host[:, 7] &= 0x07FFFFFF
+    data = host.to(dev).contiguous()
+    ctx = api.Context(device=local_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        ctx.sync()
+
+    for _ in range(args.warmup):
+        ctx.ntt_dev(data.data_ptr(), n)
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ctx.ntt_dev(data.data_ptr(), n)  # asynchronous launch + event sync inside (HIP events on the ctx stream)
+        kernel_ms.append(ctx.last_kernel_ms())
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    butterflies = (n // 2) * args.log_n
+    value = butterflies * args.steps * world / dt
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    algo_bytes = 64.0 * n  # read once + write once
+    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    out = {
+        "metric": "stark252_ntt_field_ops_per_s", "value": value, "unit": "butterflies/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
+        "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
+                   "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "traffic": None, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
+                     "mulmod_per_s": butterflies / (avg_ms * 1e-3)},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -103,15 +103,15 @@ static int ntt_dev_impl(sp_ctx* c, fe* data, uint64_t n, uint32_t batch, int inv
     // the engine's natural->natural transforms are out of place: src = data, dst = tmp, then copy back
     if (!inverse) {
         if (coset) SP_TRY(e.scale_by_powers(data, n, batch, n, h, nullptr));
-        SP_TRY(e.forward_natural(data, tmp, k, batch, n, n));
+        SP_TRY(e.forward_natural(data, tmp, k, batch, n, n, data));  // result lands back in `data`
+        return SP_OK;
     } else {
-        SP_TRY(e.inverse_natural(data, tmp, k, batch, n, n));
+        SP_TRY(e.inverse_natural(data, tmp, k, batch, n));
         if (coset) {
             if (fe_is_zero(h)) return SP_E_ZERO_INVERSE;
-            SP_TRY(e.scale_by_powers(tmp, n, batch, n, fe_inv(h), nullptr));
+            SP_TRY(e.scale_by_powers(data, n, batch, n, fe_inv(h), nullptr));
         }
     }
-    SP_HIP_CHECK(hipMemcpyAsync(data, tmp, sizeof(fe) * n * batch, hipMemcpyDeviceToDevice, c->stream));
     return SP_OK;
 }
 

@@ -57,9 +57,9 @@ class NttEngine {
     // post_table (nullable, device, 2^k entries indexed by output position) multiplies the result.
     int dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table);
     // natural -> natural forward DFT (evaluate_fft), out of place (src != dst).
-    int forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
-    // natural -> natural inverse DFT including the 1/2^k factor (interpolate_fft), out of place.
-    int inverse_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
+    int forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride, fe* final_dst = nullptr);
+    // natural -> natural inverse DFT including the 1/2^k factor (interpolate_fft); result in `data`, tmp = same-size scratch.
+    int inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_t stride);
     // LDE: coeffs = n = 2^k "h-scaled" coefficients (c_j h^j) in bit-reversed order; dst = N = n*2^logb natural-order
     // evaluations p(h w_N^i).  (zero-padded size-N DIT whose first log2(b) stages are replication.)
     int lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);

@@ -346,25 +346,37 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
     return SP_OK;
 }
 
-int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds) {
+int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds, fe* final_dst) {
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
     if (geo.empty()) geo.push_back({0, 0, 0, 0});
     bool first = true;
+    // ping-pong: pass 1 src -> dst (gather, must be out of place); if final_dst is given (same stride as src), pass 2
+    // writes dst -> final_dst and later passes run in place there, so the result lands in final_dst without a copy.
+    const fe* cur = src; uint64_t cur_stride = ss;
+    size_t pi = 0;
     for (const PassGeom& p : geo) {
         NttPassArgs a{};
-        a.src = first ? src : dst; a.dst = dst;
-        a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
+        fe* out = dst; uint64_t out_stride = ds;
+        if (final_dst && pi >= 1) { out = final_dst; out_stride = ss; }
+        a.src = cur; a.dst = out;
+        a.src_vec_stride = cur_stride; a.dst_vec_stride = out_stride;
+        cur = out; cur_stride = out_stride; ++pi;
         SP_TRY(roots(p.r, &a.small_tw));
         a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
         SP_TRY(launch_pass(false, first ? NTT_LOAD_GATHER_BITREV : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
         first = false;
     }
+    if (final_dst && geo.size() == 1)
+        for (uint32_t v = 0; v < batch; ++v)
+            SP_HIP_CHECK(hipMemcpyAsync(final_dst + v * ss, dst + v * ds, sizeof(fe) << k, hipMemcpyDeviceToDevice, stream_));
     return SP_OK;
 }
 
-int NttEngine::inverse_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds) {
+int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_t stride) {
+    // Un-passes run last-to-first: the first one goes data -> tmp, the middle ones stay in tmp, and the final
+    // bit-reversal scatter goes tmp -> data (a scatter must never run in place: other tiles still read their rows).
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
@@ -372,12 +384,17 @@ int NttEngine::inverse_natural(const fe* src, fe* dst, int k, uint32_t batch, ui
     if (!d_scalar_) SP_HIP_CHECK(hipMalloc(&d_scalar_, sizeof(fe)));
     fe ninv = fe_inv(fe_from_u64(1ULL << k));
     SP_HIP_CHECK(hipMemcpyAsync(d_scalar_, &ninv, sizeof(fe), hipMemcpyHostToDevice, stream_));
+    if (geo.size() == 1) {
+        for (uint32_t v = 0; v < batch; ++v)
+            SP_HIP_CHECK(hipMemcpyAsync(tmp + v * stride, data + v * stride, sizeof(fe) << k, hipMemcpyDeviceToDevice, stream_));
+    }
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];
-        bool firstpass = (i + 1 == geo.size());  // first executed pass reads the caller's source
+        bool firstpass = (i + 1 == geo.size()) && geo.size() > 1;
         NttPassArgs a{};
-        a.src = firstpass ? src : dst; a.dst = dst;
-        a.src_vec_stride = firstpass ? ss : ds; a.dst_vec_stride = ds;
+        a.src = firstpass ? data : tmp;
+        a.dst = (i == 0) ? data : tmp;
+        a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
         a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
         int sm = NTT_STORE_INPLACE;

@@ -1,0 +1,89 @@
+"""Parity of the fine-grained HIP entry points (the lambdaworks seam of SURVEY.md §8(b)) against the CPU oracle.
+Bit-exact: integer arithmetic mod p, compared as canonical 32-byte big-endian records."""
+import random
+
+import numpy as np
+import pytest
+
+from lambdaworks_cairo_prover_amd import api
+
+pytestmark = pytest.mark.gpu
+P = api.P
+
+
+def rand_felts(rng, n):
+    return api.felts_to_bytes([rng.randrange(P) for _ in range(n)])
+
+
+@pytest.mark.parametrize("k", [0, 1, 2, 3, 5, 8, 10, 11, 12, 13, 16, 18])
+def test_ntt_forward_inverse_matches_oracle(hip_ctx, oracle, k):
+    rng = random.Random(1000 + k)
+    x = rand_felts(rng, 1 << k)
+    want = oracle.ntt(x)
+    got = hip_ctx.ntt(x)
+    assert np.array_equal(got, want)
+    back = hip_ctx.ntt(got, inverse=True)
+    assert np.array_equal(back, x)
+    assert np.array_equal(hip_ctx.ntt(x, inverse=True), oracle.ntt(x, inverse=True))
+
+
+@pytest.mark.parametrize("k", [1, 4, 9, 12, 14])
+def test_ntt_coset_variants(hip_ctx, oracle, k):
+    rng = random.Random(2000 + k)
+    x = rand_felts(rng, 1 << k)
+    h = api.felts_to_bytes([3])
+    assert np.array_equal(hip_ctx.ntt(x, coset=h), oracle.ntt(x, coset=3))
+    assert np.array_equal(hip_ctx.ntt(x, inverse=True, coset=h), oracle.ntt(x, inverse=True, coset=3))
+
+
+def test_ntt_edge_inputs(hip_ctx, oracle):
+    # all zero, all p-1, delta
+    n = 1 << 11
+    for vals in ([0] * n, [P - 1] * n, [1] + [0] * (n - 1), [0] * (n - 1) + [P - 1]):
+        x = api.felts_to_bytes(vals)
+        assert np.array_equal(hip_ctx.ntt(x), oracle.ntt(x))
+
+
+def test_ntt_rejects_non_power_of_two(hip_ctx):
+    with pytest.raises(api.SpError):
+        hip_ctx.ntt(api.felts_to_bytes([1, 2, 3]))
+
+
+def test_ntt_2_22_properties(hip_ctx, oracle):
+    """BASELINE config #2 size: round trip and linearity (size-independent properties) + spot values vs a direct sum."""
+    rng = random.Random(22)
+    n = 1 << 22
+    raw = np.frombuffer(rng.randbytes(32 * n), dtype=np.uint8).reshape(n, 32).copy()
+    raw[:, 0] &= 0x07  # < 2^251 < p
+    y = hip_ctx.ntt(raw)
+    assert np.array_equal(hip_ctx.ntt(y, inverse=True), raw)
+    assert np.array_equal(y, oracle.ntt(raw))
+
+
+@pytest.mark.parametrize("k,blowup,cols", [(3, 2, 1), (6, 4, 3), (10, 4, 2), (12, 8, 2), (13, 16, 1)])
+def test_lde_matches_oracle(hip_ctx, oracle, k, blowup, cols):
+    rng = random.Random(3000 + k)
+    n = 1 << k
+    coeffs = np.stack([rand_felts(rng, n) for _ in range(cols)])
+    got = hip_ctx.lde(coeffs, blowup, api.felts_to_bytes([3]))
+    for j in range(cols):
+        assert np.array_equal(got[j], oracle.lde(coeffs[j], blowup, 3)), (k, blowup, j)
+
+
+@pytest.mark.parametrize("n,width", [(1, 1), (2, 1), (8, 2), (64, 18), (256, 34), (1024, 1), (512, 43), (128, 5)])
+def test_merkle_matches_oracle(hip_ctx, oracle, n, width):
+    rng = random.Random(4000 + n + width)
+    rows = rand_felts(rng, n * width).reshape(n, width, 32)
+    root, nodes = hip_ctx.merkle_build(rows, want_nodes=True)
+    oroot, onodes = oracle.merkle_build(rows, want_nodes=True)
+    assert root == oroot
+    assert np.array_equal(nodes, onodes)
+
+
+def test_batch_inverse(hip_ctx, oracle):
+    rng = random.Random(5)
+    for n in (1, 2, 63, 64, 65, 5000):
+        x = api.felts_to_bytes([rng.randrange(1, P) for _ in range(n)])
+        assert np.array_equal(hip_ctx.batch_inverse(x), oracle.batch_inverse(x))
+    with pytest.raises(api.SpError):
+        hip_ctx.batch_inverse(api.felts_to_bytes([5, 0, 7]))

@@ -50,9 +50,6 @@ __global__ void __launch_bounds__(256) bench(uint32_t* out, uint32_t seed) {
             } else if (OP == 11) {  // v_bfi / v_and_or (3-op logic)
                 asm volatile("v_bfi_b32 %0, %4, %0, %1\n\tv_bfi_b32 %1, %4, %1, %2\n\tv_bfi_b32 %2, %4, %2, %3\n\tv_bfi_b32 %3, %4, %3, %0"
                              : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
-            } else if (OP == 12) {  // v_xor3_b32
-                asm volatile("v_xor3_b32 %0, %0, %1, %4\n\tv_xor3_b32 %1, %1, %2, %4\n\tv_xor3_b32 %2, %2, %3, %4\n\tv_xor3_b32 %3, %3, %0, %4"
-                             : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));
             }
         }
     }
@@ -81,6 +78,6 @@ int main() {
     uint32_t* d; hipMalloc(&d, 256 * 8 * 256 * 4 * 4);
     run<8>("v_xor_b32", d); run<0>("v_mad_u64_u32 x4", d); run<10>("v_mad_u64_u32 chain", d); run<1>("v_mul_lo_u32", d); run<2>("v_mul_hi_u32", d);
     run<3>("v_fma_f64", d); run<4>("v_lshl_add_u64", d); run<5>("v_add_co/addc_co", d); run<6>("v_mad_u32_u24", d);
-    run<7>("v_mul_hi_u32_u24", d); run<9>("v_alignbit_b32", d); run<11>("v_bfi_b32", d); run<12>("v_xor3_b32", d);
+    run<7>("v_mul_hi_u32_u24", d); run<9>("v_alignbit_b32", d); run<11>("v_bfi_b32", d);
     return 0;
 }
