@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 rocpd SQLite outputs (kernel trace + PMC passes) into a small text table for profiles/.
+usage: rocprof_summary.py <kernel_trace.db> [<pmc.db> ...]"""
+import sqlite3
+import sys
+
+
+def main():
+    kt = sqlite3.connect(sys.argv[1])
+    print(f"# kernel trace: {sys.argv[1]}")
+    print(f"{'kernel':90s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
+    for name, calls, total, avg, pct in kt.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
+        print(f"{name[:90]:90s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}")
+    print()
+    print("# per-kernel launch geometry (first dispatch of each kernel)")
+    for row in kt.execute("select name, grid_x, grid_y, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels group by name"):
+        print("  ", row)
+    for path in sys.argv[2:]:
+        db = sqlite3.connect(path)
+        print(f"\n# PMC pass: {path}")
+        print(f"{'kernel':90s} {'counter':>12s} {'dispatches':>10s} {'avg_value':>14s}")
+        q = "select kernel_name, counter_name, count(*), avg(value) from counters_collection group by kernel_name, counter_name"
+        for name, ctr, cnt, avg in db.execute(q):
+            print(f"{name[:90]:90s} {ctr:>12s} {cnt:10d} {avg:14.1f}")
+
+
+if __name__ == "__main__":
+    main()
