@@ -100,8 +100,6 @@ int sp_sync(sp_ctx* ctx);
  * on the context stream (bench.py roofline). */
 int sp_last_kernel_ms(sp_ctx* ctx, float* ms_out);
 
-/* ---- Cairo front-end on the host (SURVEY.md §8(f) rank 3) --------------------------------------------------- */
-
 /* PublicInputs — reference src/cairo/air.rs:163-181 (HashMaps flattened to arrays). Field elements in
  * SP_FE_CANON_BE regardless of the context encoding. */
 typedef struct {
@@ -114,6 +112,69 @@ typedef struct {
     const uint8_t* public_memory;      /* (address, value) pairs, 64 bytes each */
     uint64_t num_steps;
 } sp_cairo_public_inputs;
+
+/* ---- round-level layer: one call per prover round; the Fiat-Shamir transcript stays with the
+ * caller (it is sequential Keccak over < 10 KB): roots go out, challenges come in. Field elements in the context
+ * encoding. Call order: sp_prove_setup, sp_commit_trace(0), [sp_commit_trace(1)], sp_composition, sp_ood,
+ * sp_deep_fri_commit_begin, sp_fri_fold_commit x log2(n), sp_grind, sp_open; out-of-order calls return SP_E_STATE. */
+
+/* A::new + Domain::new (reference src/starks/prover.rs:549-551, src/starks/domain.rs:20-56): sizes the device buffers
+ * for a trace of n rows (power of two), main_cols + aux_cols columns. has_rc_builtin selects the 61-column Cairo layout. */
+int sp_prove_setup(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int has_rc_builtin, const sp_proof_options* opt);
+
+/* interpolate_and_commit (prover.rs:126-159): rows = row-major n x cols trace segment (0 main, 1 auxiliary).
+ * iNTT + LDE + batched Keccak Merkle tree; keeps polynomials, LDE and tree on the device. */
+int sp_commit_trace(sp_ctx* ctx, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]);
+
+/* BoundaryConstraint (reference src/starks/constraints/boundary.rs:13-17) */
+typedef struct { uint32_t col; uint64_t step; uint8_t value[32]; } sp_boundary_constraint;
+
+/* round_2_compute_composition_polynomial (prover.rs:226-286) for the Cairo AIR: rap = 3 RAP challenges (alpha_memory,
+ * z_memory, z_range_check); coeffs = alpha^B (n_boundary), beta^B (n_boundary), alpha^T (n_transitions),
+ * beta^T (n_transitions), in the order prover.rs:597-615 samples them. Returns the [H1],[H2] root. */
+int sp_composition(sp_ctx* ctx, const uint8_t* rap, const sp_boundary_constraint* boundary, uint32_t n_boundary,
+                   const uint8_t* coeffs, uint32_t n_transitions, uint8_t root_out[32]);
+
+/* round_3 (prover.rs:288-325): out = H1(z^2), H2(z^2), then t_j(z g^k) row-major [k][j], k = 0,1: (2 + 2C) elements. */
+int sp_ood(sp_ctx* ctx, const uint8_t z[32], uint8_t* out);
+
+/* compute_deep_composition_poly + first FRI layer (prover.rs:347-378, fri/mod.rs:27-33): gammas = gamma, gamma',
+ * then the 2C trace gammas (index j*2 + k). */
+int sp_deep_fri_commit_begin(sp_ctx* ctx, const uint8_t* gammas, uint8_t root0_out[32]);
+
+/* One FRI fold + commitment (fri/mod.rs:37-67). While *is_last == 0 the output is the next layer's Merkle root; the
+ * log2(n)-th call sets *is_last = 1 and outputs fri_last_value (one field element) instead. */
+int sp_fri_fold_commit(sp_ctx* ctx, const uint8_t zeta[32], uint8_t root_or_last_out[32], int* is_last);
+
+/* generate_nonce_with_grinding (reference src/starks/grinding.rs:40-48): the smallest qualifying nonce. */
+int sp_grind(sp_ctx* ctx, const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
+
+/* fri_query_phase + open_deep_composition_poly (fri/mod.rs:74-127, prover.rs:484-529). All arrays are host memory
+ * owned by the context until the next call on it; digests are 32 bytes; field elements in the context encoding. */
+typedef struct {
+    uint32_t n_queries, n_layers, n_cols, depth0;  /* tree depth of FRI layer k is depth0 - k */
+    const uint8_t* trace_evals;     /* [q][n_cols]  trace LDE row at iota                      */
+    const uint8_t* comp_evals;      /* [q][2]       H1, H2 at iota                             */
+    const uint8_t* main_paths;      /* [q][depth0]  authentication paths, bottom-up            */
+    const uint8_t* aux_paths;       /* [q][depth0]                                              */
+    const uint8_t* comp_paths;      /* [q][depth0]                                              */
+    const uint8_t* fri_evals;       /* [q][n_layers]      layer value at iota mod |D_k|        */
+    const uint8_t* fri_evals_sym;   /* [q][n_layers]      value at the symmetric index         */
+    const uint8_t* fri_paths;       /* [q][sum_k (depth0 - k)], layers concatenated            */
+    const uint8_t* fri_paths_sym;
+} sp_openings;
+int sp_open(sp_ctx* ctx, const uint64_t* iotas, uint32_t q, sp_openings* out);
+
+/* ---- whole proof: generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + StarkProof::serialize
+ * (src/starks/proof/stark.rs:161-218). main_trace = row-major n x cols (34, or 43 with the range-check builtin) in the
+ * context encoding. *proof_out is malloc'd; release it with sp_free. The bytes equal the reference prover's. */
+int sp_cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                   const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
+void sp_free(void* p);
+/* Device time (ms, HIP events on the context stream) of rounds 0..4 of the last sp_cairo_prove. */
+int sp_last_round_ms(sp_ctx* ctx, float out[5]);
+
+/* ---- Cairo front-end on the host (SURVEY.md §8(f) rank 3) --------------------------------------------------- */
 
 typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public inputs + main trace */
 

@@ -108,6 +108,26 @@ class Context:
         check(self._lib.sp_batch_inverse(self._h, _u8p(a), ctypes.c_uint64(a.shape[0])))
         return a
 
+    # ---- whole proof -----------------------------------------------------------------------------------
+    def cairo_prove(self, main_trace, public_inputs_c, options):
+        """generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + serialize: returns the proof bytes.
+        main_trace: (n, cols, 32) uint8 in the context encoding; public_inputs_c: CairoPublicInputsC."""
+        a = np.ascontiguousarray(main_trace, dtype=np.uint8)
+        n, cols = a.shape[0], a.shape[1]
+        opt = options.to_c()
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_uint64()
+        check(self._lib.sp_cairo_prove(self._h, _u8p(a), ctypes.c_uint64(n), ctypes.c_uint32(cols), ctypes.byref(public_inputs_c),
+                                       ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln)))
+        proof = ctypes.string_at(out, ln.value)
+        self._lib.sp_free(out)
+        return proof
+
+    def last_round_ms(self):
+        ms = (ctypes.c_float * 5)()
+        check(self._lib.sp_last_round_ms(self._h, ms))
+        return list(ms)
+
     # ---- device-resident variants used by bench.py -------------------------------------------------------
     def ntt_dev(self, data_ptr, n, batch=1, inverse=False):
         check(self._lib.sp_ntt_dev(self._h, ctypes.c_void_p(data_ptr), ctypes.c_uint64(n), ctypes.c_uint32(batch), int(bool(inverse)), None))

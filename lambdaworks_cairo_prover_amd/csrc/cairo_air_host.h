@@ -1,0 +1,28 @@
+// Host-side pieces of the Cairo AIR that sit between the device rounds (reference src/cairo/air.rs):
+// CairoAIR::new (:587-658), build_auxiliary_trace (:660-729, helpers :475-572), boundary_constraints (:777-849).
+#pragma once
+#include "cairo_host.h"
+#include <vector>
+
+namespace sp {
+
+struct BoundaryConstraint { uint32_t col; uint64_t step; fe value; };
+
+struct CairoAirInfo {
+    uint32_t trace_columns, main_columns, aux_columns;
+    uint32_t num_transition_constraints;
+    bool has_rc_builtin;
+    std::vector<uint32_t> transition_degrees, transition_exemptions;
+};
+
+CairoAirInfo cairo_air_info(const PublicInputs& pub);
+
+// Row-major n x 18 auxiliary trace from the row-major n x main_cols main trace and the three RAP challenges
+// (alpha_memory, z_memory, z_range_check).
+std::vector<fe> build_auxiliary_trace(const fe* main_trace, uint64_t n, uint32_t main_cols, const PublicInputs& pub, const fe rap[3]);
+
+std::vector<BoundaryConstraint> boundary_constraints(const PublicInputs& pub, const fe rap[3], uint64_t trace_length, bool has_rc_builtin);
+
+void host_batch_inverse(std::vector<fe>& a);  // throws std::runtime_error on a zero element
+
+}  // namespace sp

@@ -1,0 +1,173 @@
+// C ABI: round-level prover entry points and the whole-proof call. See include/stark252_hip.h.
+#include "prover.h"
+#include <cstdlib>
+#include <cstring>
+
+using namespace sp;
+
+namespace {
+struct ProverHolder : public sp_deletable {
+    StarkProver prover;
+    Openings open;
+    std::vector<uint8_t> trace_evals, comp_evals, fri_evals, fri_evals_sym;
+    float round_ms[5] = {0, 0, 0, 0, 0};
+    explicit ProverHolder(sp_ctx* c) : prover(c) {}
+};
+
+ProverHolder* holder(sp_ctx* c, bool create) {
+    ProverHolder* h = dynamic_cast<ProverHolder*>(c->prover_state_deleter_holder);
+    if (!h && create) {
+        delete c->prover_state_deleter_holder;
+        h = new ProverHolder(c);
+        c->prover_state_deleter_holder = h;
+    }
+    return h;
+}
+int dec(sp_ctx* c, const uint8_t* in, uint64_t n, fe* out) { return sp_fe_to_device(c->enc, in, n, reinterpret_cast<uint8_t*>(out)); }
+int enc(sp_ctx* c, const fe* in, uint64_t n, uint8_t* out) { return sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(in), n, out); }
+
+PublicInputs to_host_pub(const sp_cairo_public_inputs* p) {
+    PublicInputs r;
+    r.pc_init = fe_from_bytes_be(p->pc_init); r.ap_init = fe_from_bytes_be(p->ap_init); r.fp_init = fe_from_bytes_be(p->fp_init);
+    r.pc_final = fe_from_bytes_be(p->pc_final); r.ap_final = fe_from_bytes_be(p->ap_final);
+    r.has_rc_min = r.has_rc_max = true;
+    r.range_check_min = p->range_check_min; r.range_check_max = p->range_check_max;
+    for (uint32_t i = 0; i < p->n_segments; ++i)
+        r.memory_segments.push_back({p->segment_types[i], p->segment_ranges[2 * i], p->segment_ranges[2 * i + 1]});
+    for (uint64_t i = 0; i < p->n_public_memory; ++i) {
+        fe a = fe_from_mont(fe_from_bytes_be(p->public_memory + 64 * i));
+        for (int k = 2; k < 8; ++k) if (a.v[k]) throw std::runtime_error("public memory address does not fit in 64 bits");
+        r.public_memory.push_back({(uint64_t)a.v[0] | ((uint64_t)a.v[1] << 32), fe_from_bytes_be(p->public_memory + 64 * i + 32)});
+    }
+    r.num_steps = p->num_steps;
+    return r;
+}
+}  // namespace
+
+extern "C" {
+
+int sp_prove_setup(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int has_rc, const sp_proof_options* opt) {
+    if (!c || !opt) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, true);
+    ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+    return h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o);
+}
+
+int sp_commit_trace(sp_ctx* c, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]) {
+    if (!c) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    if (n != h->prover.n()) return SP_E_INVALID_ARG;
+    return h->prover.commit_trace(segment, rows, cols, root_out);
+}
+
+int sp_composition(sp_ctx* c, const uint8_t* rap, const sp_boundary_constraint* bc, uint32_t nb, const uint8_t* coeffs, uint32_t T, uint8_t root_out[32]) {
+    if (!c || !rap || (!bc && nb) || !coeffs || !root_out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    try {
+        fe r[3];
+        SP_TRY(dec(c, rap, 3, r));
+        std::vector<BoundaryConstraint> bcs(nb);
+        for (uint32_t j = 0; j < nb; ++j) { bcs[j].col = bc[j].col; bcs[j].step = bc[j].step; SP_TRY(dec(c, bc[j].value, 1, &bcs[j].value)); }
+        std::vector<fe> all(2 * (size_t)(nb + T));
+        SP_TRY(dec(c, coeffs, all.size(), all.data()));
+        std::vector<fe> ba(all.begin(), all.begin() + nb), bb(all.begin() + nb, all.begin() + 2 * nb);
+        std::vector<fe> ta(all.begin() + 2 * nb, all.begin() + 2 * nb + T), tb(all.begin() + 2 * nb + T, all.end());
+        PublicInputs dummy;
+        if (T == 50) dummy.memory_segments.push_back({0, 0, 0});
+        CairoAirInfo air = cairo_air_info(dummy);
+        if (air.num_transition_constraints != T) { sp_set_error("sp_composition: the Cairo AIR has 49 (50 with the range-check builtin) transition constraints"); return SP_E_UNSUPPORTED; }
+        return h->prover.composition(r, bcs, ba, bb, ta, tb, air.transition_degrees, air.transition_exemptions, root_out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
+}
+
+int sp_ood(sp_ctx* c, const uint8_t z[32], uint8_t* out) {
+    if (!c || !z || !out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    fe zz, h1, h2;
+    SP_TRY(dec(c, z, 1, &zz));
+    std::vector<fe> tr;
+    SP_TRY(h->prover.ood(zz, &h1, &h2, tr));
+    SP_TRY(enc(c, &h1, 1, out));
+    SP_TRY(enc(c, &h2, 1, out + 32));
+    return enc(c, tr.data(), tr.size(), out + 64);
+}
+
+int sp_deep_fri_commit_begin(sp_ctx* c, const uint8_t* gammas, uint8_t root0_out[32]) {
+    if (!c || !gammas || !root0_out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    std::vector<fe> g(2 + 2 * (size_t)h->prover.cols());
+    SP_TRY(dec(c, gammas, g.size(), g.data()));
+    std::vector<fe> tg(g.begin() + 2, g.end());
+    return h->prover.deep_fri_begin(g[0], g[1], tg, root0_out);
+}
+
+int sp_fri_fold_commit(sp_ctx* c, const uint8_t zeta[32], uint8_t out[32], int* is_last) {
+    if (!c || !zeta || !out || !is_last) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    fe zt, last;
+    SP_TRY(dec(c, zeta, 1, &zt));
+    SP_TRY(h->prover.fri_fold_commit(zt, out, &last, is_last));
+    if (*is_last) return enc(c, &last, 1, out);
+    return SP_OK;
+}
+
+int sp_grind(sp_ctx* c, const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out) {
+    if (!c || !challenge || !nonce_out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, true);
+    return h->prover.grind(challenge, factor, nonce_out);
+}
+
+int sp_open(sp_ctx* c, const uint64_t* iotas, uint32_t q, sp_openings* out) {
+    if (!c || !iotas || !out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    std::vector<uint64_t> io(iotas, iotas + q);
+    SP_TRY(h->prover.open(io, h->open));
+    const Openings& o = h->open;
+    auto encv = [&](const std::vector<fe>& v, std::vector<uint8_t>& dst) { dst.resize(v.size() * 32); return enc(c, v.data(), v.size(), dst.data()); };
+    SP_TRY(encv(o.trace_evals, h->trace_evals)); SP_TRY(encv(o.comp_evals, h->comp_evals));
+    SP_TRY(encv(o.fri_evals, h->fri_evals)); SP_TRY(encv(o.fri_evals_sym, h->fri_evals_sym));
+    out->n_queries = o.n_queries; out->n_layers = o.n_layers; out->n_cols = o.n_cols; out->depth0 = o.depth0;
+    out->trace_evals = h->trace_evals.data(); out->comp_evals = h->comp_evals.data();
+    out->main_paths = reinterpret_cast<const uint8_t*>(o.main_paths.data());
+    out->aux_paths = reinterpret_cast<const uint8_t*>(o.aux_paths.data());
+    out->comp_paths = reinterpret_cast<const uint8_t*>(o.comp_paths.data());
+    out->fri_evals = h->fri_evals.data(); out->fri_evals_sym = h->fri_evals_sym.data();
+    out->fri_paths = reinterpret_cast<const uint8_t*>(o.fri_paths.data());
+    out->fri_paths_sym = reinterpret_cast<const uint8_t*>(o.fri_paths_sym.data());
+    return SP_OK;
+}
+
+int sp_cairo_prove(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                   const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    if (!c || !main_trace || !pub || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
+    try {
+        PublicInputs p = to_host_pub(pub);
+        ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+        std::vector<uint8_t> bytes;
+        float ms[5] = {0, 0, 0, 0, 0};
+        int rc = cairo_prove(c, main_trace, n, cols, p, o, bytes, ms);
+        if (rc != SP_OK) return rc;
+        std::memcpy(c->round_ms, ms, sizeof(ms));
+        *proof_out = (uint8_t*)std::malloc(bytes.size());
+        if (!*proof_out) return SP_E_ALLOC;
+        std::memcpy(*proof_out, bytes.data(), bytes.size());
+        *proof_len = bytes.size();
+        return SP_OK;
+    } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
+}
+
+void sp_free(void* p) { std::free(p); }
+
+int sp_last_round_ms(sp_ctx* c, float out[5]) {
+    if (!c || !out) return SP_E_INVALID_ARG;
+    std::memcpy(out, c->round_ms, sizeof(float) * 5);
+    return SP_OK;
+}
+
+}  // extern "C"

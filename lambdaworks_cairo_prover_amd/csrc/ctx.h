@@ -17,5 +17,6 @@ struct sp_ctx {
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     float last_ms = 0.f;
+    float round_ms[5] = {0, 0, 0, 0, 0};
     sp_deletable* prover_state_deleter_holder = nullptr;  // round-level prover state (prover.cpp)
 };

@@ -1,0 +1,624 @@
+// Round-by-round STARK prover on the device (see prover.h). Host code only: it sequences kernels on the context
+// stream, keeps every polynomial / evaluation / tree resident in HBM and moves only roots, challenges and openings.
+#include "prover.h"
+#include "keccak.h"
+#include <algorithm>
+#include <cstring>
+#include <stdexcept>
+
+namespace sp {
+
+StarkProver::~StarkProver() { free_all(); }
+
+void StarkProver::free_all() {
+    (void)hipSetDevice(c_->device);
+    (void)hipStreamSynchronize(c_->stream);
+    for (void* p : allocs_) (void)hipFree(p);
+    allocs_.clear();
+}
+
+int StarkProver::alloc(void** p, size_t bytes) {
+    *p = nullptr;
+    if (hipMalloc(p, bytes ? bytes : 1) != hipSuccess) {
+        sp_set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
+        return SP_E_ALLOC;
+    }
+    allocs_.push_back(*p);
+    return SP_OK;
+}
+
+int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc, const ProofOptionsHost& opt) {
+    int k = sp_log2_exact(n), lb = sp_log2_exact(opt.blowup_factor);
+    if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
+    if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    free_all();
+    opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
+    Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
+    h_ = fe_from_u64(opt.coset_offset);
+    if (fe_is_zero(h_)) return SP_E_INVALID_ARG;
+    hinv_ = fe_inv(h_);
+    g_ = host_primitive_root((int)logn_);
+    SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
+    SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * N_ * C_));
+    SP_TRY(alloc((void**)&d_t1_, sizeof(fe) * n_));
+    SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
+    SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
+    SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * N_ * 2));
+    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * N_ * 7));
+    SP_TRY(alloc((void**)&d_tree_main_, sizeof(digest32) * (2 * N_ - 1)));
+    SP_TRY(alloc((void**)&d_tree_aux_, sizeof(digest32) * (2 * N_ - 1)));
+    SP_TRY(alloc((void**)&d_tree_comp_, sizeof(digest32) * (2 * N_ - 1)));
+    SP_TRY(alloc((void**)&d_comp_consts_, sizeof(CompositionConsts)));
+    SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
+    SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
+    SP_TRY(alloc((void**)&d_positions_, sizeof(uint64_t) * 4096));
+    d_fri_evals_.clear(); d_fri_trees_.clear();
+    for (uint32_t l = 0; l <= logn_; ++l) {
+        fe* e = nullptr; digest32* t = nullptr;
+        uint64_t M = N_ >> l;
+        SP_TRY(alloc((void**)&e, sizeof(fe) * M));
+        d_fri_evals_.push_back(e);
+        if (l < logn_) { SP_TRY(alloc((void**)&t, sizeof(digest32) * (2 * M - 1))); d_fri_trees_.push_back(t); }
+    }
+    // T1[q] = n^-1 h^rev(q): turns the unscaled DIF output into h-scaled coefficients c_k h^k (bit-reversed order)
+    fe ninv = fe_inv(fe_from_u64(n_));
+    SP_TRY(gen_power_table(c_->stream, d_t1_, n_, logn_, h_, ninv));
+    // T2[q] = N^-1 h^-rev(q): composition-polynomial split
+    fe Ninv = fe_inv(fe_from_u64(N_));
+    SP_TRY(gen_power_table(c_->stream, d_t2_, n_, logn_, hinv_, Ninv));
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    stage_ = 1;
+    return SP_OK;
+}
+
+int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]) {
+    SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree));
+    SP_TRY(merkle_reduce(c_->stream, tree, N_));
+    SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    return SP_OK;
+}
+
+int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+    if (!rows_host || !root_out) return SP_E_INVALID_ARG;
+    if (!((segment == 0 && stage_ == 1 && cols == Cm_) || (segment == 1 && stage_ == 2 && cols == Ca_))) {
+        sp_set_error("commit_trace: wrong segment order or column count");
+        return SP_E_STATE;
+    }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
+    uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * N_);
+    SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
+    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
+    SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
+    // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients
+    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_));
+    // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
+    fe* lde = d_lde_ + (uint64_t)col0 * N_;
+    SP_TRY(c_->ntt->lde_from_bitrev(coeffs, lde, (int)logn_, (int)logb_, cols, n_, N_));
+    // batch_commit (reference prover.rs:96-104) straight from the column-major LDE
+    SP_TRY(commit_columns(lde, N_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
+    stage_ = segment == 0 ? 2 : 3;
+    return SP_OK;
+}
+
+int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
+                             const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
+                             const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint8_t root_out[32]) {
+    if (stage_ != 3 && !(stage_ == 2 && Ca_ == 0)) { sp_set_error("composition: trace segments not committed"); return SP_E_STATE; }
+    const uint32_t T = (uint32_t)t_alpha.size(), B = (uint32_t)bcs.size();
+    if (T > CAIRO_MAX_TRANSITIONS || B > CAIRO_MAX_BOUNDARY || t_beta.size() != T || b_alpha.size() != B || b_beta.size() != B ||
+        degrees.size() != T || exemptions.size() != T) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint32_t b = 1u << logb_;
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    // --- boundary denominators: distinct steps -> points g^step
+    std::vector<uint64_t> steps;
+    CompositionConsts K;
+    std::memset(&K, 0, sizeof(K));
+    for (uint32_t j = 0; j < B; ++j) {
+        auto it = std::find(steps.begin(), steps.end(), bcs[j].step);
+        if (it == steps.end()) { steps.push_back(bcs[j].step); it = steps.end() - 1; }
+        K.bden[j] = (uint32_t)(it - steps.begin());
+        K.bcol[j] = bcs[j].col;
+        K.bvalue[j] = bcs[j].value;
+        if (bcs[j].col >= C_) return SP_E_INVALID_ARG;
+    }
+    if (steps.size() > 3) { sp_set_error("composition: more than 3 distinct boundary steps"); return SP_E_UNSUPPORTED; }
+    std::vector<fe> points;
+    for (uint64_t s : steps) points.push_back(fe_pow_u64(g_, s));
+    fe* binv = d_scratch_;                 // [ndist][N]
+    fe* inv_scratch = d_scratch_ + 3 * N_;  // [3N]
+    fe* comp = d_scratch_ + 6 * N_;         // [N]
+    const uint32_t nd = (uint32_t)points.size();
+    if (nd) {
+        SP_TRY(coset_minus_points(c_->stream, binv, N_, logN_, roots, h_, points.data(), nd));
+        SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+        SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * N_, c_->d_flag));
+    }
+    // --- per-coset constants: x^n takes b values h^n w_b^c (reference evaluator.rs:156-171)
+    K.h = h_;
+    K.rap[0] = rap[0]; K.rap[1] = rap[1]; K.rap[2] = rap[2];
+    K.g_last = fe_pow_u64(g_, n_ - 1);
+    K.two = fe_from_u64(2);
+    K.b15 = fe_from_u64(1ULL << 15); K.b16 = fe_from_u64(1ULL << 16); K.b32 = fe_from_u64(1ULL << 32); K.b48 = fe_from_u64(1ULL << 48);
+    K.n_boundary = B; K.n_transitions = T; K.main_cols = Cm_; K.has_rc_builtin = has_rc_ ? 1 : 0;
+    {
+        fe hn = fe_pow_u64(h_, n_);
+        fe wb = host_primitive_root((int)logb_);
+        std::vector<fe> zf(b);
+        fe xn = hn;
+        for (uint32_t c = 0; c < b; ++c) {
+            // degree adjustment x^(D - n(deg-1)) with D = 2n (reference cairo/air.rs:855-857): (x^n)^(3-deg)
+            fe pw[4];
+            pw[0] = fe_one(); pw[1] = xn; pw[2] = fe_sqr(xn); pw[3] = fe_mul(pw[2], xn);
+            for (uint32_t k = 0; k < T; ++k) {
+                if (degrees[k] < 1 || degrees[k] > 3) return SP_E_UNSUPPORTED;
+                K.coef[c][k] = fe_add(fe_mul(t_alpha[k], pw[3 - degrees[k]]), t_beta[k]);
+                if (exemptions[k] > 1) return SP_E_UNSUPPORTED;
+            }
+            for (uint32_t j = 0; j < B; ++j) K.coef[c][T + j] = fe_add(fe_mul(b_alpha[j], xn), b_beta[j]);
+            zf[c] = fe_sub(xn, fe_one());
+            xn = fe_mul(xn, wb);
+        }
+        host_batch_inverse(zf);
+        for (uint32_t c = 0; c < b; ++c) K.zerofier[c] = zf[c];
+    }
+    // the kernel hard-codes which Cairo constraints are exempted / selector-gated; check the caller agrees
+    {
+        CairoAirInfo ref;
+        PublicInputs dummy;
+        if (has_rc_) dummy.memory_segments.push_back({0, 0, 0});
+        ref = cairo_air_info(dummy);
+        if (ref.transition_degrees != degrees || ref.transition_exemptions != exemptions) {
+            sp_set_error("composition: only the Cairo AIR constraint set is implemented on the device");
+            return SP_E_UNSUPPORTED;
+        }
+    }
+    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
+    SP_TRY(cairo_composition(c_->stream, d_lde_, N_, logN_, logb_, roots, d_comp_consts_, binv, comp));
+    // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
+    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
+    SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
+    SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, N_));
+    SP_TRY(commit_columns(d_h12_, N_, 2, d_tree_comp_, root_out));
+    int flag = 0;
+    SP_HIP_CHECK(hipMemcpy(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+    stage_ = 4;
+    return SP_OK;
+}
+
+// sum_q A[q] y^rev(q) for `vectors` arrays of 2^k elements and `points` points, by repeated folding
+// (DESIGN.md "Out-of-domain evaluation"): one level maps M elements to M >> l.
+// scratch: at least 3 * 2^k elements (two ping-pong buffers and the per-level power tables).
+static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_t vectors, uint32_t k, const std::vector<fe>& ys,
+                       fe* scratch, uint64_t scratch_elems, std::vector<fe>& out /*[vectors][points]*/) {
+    const uint32_t points = (uint32_t)ys.size();
+    std::vector<fe> ycur = ys;
+    const fe* in = arrays;
+    uint64_t in_stride = vec_stride;
+    uint32_t in_points = 1;
+    uint64_t M = 1ULL << k;
+    const uint64_t level1 = (uint64_t)vectors * points * (M >> std::min<uint32_t>(8, k));
+    if (2 * level1 + (uint64_t)points * 256 > scratch_elems) { sp_set_error("eval_bitrev: scratch too small"); return SP_E_ALLOC; }
+    fe* bufs[2] = {scratch, scratch + level1};
+    fe* yp_dev = scratch + 2 * level1;
+    int which = 0;
+    if (k == 0) {
+        out.resize((size_t)vectors * points);
+        for (uint32_t v = 0; v < vectors; ++v) {
+            fe t;
+            SP_HIP_CHECK(hipMemcpy(&t, arrays + v * vec_stride, sizeof(fe), hipMemcpyDeviceToHost));
+            for (uint32_t p = 0; p < points; ++p) out[v * points + p] = t;
+        }
+        return SP_OK;
+    }
+    while (M > 1) {
+        const uint32_t kk = (uint32_t)sp_log2_exact(M);
+        const uint32_t l = std::min<uint32_t>(8, kk);
+        const uint32_t Tn = 1u << l;
+        std::vector<fe> yp((size_t)points * Tn);
+        for (uint32_t p = 0; p < points; ++p) {
+            std::vector<fe> pw(Tn);
+            pw[0] = fe_one();
+            for (uint32_t e = 1; e < Tn; ++e) pw[e] = fe_mul(pw[e - 1], ycur[p]);
+            for (uint32_t t = 0; t < Tn; ++t) {  // yp[t] = y^rev_l(t)
+                uint32_t r = 0;
+                for (uint32_t bit = 0; bit < l; ++bit) if ((t >> bit) & 1) r |= 1u << (l - 1 - bit);
+                yp[(size_t)p * Tn + t] = pw[r];
+            }
+            fe y2 = ycur[p];
+            for (uint32_t s = 0; s < l; ++s) y2 = fe_sqr(y2);
+            ycur[p] = y2;
+        }
+        SP_HIP_CHECK(hipMemcpyAsync(yp_dev, yp.data(), yp.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp is a local vector
+        fe* outb = bufs[which];
+        SP_TRY(fold_eval_level(c->stream, in, in_stride, in_points, M, l, yp_dev, points, vectors, outb));
+        SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp_dev is rewritten by the next level
+        M >>= l;
+        in = outb; in_stride = (uint64_t)points * M; in_points = points;
+        which ^= 1;
+    }
+    out.resize((size_t)vectors * points);
+    SP_HIP_CHECK(hipMemcpyAsync(out.data(), in, out.size() * sizeof(fe), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return SP_OK;
+}
+
+int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_ood) {
+    if (stage_ != 4) { sp_set_error("ood: composition polynomial not committed"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    z_ = z;
+    // stored coefficients are c_k h^k, so evaluate at y / h (reference prover.rs:301-304, frame.rs:67-83)
+    std::vector<fe> ys = {fe_mul(z, hinv_), fe_mul(fe_mul(z, g_), hinv_)};
+    std::vector<fe> tr;
+    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, 7 * N_, tr));
+    trace_ood.resize(2 * (size_t)C_);
+    for (uint32_t j = 0; j < C_; ++j) { trace_ood[j] = tr[j * 2 + 0]; trace_ood[C_ + j] = tr[j * 2 + 1]; }
+    std::vector<fe> yh = {fe_mul(fe_sqr(z), hinv_)};
+    std::vector<fe> hv;
+    SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, 7 * N_, hv));
+    h1_z2_ = hv[0]; h2_z2_ = hv[1];
+    *h1_z2 = hv[0]; *h2_z2 = hv[1];
+    trace_ood_ = trace_ood;
+    stage_ = 5;
+    return SP_OK;
+}
+
+int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::vector<fe>& tg, uint8_t root0_out[32]) {
+    if (stage_ != 5) { sp_set_error("deep_fri_begin: out-of-domain evaluations missing"); return SP_E_STATE; }
+    if (tg.size() != 2 * (size_t)C_) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    DeepConsts K;
+    std::memset(&K, 0, sizeof(K));
+    K.gamma_h1 = gamma; K.gamma_h2 = gamma_p;
+    K.c_h = fe_add(fe_mul(gamma, h1_z2_), fe_mul(gamma_p, h2_z2_));
+    K.cols = C_;
+    K.c_t[0] = fe_zero(); K.c_t[1] = fe_zero();
+    for (uint32_t j = 0; j < C_; ++j)
+        for (uint32_t k = 0; k < 2; ++k) {
+            K.gammas[k][j] = tg[j * 2 + k];  // reference prover.rs:457-476: gamma index = j * frame_len + k
+            K.c_t[k] = fe_add(K.c_t[k], fe_mul(tg[j * 2 + k], trace_ood_[k * C_ + j]));
+        }
+    SP_HIP_CHECK(hipMemcpyAsync(d_deep_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    fe pts[3] = {z_, fe_mul(z_, g_), fe_sqr(z_)};
+    fe* inv = d_scratch_;
+    fe* inv_scratch = d_scratch_ + 3 * N_;
+    SP_TRY(coset_minus_points(c_->stream, inv, N_, logN_, roots, h_, pts, 3));
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * N_, c_->d_flag));
+    SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + N_, N_, d_deep_consts_, inv, d_fri_evals_[0]));
+    // FRI layer 0 (reference fri/mod.rs:27-33)
+    fri_layer_ = 0;
+    fri_offset_ = h_;
+    SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[0], N_, 1, N_, d_fri_trees_[0]));
+    SP_TRY(merkle_reduce(c_->stream, d_fri_trees_[0], N_));
+    SP_HIP_CHECK(hipMemcpyAsync(root0_out, d_fri_trees_[0], 32, hipMemcpyDeviceToHost, c_->stream));
+    int flag = 0;
+    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    if (flag) { sp_set_error("deep composition: z lies on the LDE coset"); return SP_E_ZERO_INVERSE; }
+    fri_layer_ = 1;
+    stage_ = 6;
+    return SP_OK;
+}
+
+int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_value, int* is_last) {
+    if (stage_ != 6) { sp_set_error("fri_fold_commit: FRI not started or already finished"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    const uint32_t k = fri_layer_ - 1;  // layer being folded
+    const uint64_t M = N_ >> k;
+    fe half = fe_inv(fe_from_u64(2));
+    fe cst = fe_mul(fe_mul(zeta, half), fe_inv(fri_offset_));
+    SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half, cst));
+    fri_offset_ = fe_sqr(fri_offset_);
+    if (k + 1 < logn_) {
+        uint64_t Mn = M >> 1;
+        SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], Mn, 1, Mn, d_fri_trees_[k + 1]));
+        SP_TRY(merkle_reduce(c_->stream, d_fri_trees_[k + 1], Mn));
+        SP_HIP_CHECK(hipMemcpyAsync(root_out, d_fri_trees_[k + 1], 32, hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        fri_layer_ += 1;
+        *is_last = 0;
+    } else {
+        // the log2(n)-th fold leaves a constant polynomial: every remaining evaluation equals it (fri/mod.rs:58-67)
+        SP_HIP_CHECK(hipMemcpyAsync(last_value, d_fri_evals_[k + 1], sizeof(fe), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        *is_last = 1;
+        stage_ = 7;
+    }
+    return SP_OK;
+}
+
+int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out) {
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint64_t batch = 1ULL << 22;
+    unsigned long long init = ~0ULL;
+    SP_HIP_CHECK(hipMemcpyAsync(d_nonce_, &init, sizeof(init), hipMemcpyHostToDevice, c_->stream));
+    for (uint64_t start = 0;; start += batch) {
+        SP_TRY(grind_range(c_->stream, challenge, factor, start, batch, d_nonce_));
+        unsigned long long r = 0;
+        SP_HIP_CHECK(hipMemcpyAsync(&r, d_nonce_, sizeof(r), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        if (r != ~0ULL) { *nonce_out = r; return SP_OK; }
+        if (start > (1ULL << 40)) { sp_set_error("grind: nonce not found"); return SP_E_UNSUPPORTED; }
+    }
+}
+
+int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
+    if (stage_ != 7) { sp_set_error("open: FRI commit phase not finished"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint32_t q = (uint32_t)iotas.size();
+    if (q == 0 || q > 1024) return SP_E_INVALID_ARG;
+    const uint32_t L = logn_, d0 = logN_;
+    o.n_queries = q; o.n_layers = L; o.n_cols = C_; o.depth0 = d0;
+    hipStream_t st = c_->stream;
+    // device staging inside the scratch area
+    uint8_t* base = reinterpret_cast<uint8_t*>(d_scratch_);
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { void* p = base + off; off += (bytes + 255) & ~size_t(255); return p; };
+    std::vector<uint64_t> pos(q);
+    for (uint32_t s = 0; s < q; ++s) pos[s] = iotas[s] % N_;
+    SP_HIP_CHECK(hipMemcpyAsync(d_positions_, pos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    fe* g_trace = (fe*)carve(sizeof(fe) * q * C_);
+    fe* g_comp = (fe*)carve(sizeof(fe) * q * 2);
+    digest32* p_main = (digest32*)carve(sizeof(digest32) * q * d0);
+    digest32* p_aux = (digest32*)carve(sizeof(digest32) * q * d0);
+    digest32* p_comp = (digest32*)carve(sizeof(digest32) * q * d0);
+    SP_TRY(gather_rows(st, d_lde_, N_, C_, d_positions_, q, g_trace));
+    SP_TRY(gather_rows(st, d_h12_, N_, 2, d_positions_, q, g_comp));
+    SP_TRY(merkle_gather_paths(st, d_tree_main_, N_, d_positions_, q, p_main));
+    if (Ca_) SP_TRY(merkle_gather_paths(st, d_tree_aux_, N_, d_positions_, q, p_aux));
+    SP_TRY(merkle_gather_paths(st, d_tree_comp_, N_, d_positions_, q, p_comp));
+    o.trace_evals.resize((size_t)q * C_); o.comp_evals.resize((size_t)q * 2);
+    o.main_paths.resize((size_t)q * d0); o.aux_paths.resize((size_t)q * d0); o.comp_paths.resize((size_t)q * d0);
+    SP_HIP_CHECK(hipMemcpyAsync(o.trace_evals.data(), g_trace, sizeof(fe) * q * C_, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipMemcpyAsync(o.comp_evals.data(), g_comp, sizeof(fe) * q * 2, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipMemcpyAsync(o.main_paths.data(), p_main, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
+    if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(o.aux_paths.data(), p_aux, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipMemcpyAsync(o.comp_paths.data(), p_comp, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipStreamSynchronize(st));
+    // FRI layers (reference fri/mod.rs:74-127): index iota mod |D_k| and its symmetric index
+    size_t path_total = 0;
+    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
+    o.fri_evals.assign((size_t)q * L, fe_zero()); o.fri_evals_sym.assign((size_t)q * L, fe_zero());
+    o.fri_paths.assign((size_t)q * path_total, digest32{}); o.fri_paths_sym.assign((size_t)q * path_total, digest32{});
+    std::vector<fe> ev(q), evs(q);
+    size_t path_off = 0;
+    for (uint32_t k = 0; k < L; ++k) {
+        const uint64_t M = N_ >> k;
+        const uint32_t depth = d0 - k;
+        std::vector<uint64_t> idx(2 * q);
+        for (uint32_t s = 0; s < q; ++s) { idx[s] = iotas[s] % M; idx[q + s] = (iotas[s] + M / 2) % M; }
+        off = 0;
+        fe* gv = (fe*)carve(sizeof(fe) * 2 * q);
+        digest32* gp = (digest32*)carve(sizeof(digest32) * 2 * q * depth);
+        SP_HIP_CHECK(hipMemcpyAsync(d_positions_, idx.data(), 2 * q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        SP_TRY(gather_rows(st, d_fri_evals_[k], M, 1, d_positions_, 2 * q, gv));
+        SP_TRY(merkle_gather_paths(st, d_fri_trees_[k], M, d_positions_, 2 * q, gp));
+        std::vector<fe> hv(2 * q);
+        std::vector<digest32> hp((size_t)2 * q * depth);
+        SP_HIP_CHECK(hipMemcpyAsync(hv.data(), gv, sizeof(fe) * 2 * q, hipMemcpyDeviceToHost, st));
+        SP_HIP_CHECK(hipMemcpyAsync(hp.data(), gp, sizeof(digest32) * 2 * q * depth, hipMemcpyDeviceToHost, st));
+        SP_HIP_CHECK(hipStreamSynchronize(st));
+        for (uint32_t s = 0; s < q; ++s) {
+            o.fri_evals[(size_t)s * L + k] = hv[s];
+            o.fri_evals_sym[(size_t)s * L + k] = hv[q + s];
+            std::copy(hp.begin() + (size_t)s * depth, hp.begin() + (size_t)(s + 1) * depth, o.fri_paths.begin() + (size_t)s * path_total + path_off);
+            std::copy(hp.begin() + (size_t)(q + s) * depth, hp.begin() + (size_t)(q + s + 1) * depth, o.fri_paths_sym.begin() + (size_t)s * path_total + path_off);
+        }
+        path_off += depth;
+    }
+    return SP_OK;
+}
+
+// ============================================================================================ whole proof (host driver)
+namespace {
+
+// DefaultTranscript of lambdaworks-crypto @ a17b951 and the sampling rules of
+// reference src/starks/transcript.rs:13-79.
+struct HostTranscript {
+    std::vector<uint8_t> buf;
+    void append(const uint8_t* d, size_t n) { buf.insert(buf.end(), d, d + n); }
+    void append_felt(const fe& x) { uint8_t b[32]; fe_to_bytes_be(x, b); append(b, 32); }
+    void challenge(uint8_t out[32]) {
+        uint8_t d[32];
+        sp_keccak256_host(buf.data(), buf.size(), d);
+        for (int i = 0; i < 32; ++i) out[i] = d[31 - i];
+        buf.assign(out, out + 32);
+    }
+    fe to_field() {
+        uint8_t r[32];
+        challenge(r);
+        r[0] &= 0x07;  // 251 random bits (transcript.rs:24-43)
+        return fe_from_bytes_be(r);
+    }
+    uint64_t to_usize() {
+        uint8_t r[32];
+        challenge(r);
+        uint64_t v = 0;
+        for (int i = 0; i < 8; ++i) v = (v << 8) | r[i];
+        return v;
+    }
+};
+
+struct ProofWriter {
+    std::vector<uint8_t> b;
+    void u64(uint64_t v) { for (int i = 7; i >= 0; --i) b.push_back((uint8_t)(v >> (8 * i))); }
+    void felt(const fe& x) { uint8_t t[32]; fe_to_bytes_be(x, t); b.insert(b.end(), t, t + 32); }
+    void digest(const digest32& d) { const uint8_t* p = reinterpret_cast<const uint8_t*>(d.w); b.insert(b.end(), p, p + 32); }
+    void raw(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
+    void path(const digest32* p, uint32_t depth) { u64(depth); for (uint32_t i = 0; i < depth; ++i) digest(p[i]); }
+    void bytes(const std::vector<uint8_t>& v) { b.insert(b.end(), v.begin(), v.end()); }
+};
+
+bool z_in_domains(const fe& z, const fe& hinv, uint32_t logn, uint32_t logN) {  // transcript.rs:53-69
+    fe a = fe_mul(z, hinv), b = z;
+    for (uint32_t i = 0; i < logN; ++i) a = fe_sqr(a);
+    for (uint32_t i = 0; i < logn; ++i) b = fe_sqr(b);
+    return fe_eq(a, fe_one()) || fe_eq(b, fe_one());
+}
+
+}  // namespace
+
+int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5]) {
+    try {
+        CairoAirInfo air = cairo_air_info(pub);
+        if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
+        StarkProver* P = new StarkProver(ctx);
+        delete ctx->prover_state_deleter_holder;
+        ctx->prover_state_deleter_holder = P;
+        hipEvent_t ev[6];
+        for (auto& e : ev) SP_HIP_CHECK(hipEventCreate(&e));
+        SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
+        HostTranscript tr;
+        uint8_t root[32];
+        // ---- round 1 (reference prover.rs:187-224)
+        SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+        SP_TRY(P->commit_trace(0, main_trace, cols, root));
+        uint8_t main_root[32]; std::memcpy(main_root, root, 32);
+        tr.append(root, 32);
+        fe rap[3] = {tr.to_field(), tr.to_field(), tr.to_field()};
+        std::vector<fe> main_fe((size_t)n * cols);
+        SP_TRY(sp_fe_to_device(ctx->enc, main_trace, n * cols, reinterpret_cast<uint8_t*>(main_fe.data())));
+        std::vector<fe> aux = build_auxiliary_trace(main_fe.data(), n, cols, pub, rap);
+        main_fe.clear(); main_fe.shrink_to_fit();
+        std::vector<uint8_t> aux_abi(aux.size() * 32);
+        SP_TRY(sp_fe_from_device(ctx->enc, reinterpret_cast<const uint8_t*>(aux.data()), aux.size(), aux_abi.data()));
+        SP_TRY(P->commit_trace(1, aux_abi.data(), air.aux_columns, root));
+        uint8_t aux_root[32]; std::memcpy(aux_root, root, 32);
+        tr.append(root, 32);
+        aux.clear(); aux_abi.clear();
+        SP_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
+        // ---- round 2 (reference prover.rs:597-635)
+        std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
+        const uint32_t T = air.num_transition_constraints;
+        std::vector<fe> b_alpha(bcs.size()), b_beta(bcs.size()), t_alpha(T), t_beta(T);
+        for (auto& x : b_alpha) x = tr.to_field();
+        for (auto& x : b_beta) x = tr.to_field();
+        for (auto& x : t_alpha) x = tr.to_field();
+        for (auto& x : t_beta) x = tr.to_field();
+        SP_TRY(P->composition(rap, bcs, b_alpha, b_beta, t_alpha, t_beta, air.transition_degrees, air.transition_exemptions, root));
+        uint8_t comp_root[32]; std::memcpy(comp_root, root, 32);
+        tr.append(root, 32);
+        SP_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
+        // ---- round 3 (reference prover.rs:652-684)
+        const uint32_t logn = (uint32_t)sp_log2_exact(n), logN = logn + (uint32_t)sp_log2_exact(opt.blowup_factor);
+        fe hinv = fe_inv(fe_from_u64(opt.coset_offset));
+        fe z;
+        do { z = tr.to_field(); } while (z_in_domains(z, hinv, logn, logN));
+        fe h1z, h2z;
+        std::vector<fe> ood;
+        SP_TRY(P->ood(z, &h1z, &h2z, ood));
+        tr.append_felt(h1z); tr.append_felt(h2z);
+        for (auto& e : ood) tr.append_felt(e);
+        SP_HIP_CHECK(hipEventRecord(ev[3], ctx->stream));
+        // ---- round 4 (reference prover.rs:327-404)
+        fe gamma = tr.to_field(), gamma_p = tr.to_field();
+        std::vector<fe> tg(2 * (size_t)P->cols());
+        for (auto& x : tg) x = tr.to_field();
+        SP_TRY(P->deep_fri_begin(gamma, gamma_p, tg, root));
+        std::vector<std::vector<uint8_t>> fri_roots;
+        fri_roots.emplace_back(root, root + 32);
+        tr.append(root, 32);
+        fe last_value;
+        for (;;) {
+            fe zeta = tr.to_field();
+            int is_last = 0;
+            SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
+            if (is_last) break;
+            fri_roots.emplace_back(root, root + 32);
+            tr.append(root, 32);
+        }
+        tr.append_felt(last_value);
+        uint8_t gch[32];
+        tr.challenge(gch);
+        uint64_t nonce = 0;
+        SP_TRY(P->grind(gch, opt.grinding_factor, &nonce));
+        {
+            uint8_t nb[8];
+            for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
+            tr.append(nb, 8);
+        }
+        std::vector<uint64_t> iotas(opt.fri_number_of_queries);
+        for (auto& x : iotas) x = tr.to_usize() % P->N();
+        Openings o;
+        SP_TRY(P->open(iotas, o));
+        SP_HIP_CHECK(hipEventRecord(ev[4], ctx->stream));
+        SP_HIP_CHECK(hipEventSynchronize(ev[4]));
+        if (round_ms) {
+            round_ms[0] = 0.f;
+            for (int r = 0; r < 4; ++r) SP_HIP_CHECK(hipEventElapsedTime(&round_ms[r + 1], ev[r], ev[r + 1]));
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        // ---- serialization (reference proof/stark.rs:161-218, fri/fri_decommit.rs:24-45, frame.rs:86-106)
+        const uint32_t C = P->cols(), L = o.n_layers, d0 = o.depth0;
+        ProofWriter w;
+        w.u64(n);
+        w.u64(2); w.raw(main_root, 32); w.raw(aux_root, 32);
+        {
+            ProofWriter f;
+            f.u64(ood.size()); f.u64(32);
+            for (auto& e : ood) f.felt(e);
+            f.u64(C);
+            w.u64(f.b.size()); w.bytes(f.b);
+        }
+        w.raw(comp_root, 32);
+        w.u64(32); w.felt(h1z); w.felt(h2z);
+        w.u64(fri_roots.size());
+        for (auto& r : fri_roots) w.raw(r.data(), 32);
+        w.felt(last_value);
+        size_t path_total = 0;
+        for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
+        w.u64(iotas.size());
+        for (size_t s = 0; s < iotas.size(); ++s) {
+            ProofWriter qw;
+            qw.u64(L);
+            size_t po = 0;
+            for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
+            qw.u64(32);
+            qw.u64(L);
+            for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals_sym[s * L + k]);
+            qw.u64(L);
+            for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals[s * L + k]);
+            qw.u64(L);
+            po = 0;
+            for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
+            w.u64(qw.b.size()); w.bytes(qw.b);
+        }
+        w.u64(iotas.size());
+        for (size_t s = 0; s < iotas.size(); ++s) {
+            ProofWriter ow;
+            ow.path(&o.comp_paths[s * d0], d0);
+            ow.u64(32);
+            ow.felt(o.comp_evals[s * 2]); ow.felt(o.comp_evals[s * 2 + 1]);
+            ow.u64(2);
+            ow.path(&o.main_paths[s * d0], d0);
+            ow.path(&o.aux_paths[s * d0], d0);
+            ow.u64(C);
+            for (uint32_t j = 0; j < C; ++j) ow.felt(o.trace_evals[s * C + j]);
+            w.u64(ow.b.size()); w.bytes(ow.b);
+        }
+        w.u64(nonce);
+        proof_out.swap(w.b);
+        return SP_OK;
+    } catch (const std::exception& e) {
+        sp_set_error(std::string("cairo_prove: ") + e.what());
+        return SP_E_INVALID_ARG;
+    }
+}
+
+}  // namespace sp

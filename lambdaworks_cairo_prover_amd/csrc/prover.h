@@ -1,0 +1,81 @@
+// Device-resident STARK prover state: one object per proof, driven round by round (the transcript stays on the
+// host; roots go out, challenges come in).  Mirrors the round structure of reference src/starks/prover.rs:532-766.
+#pragma once
+#include "ctx.h"
+#include "stark_kernels.h"
+#include "cairo_air_host.h"
+#include <vector>
+
+namespace sp {
+
+struct ProofOptionsHost { uint8_t blowup_factor; uint64_t fri_number_of_queries; uint64_t coset_offset; uint8_t grinding_factor; };
+
+struct Openings {
+    uint32_t n_queries = 0, n_layers = 0, n_cols = 0, depth0 = 0;
+    std::vector<fe> trace_evals, comp_evals;                     // [q][C], [q][2]
+    std::vector<digest32> main_paths, aux_paths, comp_paths;     // [q][depth0]
+    std::vector<fe> fri_evals, fri_evals_sym;                    // [q][L]
+    std::vector<digest32> fri_paths, fri_paths_sym;              // [q][sum_k (depth0-k)]
+};
+
+class StarkProver : public sp_deletable {
+  public:
+    StarkProver(sp_ctx* ctx) : c_(ctx) {}
+    ~StarkProver() override;
+
+    int setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
+    // round 1: interpolate + LDE + Merkle of one trace segment (0 = main, 1 = aux); rows = row-major n x cols, ABI encoding
+    int commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    // round 2: constraint composition, H1/H2 split, LDE and commitment
+    int composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
+                    const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
+                    const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint8_t root_out[32]);
+    // round 3: H1(z^2), H2(z^2), t_j(z g^k) for k = 0,1 (row-major [k][j])
+    int ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_ood);
+    // round 4
+    int deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::vector<fe>& trace_gammas /*[j*2+k]*/, uint8_t root0_out[32]);
+    int fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_value, int* is_last);
+    int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
+    int open(const std::vector<uint64_t>& iotas, Openings& out);
+
+    uint64_t n() const { return n_; }
+    uint64_t N() const { return N_; }
+    uint32_t cols() const { return C_; }
+    uint32_t fri_layers() const { return logn_; }
+    // per-round device time of the last proof (ms, hipEvent)
+    float round_ms[5] = {0, 0, 0, 0, 0};
+
+  private:
+    void free_all();
+    int alloc(void** p, size_t bytes);
+    int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]);
+
+    sp_ctx* c_;
+    ProofOptionsHost opt_{};
+    uint64_t n_ = 0, N_ = 0;
+    uint32_t logn_ = 0, logb_ = 0, logN_ = 0, Cm_ = 0, Ca_ = 0, C_ = 0;
+    bool has_rc_ = false;
+    fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
+    std::vector<void*> allocs_;
+    fe *d_coeffs_ = nullptr, *d_lde_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr;
+    fe *d_h12s_ = nullptr, *d_h12_ = nullptr, *d_scratch_ = nullptr;  // scratch: 4N elements
+    digest32 *d_tree_main_ = nullptr, *d_tree_aux_ = nullptr, *d_tree_comp_ = nullptr;
+    std::vector<fe*> d_fri_evals_;          // layer k: N >> k elements
+    std::vector<digest32*> d_fri_trees_;
+    uint32_t fri_layer_ = 0;                // number of committed layers so far
+    fe fri_offset_;                         // h^(2^layer)
+    CompositionConsts* d_comp_consts_ = nullptr;
+    DeepConsts* d_deep_consts_ = nullptr;
+    unsigned long long* d_nonce_ = nullptr;
+    uint64_t* d_positions_ = nullptr;
+    fe z_; fe h1_z2_, h2_z2_;
+    std::vector<fe> trace_ood_;
+    int stage_ = 0;  // 0 new, 1 setup, 2 main committed, 3 aux committed, 4 composition, 5 ood, 6 fri running, 7 fri done
+};
+
+// Whole proof on the device: generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + serialize
+// (src/starks/proof/stark.rs:161-218). main_trace: row-major n x cols in the context encoding.
+int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5]);
+
+}  // namespace sp

@@ -1,0 +1,78 @@
+// Device kernels of the STARK rounds beyond NTT and Merkle: Cairo constraint composition, composition-polynomial
+// split, out-of-domain evaluation, DEEP composition, FRI folding, grinding, query gathers.
+// Reference code each one replaces is cited at the declaration.
+#pragma once
+#include "common.h"
+#include "merkle.h"
+
+namespace sp {
+
+constexpr int CAIRO_MAX_TRANSITIONS = 50;
+constexpr int CAIRO_MAX_BOUNDARY = 8;
+constexpr int CAIRO_MAX_BLOWUP = 32;
+
+// out[q] = c * base^(bitrev_bits(q)) for q < count (bitrev_bits = 0: natural exponent q)
+int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bits, const fe& base, const fe& c);
+
+// den[d*N + i] = h*w_N^i - point[d]   for d < ndist  (then batch-inverted by the caller).
+// Replaces the N-long zerofier tables of reference src/starks/constraints/evaluator.rs:58-72 and the Ruffini
+// divisions of src/starks/prover.rs:436-473 (evaluation form).
+int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist);
+
+// Constants of one composition evaluation (device copy lives in CompositionConsts_dev).
+struct CompositionConsts {
+    fe h;                       // coset offset
+    fe rap[3];                  // alpha_memory, z_memory, z_range_check (reference src/cairo/air.rs:469-473)
+    fe g_last;                  // g^(n-1): root of the single transition exemption X - g^(n-1) (traits.rs:49-79)
+    fe b16, b32, b48, b15, two; // constants of the instruction-decoding constraints (air.rs:883-912)
+    fe zerofier[CAIRO_MAX_BLOWUP];                                          // 1/(x^n - 1) per coset (evaluator.rs:156-171)
+    fe coef[CAIRO_MAX_BLOWUP][CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY];  // alpha_k * x^(D-D_k) + beta_k per coset
+    fe bvalue[CAIRO_MAX_BOUNDARY];                                          // boundary values
+    uint32_t bcol[CAIRO_MAX_BOUNDARY];                                      // boundary columns
+    uint32_t bden[CAIRO_MAX_BOUNDARY];                                      // index of the inverse-denominator array
+    uint32_t n_boundary, n_transitions, main_cols, has_rc_builtin;
+};
+
+// ConstraintEvaluator::evaluate (reference src/starks/constraints/evaluator.rs:38-260) with CairoAIR::compute_transition
+// (src/cairo/air.rs:743-767, helpers :869-1160) fused per LDE point.  lde: column-major [C][N] natural order;
+// binv: [ndist][N] inverse boundary denominators; out: [N].
+int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, uint32_t logb, const fe* roots_N,
+                      const CompositionConsts* consts_dev, const fe* binv, fe* out);
+
+// Split of the composition polynomial (reference src/starks/prover.rs:250-252, evaluation_table.rs:27-33):
+// X = unscaled bit-reversed size-N inverse transform of the N evaluations; writes the h-scaled bit-reversed coefficient
+// arrays (n each) of H1 (even) and H2 (odd): H1s[q] = X[q*b/2] * t2[q], H2s[q] = X[N/2 + q*b/2] * t2[q] * hinv,
+// t2[q] = N^-1 h^(-rev_n(q)).
+int split_composition(hipStream_t st, const fe* X, uint64_t n, uint32_t logb, const fe* t2, const fe& hinv, fe* H1s, fe* H2s);
+
+// One level of the out-of-domain evaluation (reference src/starks/prover.rs:301-304, frame.rs:67-83; Horner replaced
+// by a bit-reversed-order fold): out[v][p][q'] = sum_t in[v][(p)][q' + t*M/2^l] * yp[p][t]   for q' < M/2^l.
+// first level: in has no point dimension (in_points = 1), later levels have in_points = points.
+int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32_t in_points, uint64_t M, uint32_t l,
+                    const fe* yp /*[points][2^l]*/, uint32_t points, uint32_t vectors, fe* out /*[vectors][points][M>>l]*/);
+
+struct DeepConsts {
+    fe gamma_h1, gamma_h2;       // gamma, gamma'
+    fe c_h;                      // gamma*H1(z^2) + gamma'*H2(z^2)
+    fe c_t[2];                   // sum_j gamma_{j,k} t_j(z g^k)
+    fe gammas[2][64];            // gamma_{j,k}, k = frame row, j = column (<= 61 columns)
+    uint32_t cols;
+};
+// compute_deep_composition_poly (reference src/starks/prover.rs:410-482) in evaluation form:
+// p0(x) = (sum_j g_j0 t_j(x) - c_t0) / (x - z) + (sum_j g_j1 t_j(x) - c_t1) / (x - z g) + (g H1 + g' H2 - c_h) / (x - z^2);
+// inv: [3][N] = 1/(x - z), 1/(x - z g), 1/(x - z^2).
+int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t N, const DeepConsts* consts_dev, const fe* inv, fe* out);
+
+// fold_polynomial + FriLayer::new (reference src/starks/fri/fri_functions.rs:4-27, fri_commitment.rs:30-47) in evaluation
+// form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.
+// roots_N: half table of w_N; M = N >> layer. c = zeta / (2 * offset).
+int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c);
+
+// generate_nonce_with_grinding (reference src/starks/grinding.rs:17-48): smallest nonce in [start, start+count) whose
+// Keccak256(challenge || nonce_le)[0..8] (BE) has >= factor trailing zeros; *result_dev = min(*result_dev, nonce).
+int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uint64_t start, uint64_t count, unsigned long long* result_dev);
+
+// out[r*cols + j] = cols_base[j*col_stride + rows[r]]
+int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out);
+
+}  // namespace sp

@@ -1,0 +1,348 @@
+// Device kernels of the STARK rounds (see stark_kernels.h).
+#include "stark_kernels.h"
+#include "keccak.h"
+
+namespace sp {
+
+__device__ __forceinline__ fe sk_ld(const fe* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 lo = q[0], hi = q[1];
+    fe r;
+    r.v[0] = lo.x; r.v[1] = lo.y; r.v[2] = lo.z; r.v[3] = lo.w;
+    r.v[4] = hi.x; r.v[5] = hi.y; r.v[6] = hi.z; r.v[7] = hi.w;
+    return r;
+}
+__device__ __forceinline__ void sk_st(fe* p, const fe& a) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+    q[1] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+}
+__device__ __forceinline__ fe operator+(const fe& a, const fe& b) { return fe_add(a, b); }
+__device__ __forceinline__ fe operator-(const fe& a, const fe& b) { return fe_sub(a, b); }
+__device__ __forceinline__ fe operator*(const fe& a, const fe& b) { return fe_mul(a, b); }
+
+// w_N^e (e in [0, N)) from the half table
+__device__ __forceinline__ fe root_pow(const fe* tw, uint32_t e, uint32_t logN) {
+    uint32_t half = 1u << (logN - 1);
+    fe w = sk_ld(tw + (e & (half - 1)));
+    return (e & half) ? fe_neg(w) : w;
+}
+
+// ---------------------------------------------------------------------------------------------- power tables
+struct PowTableArgs { fe pw[32]; fe c; };
+__global__ void __launch_bounds__(256) power_table_kernel(fe* out, uint64_t count, uint32_t bitrev_bits, PowTableArgs a) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    uint32_t e = bitrev_bits ? (__brev((uint32_t)q) >> (32 - bitrev_bits)) : (uint32_t)q;
+    fe acc = a.c;
+    for (uint32_t i = 0; i < 32; ++i)
+        if ((e >> i) & 1) acc = fe_mul(acc, a.pw[i]);
+    sk_st(out + q, acc);
+}
+int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bits, const fe& base, const fe& c) {
+    PowTableArgs a;
+    fe cur = base;
+    for (int i = 0; i < 32; ++i) { a.pw[i] = cur; cur = fe_sqr(cur); }
+    a.c = c;
+    hipLaunchKernelGGL(power_table_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, out, count, bitrev_bits, a);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- x_i - point
+struct PointsArgs { fe h; fe pt[4]; };
+__global__ void __launch_bounds__(256) coset_minus_points_kernel(fe* den, uint64_t N, uint32_t logN, const fe* roots, uint32_t ndist, PointsArgs a) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    fe x = fe_mul(root_pow(roots, (uint32_t)i, logN), a.h);
+    for (uint32_t d = 0; d < ndist; ++d) sk_st(den + (uint64_t)d * N + i, fe_sub(x, a.pt[d]));
+}
+int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist) {
+    if (ndist > 4) return SP_E_INVALID_ARG;
+    PointsArgs a;
+    a.h = h;
+    for (uint32_t d = 0; d < ndist; ++d) a.pt[d] = points_host[d];
+    hipLaunchKernelGGL(coset_minus_points_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, den, N, logN, roots_N, ndist, a);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- Cairo composition
+// Column ids of the main trace (reference src/cairo/air.rs:73-110); aux columns start at main_cols:
+// +0..2 sorted offsets, +3..6 sorted addresses, +7..10 sorted values, +11..14 memory permutation, +15..17 rc permutation.
+enum {
+    K_RES = 16, K_AP = 17, K_FP = 18, K_PC = 19, K_DST_ADDR = 20, K_OP0_ADDR = 21, K_OP1_ADDR = 22, K_INST = 23, K_DST = 24,
+    K_OP0 = 25, K_OP1 = 26, K_OFF_DST = 27, K_OFF_OP0 = 28, K_OFF_OP1 = 29, K_T0 = 30, K_T1 = 31, K_MUL = 32, K_SEL = 33,
+    K_RC0 = 34, K_RCV = 42
+};
+
+__global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __restrict__ lde, uint64_t N, uint32_t logN, uint32_t logb,
+                                                                const fe* __restrict__ roots, const CompositionConsts* __restrict__ K,
+                                                                const fe* __restrict__ binv, fe* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint4 sh_raw[];
+    fe* sh_coef = reinterpret_cast<fe*>(sh_raw);  // [b][T + B]
+    const uint32_t b = 1u << logb;
+    const uint32_t T = K->n_transitions, B = K->n_boundary, W = T + B;
+    for (uint32_t t = threadIdx.x; t < b * W; t += 256) {
+        uint32_t c = t / W, k = t % W;
+        sh_coef[t] = K->coef[c][k];
+    }
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const uint32_t c = (uint32_t)i & (b - 1);
+    const uint64_t inext = (i + b) & (N - 1);  // frame row offset 1 = LDE index + blowup (reference frame.rs:40-59)
+    const fe* coef = sh_coef + c * W;
+    const uint32_t A = K->main_cols;
+    auto cur = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + i); };
+    auto nxt = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + inext); };
+
+    const fe one = fe_one();
+    fe S0 = fe_zero(), S1 = fe_zero(), S2 = fe_zero(), S3 = fe_zero();
+    // S0: no selector, no exemption; S1: exempted; S2: selector; S3: selector and exempted.
+
+    // --- flags (air.rs:869-881) and the instruction word (air.rs:883-896)
+    fe f0s = fe_zero();
+    for (int k = 14; k >= 0; --k) {
+        fe f = cur(k);
+        S0 = S0 + coef[k] * (f * f - f);
+        f0s = f + (f0s + f0s);
+    }
+    S0 = S0 + coef[15] * cur(15);
+    {
+        fe c16 = cur(K_OFF_DST) + K->b16 * cur(K_OFF_OP0) + K->b32 * cur(K_OFF_OP1) + K->b48 * f0s - cur(K_INST);
+        S2 = S2 + coef[16] * c16;
+    }
+    const fe ap = cur(K_AP), fp = cur(K_FP), pc = cur(K_PC);
+    // --- operand constraints (air.rs:899-924)
+    {
+        fe f_dst_fp = cur(0), f_op0_fp = cur(1);
+        fe d = fp - ap;
+        S2 = S2 + coef[17] * (ap + f_dst_fp * d + (cur(K_OFF_DST) - K->b15) - cur(K_DST_ADDR));
+        S2 = S2 + coef[18] * (ap + f_op0_fp * d + (cur(K_OFF_OP0) - K->b15) - cur(K_OP0_ADDR));
+        fe f2 = cur(2), f3 = cur(3), f4 = cur(4);
+        fe op0 = cur(K_OP0);
+        fe c19 = f2 * pc + f4 * ap + f3 * fp + (one - f2 - f4 - f3) * op0 + (cur(K_OFF_OP1) - K->b15) - cur(K_OP1_ADDR);
+        S2 = S2 + coef[19] * c19;
+    }
+    // --- register constraints (air.rs:926-959)
+    {
+        fe res = cur(K_RES), dst = cur(K_DST);
+        fe f9 = cur(9), f12 = cur(12), f13 = cur(13);
+        fe size = cur(2) + one;  // frame_inst_size (air.rs:1137-1139)
+        fe npc = nxt(K_PC);
+        fe c20 = ap + cur(10) * res + cur(11) + (f12 + f12) - nxt(K_AP);
+        S3 = S3 + coef[20] * c20;
+        fe c21 = f13 * dst + f12 * (ap + K->two) + (one - f13 - f12) * fp - nxt(K_FP);
+        S3 = S3 + coef[21] * c21;
+        fe t0 = cur(K_T0), t1 = cur(K_T1);
+        fe pc_size = pc + size;
+        S3 = S3 + coef[22] * ((t1 - f9) * (npc - pc_size));
+        fe f7 = cur(7), f8 = cur(8);
+        fe c23 = t0 * (npc - (pc + cur(K_OP1))) + (one - f9) * npc -
+                 ((one - f7 - f8 - f9) * pc_size + f7 * res + f8 * (pc + res));
+        S3 = S3 + coef[23] * c23;
+        S2 = S2 + coef[24] * (f9 * dst - t0);
+        S2 = S2 + coef[25] * (t0 * res - t1);
+        // --- opcode constraints (air.rs:961-978)
+        fe op0 = cur(K_OP0), op1 = cur(K_OP1), mul = cur(K_MUL);
+        fe f5 = cur(5), f6 = cur(6);
+        S2 = S2 + coef[26] * (mul - op0 * op1);
+        fe c27 = f5 * (op0 + op1) + f6 * mul + (one - f5 - f6 - f9) * op1 - (one - f9) * res;
+        S2 = S2 + coef[27] * c27;
+        S2 = S2 + coef[28] * (f12 * (dst - fp));
+        S2 = S2 + coef[29] * (f12 * (op0 - pc_size));
+        S2 = S2 + coef[30] * (cur(14) * (dst - res));
+    }
+    // --- memory (air.rs:987-1043) and permutation argument (air.rs:1045-1090)
+    {
+        const fe alpha = K->rap[0], z = K->rap[1];
+        fe a_prev = cur(A + 3), v_prev = cur(A + 7), p_prev = cur(A + 11);
+#pragma unroll 1
+        for (uint32_t k = 1; k <= 4; ++k) {
+            // k = 1..3: next sorted cell of this row; k = 4: first sorted cell of the next row
+            fe a_k = (k < 4) ? cur(A + 3 + k) : nxt(A + 3);
+            fe v_k = (k < 4) ? cur(A + 7 + k) : nxt(A + 7);
+            fe p_k = (k < 4) ? cur(A + 11 + k) : nxt(A + 11);
+            fe step = a_k - a_prev - one;
+            fe inc = (a_prev - a_k) * step;           // MEMORY_INCREASING_{k-1}
+            fe cons = (v_prev - v_k) * step;          // MEMORY_CONSISTENCY_{k-1}
+            // original (unsorted) access k: (dst_addr,dst), (op0_addr,op0), (op1_addr,op1), then next row's (pc,inst)
+            fe a_o = (k < 4) ? cur(K_PC + k) : nxt(K_PC);
+            fe v_o = (k < 4) ? cur(K_INST + k) : nxt(K_INST);
+            fe perm = (z - (a_k + alpha * v_k)) * p_k - (z - (a_o + alpha * v_o)) * p_prev;  // PERMUTATION_ARGUMENT_{k-1}
+            if (k < 4) {
+                S0 = S0 + coef[31 + k - 1] * inc + coef[35 + k - 1] * cons + coef[39 + k - 1] * perm;
+            } else {
+                S1 = S1 + coef[34] * inc + coef[38] * cons + coef[42] * perm;
+            }
+            a_prev = a_k; v_prev = v_k; p_prev = p_k;
+        }
+    }
+    // --- range check (air.rs:1092-1135)
+    {
+        const fe zrc = K->rap[2];
+        fe rc0 = cur(A + 0), rc1 = cur(A + 1), rc2 = cur(A + 2), rc0n = nxt(A + 0);
+        S0 = S0 + coef[43] * ((rc0 - rc1) * (rc1 - rc0 - one));
+        S0 = S0 + coef[44] * ((rc1 - rc2) * (rc2 - rc1 - one));
+        S1 = S1 + coef[45] * ((rc2 - rc0n) * (rc0n - rc2 - one));
+        fe q0 = cur(A + 15), q1 = cur(A + 16), q2 = cur(A + 17), q0n = nxt(A + 15);
+        S0 = S0 + coef[46] * ((zrc - rc1) * q1 - (zrc - cur(K_OFF_OP0)) * q0);
+        S0 = S0 + coef[47] * ((zrc - rc2) * q2 - (zrc - cur(K_OFF_OP1)) * q1);
+        S0 = S0 + coef[48] * ((zrc - rc0n) * q0n - (zrc - nxt(K_OFF_DST)) * q2);
+    }
+    // --- range-check builtin (air.rs:1141-1160)
+    if (K->has_rc_builtin) {
+        fe acc = fe_zero();
+        for (int k = 7; k >= 0; --k) acc = acc * K->b16 + cur(K_RC0 + k);
+        S0 = S0 + coef[49] * (acc - cur(K_RCV));
+    }
+    // --- combine (evaluator.rs:205-253): zerofier * (sum + exemption * sum_exempted)
+    const fe x = root_pow(roots, (uint32_t)i, logN) * K->h;
+    const fe sel = cur(K_SEL);
+    fe total = K->zerofier[c] * ((S0 + sel * S2) + (x - K->g_last) * (S1 + sel * S3));
+    // --- boundary term (evaluator.rs:58-115)
+    for (uint32_t j = 0; j < B; ++j) {
+        fe num = cur(K->bcol[j]) - K->bvalue[j];
+        total = total + coef[T + j] * num * sk_ld(binv + (uint64_t)K->bden[j] * N + i);
+    }
+    sk_st(out + i, total);
+}
+
+int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, uint32_t logb, const fe* roots_N,
+                      const CompositionConsts* consts_dev, const fe* binv, fe* out) {
+    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
+    size_t lds = (size_t)(1u << logb) * (CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY) * sizeof(fe);
+    hipLaunchKernelGGL(cairo_composition_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, st, lde, N, logN, logb, roots_N, consts_dev, binv, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- composition split
+struct SplitArgs { fe hinv; };
+__global__ void __launch_bounds__(256) split_composition_kernel(const fe* X, uint64_t n, uint32_t logb, const fe* t2, SplitArgs a, fe* H1s, fe* H2s) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= n) return;
+    uint64_t N = n << logb;
+    uint64_t pos = logb ? (q << (logb - 1)) : 0;
+    fe t = sk_ld(t2 + q);
+    if (logb == 0) {
+        // blowup 1: X has n entries in bit-reversed order of k; even k -> first half. Not used by the prover (b >= 2).
+        return;
+    }
+    sk_st(H1s + q, fe_mul(sk_ld(X + pos), t));
+    sk_st(H2s + q, fe_mul(fe_mul(sk_ld(X + (N >> 1) + pos), t), a.hinv));
+}
+int split_composition(hipStream_t st, const fe* X, uint64_t n, uint32_t logb, const fe* t2, const fe& hinv, fe* H1s, fe* H2s) {
+    if (logb == 0) { sp_set_error("split_composition: blowup factor must be >= 2"); return SP_E_UNSUPPORTED; }
+    SplitArgs a; a.hinv = hinv;
+    hipLaunchKernelGGL(split_composition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, n, logb, t2, a, H1s, H2s);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- OOD fold
+__global__ void __launch_bounds__(256) fold_eval_kernel(const fe* in, uint64_t in_vec_stride, uint32_t in_points, uint64_t Mq, uint32_t T,
+                                                        const fe* yp, uint32_t points, fe* out) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= Mq) return;
+    uint32_t v = blockIdx.y;
+    for (uint32_t p = 0; p < points; ++p) {
+        const fe* src = in + (uint64_t)v * in_vec_stride + (in_points > 1 ? (uint64_t)p * Mq * T : 0);
+        fe acc = fe_zero();
+        for (uint32_t t = 0; t < T; ++t) acc = fe_add(acc, fe_mul(sk_ld(src + (uint64_t)t * Mq + q), yp[p * T + t]));
+        sk_st(out + ((uint64_t)v * points + p) * Mq + q, acc);
+    }
+}
+int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32_t in_points, uint64_t M, uint32_t l,
+                    const fe* yp, uint32_t points, uint32_t vectors, fe* out) {
+    uint64_t Mq = M >> l;
+    dim3 grid((unsigned)((Mq + 255) / 256), vectors);
+    hipLaunchKernelGGL(fold_eval_kernel, grid, dim3(256), 0, st, in, in_vec_stride, in_points, Mq, 1u << l, yp, points, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- DEEP composition
+__global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, const fe* __restrict__ h1, const fe* __restrict__ h2, uint64_t N,
+                                                   const DeepConsts* __restrict__ K, const fe* __restrict__ inv, fe* __restrict__ out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    fe a0 = fe_zero(), a1 = fe_zero();
+    const uint32_t C = K->cols;
+    for (uint32_t j = 0; j < C; ++j) {
+        fe t = sk_ld(lde + (uint64_t)j * N + i);
+        a0 = a0 + K->gammas[0][j] * t;
+        a1 = a1 + K->gammas[1][j] * t;
+    }
+    fe hh = K->gamma_h1 * sk_ld(h1 + i) + K->gamma_h2 * sk_ld(h2 + i) - K->c_h;
+    fe r = (a0 - K->c_t[0]) * sk_ld(inv + i) + (a1 - K->c_t[1]) * sk_ld(inv + N + i) + hh * sk_ld(inv + 2 * N + i);
+    sk_st(out + i, r);
+}
+int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t N, const DeepConsts* consts_dev, const fe* inv, fe* out) {
+    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lde, h1, h2, N, consts_dev, inv, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- FRI fold
+struct FriArgs { fe half, c; };
+__global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, uint64_t Mh, uint32_t logN, uint32_t layer, const fe* roots, FriArgs a) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mh) return;
+    fe x = sk_ld(cur + i), y = sk_ld(cur + Mh + i);
+    uint32_t Nm = (1u << logN) - 1;
+    uint32_t e = (0u - ((uint32_t)i << layer)) & Nm;  // w_M^-i = w_N^(-i 2^layer)
+    fe w = root_pow(roots, e, logN);
+    sk_st(next + i, a.half * (x + y) + a.c * (w * (x - y)));
+}
+int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c) {
+    uint64_t Mh = M >> 1;
+    FriArgs a; a.half = half; a.c = c;
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- grinding
+struct GrindArgs { uint64_t ch[4]; };
+__global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t factor, uint64_t start, uint64_t count, unsigned long long* result) {
+    uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= count) return;
+    uint64_t nonce = start + t;
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = 0;
+    s[0] = a.ch[0]; s[1] = a.ch[1]; s[2] = a.ch[2]; s[3] = a.ch[3];
+    s[4] = nonce;             // 8 bytes little-endian
+    s[5] = 0x01ULL;           // Keccak padding starts at byte 40
+    s[16] = 0x8000000000000000ULL;
+    sp_keccak_f1600_dev(s);
+    uint64_t head = sp_bswap64(s[0]);  // first 8 digest bytes read big-endian
+    uint64_t mask = factor >= 64 ? ~0ULL : ((1ULL << factor) - 1ULL);
+    if ((head & mask) == 0) atomicMin(result, (unsigned long long)nonce);
+}
+int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uint64_t start, uint64_t count, unsigned long long* result_dev) {
+    GrindArgs a;
+    __builtin_memcpy(a.ch, challenge, 32);
+    hipLaunchKernelGGL(grind_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, a, (uint32_t)factor, start, count, result_dev);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- gathers
+__global__ void gather_rows_kernel(const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows, uint32_t nrows, fe* out) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nrows * ncols) return;
+    uint32_t r = t / ncols, j = t % ncols;
+    sk_st(out + t, sk_ld(cols_base + (uint64_t)j * col_stride + rows[r]));
+}
+int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out) {
+    uint32_t total = nrows * ncols;
+    if (total == 0) return SP_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((total + 127) / 128), dim3(128), 0, st, cols_base, col_stride, ncols, rows_dev, nrows, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+}  // namespace sp
