@@ -1,0 +1,91 @@
+"""The oracle (fed by the host-side Cairo front-end) reproduces the reference's golden proofs byte for byte.
+
+benches/proofs/fibonacci_{500,1000}.proof come from an older commit whose only protocol difference is the boundary
+term; the oracle carries a test-only `legacy_boundary` switch for them. fibonacci_70000.proof is the
+current protocol at BASELINE config #4's shape (n = 2^19, blowup 4)."""
+import hashlib
+import os
+import struct
+
+import pytest
+
+from lambdaworks_cairo_prover_amd import api
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DEFAULT_TEST_OPTIONS = (4, 3, 3, 1)
+
+
+def parse_proof_file(path):
+    d = open(path, "rb").read()
+    plen = struct.unpack(">Q", d[:8])[0]
+    proof, pi = d[8:8 + plen], d[8 + plen:]
+    p = 8
+    regs = [int.from_bytes(pi[p + 32 * i:p + 32 * i + 32], "big") for i in range(5)]
+    p += 5 * 32
+    rc = []
+    for _ in range(2):
+        if pi[p] == 1:
+            rc.append(struct.unpack(">H", pi[p + 1:p + 3])[0])
+            p += 3
+        else:
+            rc.append(None)
+            p += 1
+    nseg = struct.unpack(">Q", pi[p:p + 8])[0]
+    p += 8 + 17 * nseg
+    npm = struct.unpack(">Q", pi[p:p + 8])[0]
+    p += 8
+    pm = {}
+    for _ in range(npm):
+        pm[int.from_bytes(pi[p:p + 32], "big")] = int.from_bytes(pi[p + 32:p + 64], "big")
+        p += 64
+    num_steps = struct.unpack(">Q", pi[p:p + 8])[0]
+    return proof, dict(regs=regs, rc=rc, public_memory=pm, num_steps=num_steps)
+
+
+@pytest.mark.parametrize("name,sha,legacy", [
+    ("fibonacci_500", "ce9d492f837c418ce3cf1ca3bf7706142ae4de1be4dd3dacc533ffa83b14f34c", True),
+    ("fibonacci_1000", "7a3bcdd78bf499e315a8db135433490643ad9549a6ea15b55ebbfccdd3acf99a", True),
+    ("fibonacci_70000", "da962bd4513d991c39a0e0cc11cc76d25b9ec405cebcdaaf1449184d4b54cd6b", False),
+])
+def test_oracle_reproduces_golden_proof(oracle, hip_lib, name, sha, legacy):
+    golden, pi = parse_proof_file(os.path.join(GOLDEN, name + ".proof"))
+    assert hashlib.sha256(golden).hexdigest() == sha
+    words = [pi["public_memory"][a] for a in sorted(pi["public_memory"])]
+    run = api.CairoRun.from_program(words)
+    # cross-checks stored in the file's public-input section
+    assert run.num_steps == pi["num_steps"]
+    c = run.public_inputs_c
+    assert [int.from_bytes(bytes(getattr(c, f)), "big") for f in ("pc_init", "ap_init", "fp_init", "pc_final", "ap_final")] == pi["regs"]
+    assert [c.range_check_min, c.range_check_max] == pi["rc"]
+    got = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, DEFAULT_TEST_OPTIONS, legacy_boundary=legacy)
+    assert len(got) == len(golden)
+    assert got == golden
+    if not legacy:
+        assert oracle.cairo_verify(got, run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+
+
+def test_verifier_rejects_tampering(oracle, hip_lib):
+    """Negative tests in the spirit of reference tests/integration_tests.rs:206-357."""
+    run = api.CairoRun.fibonacci(20)
+    trace = run.main_trace()
+    proof = oracle.cairo_prove(trace, run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+    assert oracle.cairo_verify(proof, run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+    # flipped proof byte (a trace OOD evaluation)
+    bad = bytearray(proof)
+    bad[8 + 8 + 64 + 8 + 16 + 40] ^= 1
+    assert not oracle.cairo_verify(bytes(bad), run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+    # wrong public input
+    import ctypes
+    pub2 = type(run.public_inputs_c)()
+    ctypes.memmove(ctypes.byref(pub2), ctypes.byref(run.public_inputs_c), ctypes.sizeof(pub2))
+    pub2.range_check_max += 1
+    assert not oracle.cairo_verify(proof, pub2, DEFAULT_TEST_OPTIONS)
+    # more queries requested than the proof holds (reference verifier.rs:570-572)
+    assert not oracle.cairo_verify(proof, run.public_inputs_c, (4, 4, 3, 1))
+    # corrupted trace cell -> prover output must not verify
+    t2 = trace.copy()
+    t2[3, 16, 31] ^= 1
+    proof2 = oracle.cairo_prove(t2, run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+    assert not oracle.cairo_verify(proof2, run.public_inputs_c, DEFAULT_TEST_OPTIONS)
+    # truncated proof is malformed, not accepted
+    assert not oracle.cairo_verify(proof[:-9], run.public_inputs_c, DEFAULT_TEST_OPTIONS)
