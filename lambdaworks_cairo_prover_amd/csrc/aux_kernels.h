@@ -1,0 +1,41 @@
+// Cairo auxiliary (RAP) trace on the device. Replaces CairoAIR::build_auxiliary_trace (reference src/cairo/air.rs:660-729)
+// and its helpers: add_pub_memory_in_public_input_section (:475-494), sort_columns_by_memory_address (:519-523),
+// generate_memory_permutation_argument_column (:525-551), generate_range_check_permutation_argument_column (:552-572).
+#pragma once
+#include "common.h"
+
+namespace sp {
+
+struct AuxWorkspace {
+    // 4n-element arrays
+    fe *a_aux, *v_aux, *num, *a_s, *v_s, *den, *inv_scratch;
+    // 3n-element arrays (range check)
+    fe *rc_terms;
+    uint16_t* rc_sorted;      // 3n
+    uint64_t *keys_in, *keys_out;  // 4n
+    uint32_t *idx_in, *idx_out;    // 4n
+    uint32_t* hist;           // 65537
+    fe *rc_den, *rc_den_scratch;   // 65536 each
+    fe* block_tot;            // prefix-product block totals (>= 4n / 2048 + 1, two levels)
+    fe *pm_addr, *pm_val;     // public memory (capacity pm_cap)
+    void* sort_tmp; size_t sort_tmp_bytes;
+    uint64_t n; uint64_t pm_cap;
+};
+
+size_t aux_workspace_bytes(uint64_t n, uint64_t pm_cap, size_t* sort_tmp_bytes);
+// carve the workspace out of one allocation of aux_workspace_bytes(n, pm_cap)
+void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_cap, size_t sort_tmp_bytes);
+
+// mem_cols: the 11 natural-order main-trace columns 19..29 (pc, dst_addr, op0_addr, op1_addr, inst, dst, op0, op1,
+// off_dst, off_op0, off_op1), column k at mem_cols + k*n.  pm_addr_host/pm_val_host: the public-memory (address, value)
+// list in the order of get_pub_memory_addrs (air.rs:500-517).  rap = alpha_memory, z_memory, z_range_check.
+// aux_cols_out: 18 natural-order columns at stride n (sorted offsets 0-2, sorted addresses 3-6, sorted values 7-10,
+// memory permutation 11-14, range-check permutation 15-17).  *flag_dev is set on malformed input (address >= 2^64,
+// offset >= 2^16, zero denominator).
+int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
+                           uint64_t pm, const fe rap[3], fe* aux_cols_out, int* flag_dev);
+
+// In-place inclusive prefix product of M elements (block_tot: workspace of >= M/2048 + 2 elements).
+int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot);
+
+}  // namespace sp

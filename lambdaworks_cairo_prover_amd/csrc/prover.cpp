@@ -5,8 +5,19 @@
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace sp {
+
+static double wall_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static bool timing_enabled() { static int v = -1; if (v < 0) v = std::getenv("SP_TIMING") ? 1 : 0; return v == 1; }
+#define SP_TIMEPOINT(label)                                                                 \
+    do { if (timing_enabled()) { (void)hipStreamSynchronize(ctx->stream); double _t = wall_ms(); \
+         std::fprintf(stderr, "[sp_timing] %-28s %9.2f ms\n", label, _t - _tp); _tp = _t; } } while (0)
 
 StarkProver::~StarkProver() { free_all(); }
 
@@ -32,7 +43,14 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
     if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c_->device));
+    if (!allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
+        opt.coset_offset == opt_.coset_offset) {
+        // same shape as the previous proof on this context: keep every device buffer and table
+        opt_ = opt; stage_ = 1; fri_layer_ = 0;
+        return SP_OK;
+    }
     free_all();
+    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
     h_ = fe_from_u64(opt.coset_offset);
@@ -53,6 +71,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
     SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
     SP_TRY(alloc((void**)&d_positions_, sizeof(uint64_t) * 4096));
+    SP_TRY(alloc((void**)&d_memcols_, sizeof(fe) * n_ * 11));
     d_fri_evals_.clear(); d_fri_trees_.clear();
     for (uint32_t l = 0; l <= logn_; ++l) {
         fe* e = nullptr; digest32* t = nullptr;
@@ -94,6 +113,15 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
+    if (segment == 0 && cols >= 30)  // memory and offset columns feed the Cairo auxiliary trace
+        SP_HIP_CHECK(hipMemcpyAsync(d_memcols_, coeffs + 19 * n_, sizeof(fe) * n_ * 11, hipMemcpyDeviceToDevice, c_->stream));
+    return commit_segment_resident(segment, cols, root_out);
+}
+
+// Second half of interpolate_and_commit: the segment's columns sit in natural order in the coefficient area.
+int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]) {
+    const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_));
     // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
@@ -103,6 +131,46 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_TRY(commit_columns(lde, N_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
     return SP_OK;
+}
+
+int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]) {
+    if (stage_ != 2 || Ca_ != 18 || Cm_ < 34) { sp_set_error("commit_aux_cairo: main segment not committed or not a Cairo layout"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint64_t pm = pub.public_memory.size();
+    if (!d_auxws_ || pm > auxws_pm_cap_) {
+        size_t sort_tmp = 0;
+        uint64_t cap = std::max<uint64_t>(pm, 1024);
+        size_t bytes = aux_workspace_bytes(n_, cap, &sort_tmp);
+        void* base = nullptr;
+        SP_TRY(alloc(&base, bytes));  // an outgrown workspace stays in allocs_ until the next reshaping setup()
+        d_auxws_ = base; auxws_bytes_ = bytes; auxws_pm_cap_ = cap;
+        aux_workspace_carve(auxws_, base, n_, cap, sort_tmp);
+    }
+    // get_pub_memory_addrs (reference cairo/air.rs:500-517) and the matching values
+    std::vector<fe> pa, pv;
+    {
+        std::vector<uint64_t> addrs;
+        if (const MemorySegment* out = pub.segment(1)) {
+            uint64_t output_section = out->end - out->start, program_section = pm - output_section;
+            for (uint64_t i = 1; i <= program_section; ++i) addrs.push_back(i);
+            for (uint64_t a = out->start; a < out->end; ++a) addrs.push_back(a);
+        } else {
+            for (uint64_t i = 1; i <= pm; ++i) addrs.push_back(i);
+        }
+        for (uint64_t a : addrs) {
+            const fe* val = nullptr;
+            for (auto& kv : pub.public_memory) if (kv.first == a) { val = &kv.second; break; }
+            if (!val) { sp_set_error("commit_aux_cairo: public memory address missing"); return SP_E_INVALID_ARG; }
+            pa.push_back(fe_from_u64(a)); pv.push_back(*val);
+        }
+    }
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_coeffs_ + (uint64_t)Cm_ * n_, c_->d_flag));
+    int flag = 0;
+    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // pa / pv are locals; flag
+    if (flag) { sp_set_error("commit_aux_cairo: malformed trace (address >= 2^64, offset >= 2^16 or zero permutation denominator)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
+    return commit_segment_resident(1, Ca_, root_out);
 }
 
 int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
@@ -478,30 +546,30 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
     try {
         CairoAirInfo air = cairo_air_info(pub);
         if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
-        StarkProver* P = new StarkProver(ctx);
-        delete ctx->prover_state_deleter_holder;
-        ctx->prover_state_deleter_holder = P;
+        StarkProver* P = dynamic_cast<StarkProver*>(ctx->prover_state_deleter_holder);
+        if (!P) {  // keep the prover (and its device buffers) across proofs of the same shape on this context
+            P = new StarkProver(ctx);
+            delete ctx->prover_state_deleter_holder;
+            ctx->prover_state_deleter_holder = P;
+        }
         hipEvent_t ev[6];
         for (auto& e : ev) SP_HIP_CHECK(hipEventCreate(&e));
+        double _tp = wall_ms();
         SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
+        SP_TIMEPOINT("setup (alloc + tables)");
         HostTranscript tr;
         uint8_t root[32];
         // ---- round 1 (reference prover.rs:187-224)
         SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
         SP_TRY(P->commit_trace(0, main_trace, cols, root));
         uint8_t main_root[32]; std::memcpy(main_root, root, 32);
+        SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");
         tr.append(root, 32);
         fe rap[3] = {tr.to_field(), tr.to_field(), tr.to_field()};
-        std::vector<fe> main_fe((size_t)n * cols);
-        SP_TRY(sp_fe_to_device(ctx->enc, main_trace, n * cols, reinterpret_cast<uint8_t*>(main_fe.data())));
-        std::vector<fe> aux = build_auxiliary_trace(main_fe.data(), n, cols, pub, rap);
-        main_fe.clear(); main_fe.shrink_to_fit();
-        std::vector<uint8_t> aux_abi(aux.size() * 32);
-        SP_TRY(sp_fe_from_device(ctx->enc, reinterpret_cast<const uint8_t*>(aux.data()), aux.size(), aux_abi.data()));
-        SP_TRY(P->commit_trace(1, aux_abi.data(), air.aux_columns, root));
+        SP_TRY(P->commit_aux_cairo(pub, rap, root));
+        SP_TIMEPOINT("r1 aux trace + commit (device)");
         uint8_t aux_root[32]; std::memcpy(aux_root, root, 32);
         tr.append(root, 32);
-        aux.clear(); aux_abi.clear();
         SP_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
         // ---- round 2 (reference prover.rs:597-635)
         std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
@@ -513,6 +581,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         for (auto& x : t_beta) x = tr.to_field();
         SP_TRY(P->composition(rap, bcs, b_alpha, b_beta, t_alpha, t_beta, air.transition_degrees, air.transition_exemptions, root));
         uint8_t comp_root[32]; std::memcpy(comp_root, root, 32);
+        SP_TIMEPOINT("r2 composition");
         tr.append(root, 32);
         SP_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
         // ---- round 3 (reference prover.rs:652-684)
@@ -523,6 +592,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         fe h1z, h2z;
         std::vector<fe> ood;
         SP_TRY(P->ood(z, &h1z, &h2z, ood));
+        SP_TIMEPOINT("r3 ood");
         tr.append_felt(h1z); tr.append_felt(h2z);
         for (auto& e : ood) tr.append_felt(e);
         SP_HIP_CHECK(hipEventRecord(ev[3], ctx->stream));
@@ -543,6 +613,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             fri_roots.emplace_back(root, root + 32);
             tr.append(root, 32);
         }
+        SP_TIMEPOINT("r4 deep + fri commit");
         tr.append_felt(last_value);
         uint8_t gch[32];
         tr.challenge(gch);
@@ -553,10 +624,12 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
             tr.append(nb, 8);
         }
+        SP_TIMEPOINT("r4 grinding");
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings o;
         SP_TRY(P->open(iotas, o));
+        SP_TIMEPOINT("r4 openings");
         SP_HIP_CHECK(hipEventRecord(ev[4], ctx->stream));
         SP_HIP_CHECK(hipEventSynchronize(ev[4]));
         if (round_ms) {

@@ -4,6 +4,7 @@
 #include "ctx.h"
 #include "stark_kernels.h"
 #include "cairo_air_host.h"
+#include "aux_kernels.h"
 #include <vector>
 
 namespace sp {
@@ -26,6 +27,8 @@ class StarkProver : public sp_deletable {
     int setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
     // round 1: interpolate + LDE + Merkle of one trace segment (0 = main, 1 = aux); rows = row-major n x cols, ABI encoding
     int commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    // round 1, Cairo auxiliary segment built on the device from the resident main trace (reference cairo/air.rs:660-729)
+    int commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]);
     // round 2: constraint composition, H1/H2 split, LDE and commitment
     int composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
                     const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
@@ -49,6 +52,7 @@ class StarkProver : public sp_deletable {
     void free_all();
     int alloc(void** p, size_t bytes);
     int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]);
+    int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
 
     sp_ctx* c_;
     ProofOptionsHost opt_{};
@@ -68,6 +72,9 @@ class StarkProver : public sp_deletable {
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
     uint64_t* d_positions_ = nullptr;
+    fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
+    void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
+    AuxWorkspace auxws_{};
     fe z_; fe h1_z2_, h2_z2_;
     std::vector<fe> trace_ood_;
     int stage_ = 0;  // 0 new, 1 setup, 2 main committed, 3 aux committed, 4 composition, 5 ood, 6 fri running, 7 fri done

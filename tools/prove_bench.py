@@ -1,0 +1,17 @@
+#!/usr/bin/env python3
+"""Times the whole-proof device path on the BASELINE shapes. usage: prove_bench.py <fib_index> <blowup> <queries> <grinding> [check]"""
+import sys, time, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+from lambdaworks_cairo_prover_amd import api
+idx, b, q, g = (int(x) for x in sys.argv[1:5])
+t0 = time.time(); run = api.CairoRun.fibonacci(idx); tr = run.main_trace(); t1 = time.time()
+print(f"trace: fib({idx}) steps={run.num_steps} n={run.n_rows} cols={run.n_cols} gen {t1-t0:.2f}s", flush=True)
+ctx = api.Context()
+opt = api.ProofOptions(b, q, 3, g)
+for it in range(2):
+    t0 = time.time(); proof = ctx.cairo_prove(tr, run.public_inputs_c, opt); t1 = time.time()
+    print(f"prove[{it}]: wall {1e3*(t1-t0):.1f} ms, device rounds {['%.1f' % x for x in ctx.last_round_ms()]} ms, proof {len(proof)} bytes", flush=True)
+if len(sys.argv) > 5:
+    import oracle_lib as O
+    t0 = time.time(); ok = O.cairo_verify(proof, run.public_inputs_c, (b, q, 3, g)); print("oracle verify:", ok, f"{time.time()-t0:.1f}s")
