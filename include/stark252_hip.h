@@ -126,6 +126,11 @@ int sp_prove_setup(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_col
  * iNTT + LDE + batched Keccak Merkle tree; keeps polynomials, LDE and tree on the device. */
 int sp_commit_trace(sp_ctx* ctx, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]);
 
+/* CairoAIR::build_auxiliary_trace + interpolate_and_commit of the auxiliary segment, entirely on the device
+ * (reference src/cairo/air.rs:660-729, src/starks/prover.rs:199-213): rap = alpha_memory, z_memory, z_range_check
+ * sampled by the caller after the main root. Requires sp_commit_trace(0) of a Cairo main trace (34|43 columns). */
+int sp_cairo_commit_aux(sp_ctx* ctx, const uint8_t* rap, const sp_cairo_public_inputs* pub, uint8_t root_out[32]);
+
 /* BoundaryConstraint (reference src/starks/constraints/boundary.rs:13-17) */
 typedef struct { uint32_t col; uint64_t step; uint8_t value[32]; } sp_boundary_constraint;
 

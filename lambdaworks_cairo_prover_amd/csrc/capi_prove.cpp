@@ -61,6 +61,18 @@ int sp_commit_trace(sp_ctx* c, int segment, const uint8_t* rows, uint64_t n, uin
     return h->prover.commit_trace(segment, rows, cols, root_out);
 }
 
+int sp_cairo_commit_aux(sp_ctx* c, const uint8_t* rap, const sp_cairo_public_inputs* pub, uint8_t root_out[32]) {
+    if (!c || !rap || !pub || !root_out) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    try {
+        fe r[3];
+        SP_TRY(dec(c, rap, 3, r));
+        PublicInputs p = to_host_pub(pub);
+        return h->prover.commit_aux_cairo(p, r, root_out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
+}
+
 int sp_composition(sp_ctx* c, const uint8_t* rap, const sp_boundary_constraint* bc, uint32_t nb, const uint8_t* coeffs, uint32_t T, uint8_t root_out[32]) {
     if (!c || !rap || (!bc && nb) || !coeffs || !root_out) return SP_E_INVALID_ARG;
     ProverHolder* h = holder(c, false);
