@@ -56,16 +56,19 @@ SP_HD bool fe_eq(const fe& a, const fe& b) {
     return o == 0;
 }
 
+// 32-bit add/sub with carry: clang lowers these to v_addc_co_u32 / v_subb_co_u32 chains on gfx950
+#define SP_ADDC(x, y, cin, cout) __builtin_addc((uint32_t)(x), (uint32_t)(y), (unsigned)(cin), &(cout))
+#define SP_SUBC(x, y, bin, bout) __builtin_subc((uint32_t)(x), (uint32_t)(y), (unsigned)(bin), &(bout))
+
 // r = a - p if a >= p else a   (a < 2p)
 SP_HD fe fe_reduce_once(const fe& a) {
-    // d = a - p ; p = {1,0,0,0,0,0,0x11,0x08000000}
     fe d;
-    uint64_t br;
-    uint64_t t = (uint64_t)a.v[0] - SP_P0; d.v[0] = (uint32_t)t; br = (t >> 32) & 1;
+    unsigned br = 0, bo;
+    d.v[0] = SP_SUBC(a.v[0], SP_P0, br, bo); br = bo;
 #pragma unroll
-    for (int i = 1; i < 6; ++i) { t = (uint64_t)a.v[i] - br; d.v[i] = (uint32_t)t; br = (t >> 32) & 1; }
-    t = (uint64_t)a.v[6] - SP_P6 - br; d.v[6] = (uint32_t)t; br = (t >> 32) & 1;
-    t = (uint64_t)a.v[7] - SP_P7 - br; d.v[7] = (uint32_t)t; br = (t >> 32) & 1;
+    for (int i = 1; i < 6; ++i) { d.v[i] = SP_SUBC(a.v[i], 0u, br, bo); br = bo; }
+    d.v[6] = SP_SUBC(a.v[6], SP_P6, br, bo); br = bo;
+    d.v[7] = SP_SUBC(a.v[7], SP_P7, br, bo); br = bo;
     fe r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
@@ -74,79 +77,62 @@ SP_HD fe fe_reduce_once(const fe& a) {
 
 SP_HD fe fe_add(const fe& a, const fe& b) {
     fe s;
-    uint64_t c = 0;
+    unsigned c = 0, co;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { c += (uint64_t)a.v[i] + b.v[i]; s.v[i] = (uint32_t)c; c >>= 32; }
+    for (int i = 0; i < 8; ++i) { s.v[i] = SP_ADDC(a.v[i], b.v[i], c, co); c = co; }
     return fe_reduce_once(s);  // a+b < 2p < 2^256: no carry out
 }
 
 SP_HD fe fe_sub(const fe& a, const fe& b) {
     fe d;
-    uint64_t t, br = 0;
+    unsigned br = 0, bo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { t = (uint64_t)a.v[i] - b.v[i] - br; d.v[i] = (uint32_t)t; br = (t >> 32) & 1; }
+    for (int i = 0; i < 8; ++i) { d.v[i] = SP_SUBC(a.v[i], b.v[i], br, bo); br = bo; }
     // add p back when the subtraction borrowed
-    uint32_t m = (uint32_t)(0 - (uint32_t)br);
-    uint64_t c = 0;
+    const uint32_t m = 0u - (uint32_t)br;
     fe r;
-    c = (uint64_t)d.v[0] + (m & SP_P0); r.v[0] = (uint32_t)c; c >>= 32;
+    unsigned c = 0, co;
+    r.v[0] = SP_ADDC(d.v[0], m & SP_P0, c, co); c = co;
 #pragma unroll
-    for (int i = 1; i < 6; ++i) { c += (uint64_t)d.v[i]; r.v[i] = (uint32_t)c; c >>= 32; }
-    c += (uint64_t)d.v[6] + (m & SP_P6); r.v[6] = (uint32_t)c; c >>= 32;
-    c += (uint64_t)d.v[7] + (m & SP_P7); r.v[7] = (uint32_t)c;
+    for (int i = 1; i < 6; ++i) { r.v[i] = SP_ADDC(d.v[i], 0u, c, co); c = co; }
+    r.v[6] = SP_ADDC(d.v[6], m & SP_P6, c, co); c = co;
+    r.v[7] = SP_ADDC(d.v[7], m & SP_P7, c, co);
     return r;
 }
 
 SP_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
 
-// Montgomery reduction of the 16-limb integer t (< p * 2^256): returns t / 2^256 mod p, canonical.
-SP_HD fe fe_mont_reduce(uint32_t t[16]) {
-    uint32_t top = 0;  // carry out of limb 15 never happens for t < p*2^256, kept for safety in debug
+// Montgomery product, CIOS with the reduction round merged into the accumulate carry chain.
+// Row i:  u = t + a_i * b  (eight v_mad_u64_u32, D_j = a_i b_j + t_j),  m = -u_0 (p = 1 mod 2^32, so -p^-1 = -1),
+//         u += m * p  with  m * p = m + 17 m 2^192 + m 2^251  (one mad and two shifts),  t = u >> 32.
+// t stays < 2p < 2^253, so eight limbs suffice between rows; one conditional subtraction at the end.
+SP_HD fe fe_mul(const fe& a, const fe& b) {
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        uint32_t m = 0u - t[i];
-        // t += m * p * 2^(32 i):   limb i   += m            (becomes 0, carry = (t[i] != 0))
-        //                          limb i+6 += 17 m          (two limbs)
-        //                          limb i+7 += m << 27       (two limbs)
-        uint64_t c = (t[i] != 0) ? 1 : 0;
+        uint64_t D[8];
 #pragma unroll
-        for (int j = i + 1; j < i + 6; ++j) { c += t[j]; t[j] = (uint32_t)c; c >>= 32; }
-        c += (uint64_t)t[i + 6] + (uint64_t)m * 17u;
-        t[i + 6] = (uint32_t)c; c >>= 32;
-        c += (uint64_t)t[i + 7] + ((uint64_t)m << 27);
-        t[i + 7] = (uint32_t)c; c >>= 32;
+        for (int j = 0; j < 8; ++j) D[j] = (uint64_t)a.v[i] * b.v[j] + t[j];
+        const uint32_t u0 = (uint32_t)D[0];
+        const uint32_t m = 0u - u0;
+        unsigned c = (u0 != 0), c1, c2;  // u0 + m = c * 2^32
 #pragma unroll
-        for (int j = i + 8; j < 16; ++j) { c += t[j]; t[j] = (uint32_t)c; c >>= 32; }
-        top += (uint32_t)c;
+        for (int j = 1; j <= 5; ++j) { t[j - 1] = SP_ADDC(D[j], D[j - 1] >> 32, c, c1); c = c1; }
+        const uint64_t m17 = (uint64_t)m * 17u;
+        const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
+        t[5] = SP_ADDC(x6, m17, 0u, c2);
+        const uint32_t x7 = SP_ADDC(D[7], D[6] >> 32, c1, c1);
+        const uint32_t k7 = (uint32_t)(m17 >> 32) + (m << 27);  // <= 16 + multiple of 2^27: no overflow
+        t[6] = SP_ADDC(x7, k7, c2, c2);
+        const uint32_t x8 = SP_ADDC(D[7] >> 32, m >> 5, c1, c1);
+        t[7] = SP_ADDC(x8, 0u, c2, c2);
     }
-    (void)top;
     fe r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = t[8 + i];
+    for (int j = 0; j < 8; ++j) r.v[j] = t[j];
     return fe_reduce_once(r);
-}
-
-SP_HD fe fe_mul(const fe& a, const fe& b) {
-    uint32_t t[16];
-    // schoolbook 8x8: row i adds a_i * b into t[i..i+8]
-    {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { c += (uint64_t)a.v[0] * b.v[j]; t[j] = (uint32_t)c; c >>= 32; }
-        t[8] = (uint32_t)c;
-    }
-#pragma unroll
-    for (int i = 1; i < 8; ++i) {
-        uint64_t c = 0;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c += (uint64_t)a.v[i] * b.v[j] + t[i + j];
-            t[i + j] = (uint32_t)c;
-            c >>= 32;
-        }
-        t[i + 8] = (uint32_t)c;
-    }
-    return fe_mont_reduce(t);
 }
 
 SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
@@ -155,10 +141,9 @@ SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 SP_HD fe fe_to_mont(const fe& raw) { return fe_mul(raw, fe_r2()); }
 // Montgomery -> canonical integer
 SP_HD fe fe_from_mont(const fe& a) {
-    uint32_t t[16];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { t[i] = a.v[i]; t[8 + i] = 0; }
-    return fe_mont_reduce(t);
+    fe one_raw = fe_zero();
+    one_raw.v[0] = 1;
+    return fe_mul(a, one_raw);  // a * 1 / R: the zero limbs of the constant fold away
 }
 
 SP_HD fe fe_from_u64(uint64_t x) {
