@@ -54,12 +54,27 @@ typedef struct {
 
 typedef struct sp_ctx sp_ctx;
 
+/* Blocking all-gather hook for coset sharding across GPUs: every rank contributes `bytes_per_rank` bytes at send_dev
+ * (device memory) and receives world*bytes_per_rank bytes at recv_dev, rank-major. Must have completed when it returns. */
+typedef int (*sp_allgather_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+
 const char* sp_version(void);
 const char* sp_last_error(void);          /* thread-local description of the last failure */
 int sp_device_count(int* count_out);      /* number of visible HIP devices (0 without a GPU) */
 
 int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
 void sp_ctx_destroy(sp_ctx* ctx);
+
+/* ---- multi-GPU: one process and one context per GPU; the LDE cosets are sharded over `world` ranks
+ * (world a power of two <= blowup factor). Every rank calls the same sequence (sp_cairo_prove or the round-level calls)
+ * with the same inputs and obtains the same roots / proof bytes. The data-path exchanges are all-gathers of 32-byte leaf
+ * digests, composition evaluations and DEEP evaluations; everything else is local. Either install a hook ... */
+int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void* user);
+/* ... or let the library own an RCCL communicator (ncclAllGather on the context stream over xGMI): rank 0 obtains a 128-byte
+ * id with sp_comm_unique_id and distributes it out of band (e.g. torch.distributed broadcast); every rank then calls
+ * sp_comm_init_rccl with it. */
+int sp_comm_unique_id(uint8_t id_out[128]);
+int sp_comm_init_rccl(sp_ctx* ctx, const uint8_t id[128], int world, int rank);
 
 /* ---- fine-grained layer: the lambdaworks seam the reference calls ------------------------ */
 

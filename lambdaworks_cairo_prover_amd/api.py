@@ -221,3 +221,88 @@ class CairoRun:
 def generate_prover_args_fibonacci(fib_index):
     """(main_trace, public_inputs) for fib(1, 1, fib_index), the shape of the reference's benches."""
     return CairoRun.fibonacci(fib_index)
+
+
+# ---- multi-GPU: coset sharding (SURVEY.md §8(e)) ---------------------------------------------------------------
+ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64)
+
+
+def shard_global_index(i_loc, logb, shard_log, shard_rank):
+    """Global LDE index of local index i_loc on the rank holding the cosets c = c_loc * 2^shard_log + shard_rank
+    (same map as `shard_global_index` in csrc/stark_kernels.hip)."""
+    lb_loc = logb - shard_log
+    c_loc, q = i_loc & ((1 << lb_loc) - 1), i_loc >> lb_loc
+    return (q << logb) + (c_loc << shard_log) + shard_rank
+
+
+def interleave_shards(gathered, n, logb, shard_log):
+    """numpy mirror of `interleave_shards_kernel`: gathered[r][q*b_loc + c_loc] -> out[q*b + c_loc*G + r]."""
+    world = 1 << shard_log
+    g = np.asarray(gathered)
+    n_loc = g.shape[1]
+    out = np.empty((world * n_loc,) + g.shape[2:], dtype=g.dtype)
+    for r in range(world):
+        idx = np.array([shard_global_index(i, logb, shard_log, r) for i in range(n_loc)])
+        out[idx] = g[r]
+    return out
+
+
+class StagedAllGather:
+    """Blocking all-gather hook over torch.distributed with host staging (works with the gloo backend, i.e. also when
+    several ranks share one GPU). Production multi-GPU runs use the library's own RCCL communicator instead
+    (Context.init_rccl). `device_memory=False` treats the pointers as host memory (CPU-only protocol tests)."""
+
+    def __init__(self, group=None, device_memory=True):
+        import torch.distributed as dist
+        self.dist, self.group, self.device_memory = dist, group, device_memory
+        self.world = dist.get_world_size(group)
+        if device_memory:
+            self.hip = ctypes.CDLL("libamdhip64.so")
+            self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        self.cfn = ALLGATHER_FN(self._call)
+
+    def _copy(self, dst, src, nbytes, kind):
+        if self.device_memory:
+            return self.hip.hipMemcpy(dst, src, nbytes, kind)  # 1 = H2D, 2 = D2H
+        ctypes.memmove(dst, src, nbytes)
+        return 0
+
+    def _call(self, user, send, recv, nbytes):
+        try:
+            import torch
+            host = np.empty(nbytes, dtype=np.uint8)
+            if self._copy(host.ctypes.data, send, nbytes, 2) != 0:
+                return -1
+            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(outs, torch.from_numpy(host), group=self.group)
+            allb = torch.cat(outs).numpy()
+            if self._copy(recv, allb.ctypes.data, allb.nbytes, 1) != 0:
+                return -2
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -3
+
+
+def _ctx_set_collective(self, world, rank, hook):
+    self._hook = hook  # keep the callback alive
+    check(self._lib.sp_set_collective(self._h, world, rank, hook.cfn if hook is not None else None, None))
+
+
+def _ctx_init_rccl(self, group=None):
+    """Native path: ncclAllGather over xGMI on the context stream; the 128-byte id travels over torch.distributed."""
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    idb = (ctypes.c_uint8 * 128)()
+    if rank == 0:
+        check(self._lib.sp_comm_unique_id(idb))
+    obj = [bytes(idb)]
+    dist.broadcast_object_list(obj, src=0, group=group)
+    check(self._lib.sp_comm_init_rccl(self._h, obj[0], world, rank))
+
+
+Context.set_collective = _ctx_set_collective
+Context.init_rccl = _ctx_init_rccl
+__all__ += ["StagedAllGather", "shard_global_index", "interleave_shards"]

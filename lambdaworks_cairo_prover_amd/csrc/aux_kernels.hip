@@ -136,42 +136,15 @@ int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot) {
 }
 
 // ---- range-check part --------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) rc_hist_kernel(const fe* off_cols, uint64_t n, uint32_t* hist, int* flag) {
+// the 3n offsets as 16-bit keys in row-major (long) order; they are then sorted with a key-only radix sort
+// (a global-memory histogram would serialise: a Cairo trace uses only a handful of distinct offsets)
+__global__ void __launch_bounds__(256) rc_keys_kernel(const fe* off_cols, uint64_t n, uint16_t* keys, int* flag) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= 3 * n) return;
     uint64_t i = e / 3; uint32_t k = (uint32_t)(e % 3);
     fe raw = fe_from_mont(ax_ld(off_cols + (uint64_t)k * n + i));
-    if ((raw.v[0] >> 16) | raw.v[1] | raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) { atomicExch(flag, 3); return; }
-    atomicAdd(&hist[raw.v[0]], 1u);
-}
-// exclusive scan of 65536 bins -> hist[v] = first position of value v; hist[65536] = total
-__global__ void __launch_bounds__(1024) rc_scan_kernel(uint32_t* hist) {
-    __shared__ uint32_t sh[1024];
-    const uint32_t t = threadIdx.x;
-    uint32_t local = 0;
-    for (uint32_t k = 0; k < 64; ++k) local += hist[t * 64 + k];
-    sh[t] = local;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-        uint32_t o = t >= off ? sh[t - off] : 0;
-        __syncthreads();
-        sh[t] += o;
-        __syncthreads();
-    }
-    uint32_t run = t == 0 ? 0 : sh[t - 1];
-    for (uint32_t k = 0; k < 64; ++k) { uint32_t c = hist[t * 64 + k]; hist[t * 64 + k] = run; run += c; }
-    if (t == 1023) hist[65536] = run;
-}
-__global__ void __launch_bounds__(256) rc_fill_kernel(const uint32_t* start, uint64_t M, uint16_t* sorted) {
-    uint64_t p = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= M) return;
-    // largest v with start[v] <= p
-    uint32_t lo = 0, hi = 65535;
-    while (lo < hi) {
-        uint32_t mid = (lo + hi + 1) >> 1;
-        if (start[mid] <= p) lo = mid; else hi = mid - 1;
-    }
-    sorted[p] = (uint16_t)lo;
+    if ((raw.v[0] >> 16) | raw.v[1] | raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 3);
+    keys[e] = (uint16_t)raw.v[0];
 }
 __global__ void __launch_bounds__(256) rc_den_kernel(fe* den, AuxConsts K) {
     uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -211,6 +184,10 @@ size_t aux_workspace_bytes(uint64_t n, uint64_t pm_cap, size_t* sort_tmp_bytes) 
     size_t tmp = 0;
     uint64_t* k = nullptr; uint32_t* v = nullptr;
     (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, (size_t)(4 * n), 0, 64, (hipStream_t)0);
+    size_t tmp16 = 0;
+    uint16_t* k16 = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, tmp16, k16, k16, (size_t)(3 * n), 0, 16, (hipStream_t)0);
+    if (tmp16 > tmp) tmp = tmp16;
     *sort_tmp_bytes = tmp;
     size_t b = 0;
     b += 7 * align_up(sizeof(fe) * 4 * n);          // a_aux v_aux num a_s v_s den inv_scratch
@@ -264,10 +241,10 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
     SP_TRY(prefix_product(st, w.num, M, w.block_tot));
     // range check: counting sort of the 3n 16-bit offsets, permutation column
     const fe* off_cols = mem_cols + 8 * n;
-    SP_HIP_CHECK(hipMemsetAsync(w.hist, 0, sizeof(uint32_t) * 65537, st));
-    hipLaunchKernelGGL(rc_hist_kernel, blocks(M3), dim3(256), 0, st, off_cols, n, w.hist, flag);
-    hipLaunchKernelGGL(rc_scan_kernel, dim3(1), dim3(1024), 0, st, w.hist);
-    hipLaunchKernelGGL(rc_fill_kernel, blocks(M3), dim3(256), 0, st, w.hist, M3, w.rc_sorted);
+    uint16_t* rc_keys = reinterpret_cast<uint16_t*>(w.keys_in);  // the 4n u64 key buffer is free again here
+    hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, off_cols, n, rc_keys, flag);
+    size_t tmp2 = w.sort_tmp_bytes;
+    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp, tmp2, rc_keys, w.rc_sorted, (size_t)M3, 0, 16, st));
     hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, st, w.rc_den, K);
     SP_TRY(batch_inverse(st, w.rc_den, w.rc_den_scratch, 65536, flag));
     hipLaunchKernelGGL(rc_terms_kernel, blocks(M3), dim3(256), 0, st, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);

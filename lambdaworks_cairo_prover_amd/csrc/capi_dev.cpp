@@ -1,6 +1,7 @@
 // C ABI: context and the fine-grained device entry points (sp_ntt, sp_lde, sp_merkle_build, sp_batch_inverse).
 // See include/stark252_hip.h for the reference call sites each one replaces.
 #include "ctx.h"
+#include <rccl/rccl.h>
 #include <cstring>
 #include <vector>
 
@@ -51,6 +52,7 @@ void sp_ctx_destroy(sp_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     delete c->prover_state_deleter_holder;
+    delete c->comm_holder;
     delete c->ntt;
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -58,6 +60,48 @@ void sp_ctx_destroy(sp_ctx* c) {
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+}
+
+int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* user) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) || (world > 1 && !fn)) return SP_E_INVALID_ARG;
+    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user;
+    return SP_OK;
+}
+
+namespace {
+struct RcclComm : public sp_deletable {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    ~RcclComm() override { if (comm) (void)ncclCommDestroy(comm); }
+};
+int rccl_allgather(void* user, const void* send, void* recv, uint64_t bytes) {
+    RcclComm* rc = static_cast<RcclComm*>(user);
+    if (ncclAllGather(send, recv, bytes, ncclUint8, rc->comm, rc->stream) != ncclSuccess) return -1;
+    if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
+    return 0;
+}
+}  // namespace
+
+int sp_comm_unique_id(uint8_t id_out[128]) {
+    if (!id_out) return SP_E_INVALID_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    if (ncclGetUniqueId(&id) != ncclSuccess) { sp_set_error("ncclGetUniqueId failed"); return SP_E_HIP; }
+    std::memcpy(id_out, &id, 128);
+    return SP_OK;
+}
+
+int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int rank) {
+    if (!c || !id_bytes || world < 1 || rank < 0 || rank >= world || (world & (world - 1))) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_bytes, 128);
+    RcclComm* rc = new RcclComm();
+    rc->stream = c->stream;
+    if (ncclCommInitRank(&rc->comm, world, id, rank) != ncclSuccess) { delete rc; sp_set_error("ncclCommInitRank failed"); return SP_E_HIP; }
+    delete c->comm_holder;
+    c->comm_holder = rc;
+    return sp_set_collective(c, world, rank, rccl_allgather, rc);
 }
 
 int sp_sync(sp_ctx* c) {

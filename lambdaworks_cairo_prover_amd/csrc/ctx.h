@@ -19,4 +19,9 @@ struct sp_ctx {
     float last_ms = 0.f;
     float round_ms[5] = {0, 0, 0, 0, 0};
     sp_deletable* prover_state_deleter_holder = nullptr;  // round-level prover state (prover.cpp)
+    // coset sharding across GPUs: world size (power of two), rank and the blocking all-gather hook (see sp_set_collective)
+    int world = 1, rank = 0;
+    sp_allgather_fn allgather = nullptr;
+    void* allgather_user = nullptr;
+    sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

@@ -14,6 +14,8 @@ struct digest32 { uint64_t w[4]; };
 // element as canonical 32-byte big-endian.  Columns are device arrays in the device fe layout:
 // column j starts at cols + j*col_stride, element i of a column at index i (natural LDE order).
 int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes);
+// Same, but the n_leaves digests go to a plain array (coset-sharded commitment: leaves are exchanged before the tree is built).
+int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out);
 // Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves);
 // Gather authentication paths: for each of `q` leaf positions, `depth` sibling digests bottom-up (lambdaworks

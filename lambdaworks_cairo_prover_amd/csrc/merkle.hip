@@ -92,6 +92,14 @@ int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint
     return SP_OK;
 }
 
+int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out) {
+    if (n_leaves == 0 || ncols == 0) return SP_E_INVALID_ARG;
+    unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, leaves_out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
     for (uint64_t count = n_leaves >> 1; count >= 1; count >>= 1) {
         uint64_t first = count - 1;

@@ -37,6 +37,9 @@ struct NttPassArgs {
     uint32_t s_prev;      // stride (log2) of the neighbouring lower pass (inter-pass twiddle), used when s > 0
     uint32_t big_neg;     // 1: use w_M^(-E) (inverse transform)
     uint32_t log_expand;  // EXPAND load: src index = pos >> log_expand (zero-padded/replicated LDE input)
+    // Coset sharding across GPUs (LDE only): this rank holds the cosets c = c_loc * 2^shard_log + shard_rank of the
+    // 2^(log_expand + shard_log) cosets; arrays are local (2^(logM - shard_log) elements), twiddles use global indices.
+    uint32_t shard_log, shard_rank;
 };
 
 enum NttLoadMode { NTT_LOAD_INPLACE = 0, NTT_LOAD_GATHER_BITREV = 1, NTT_LOAD_EXPAND = 2 };
@@ -62,7 +65,10 @@ class NttEngine {
     int inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_t stride);
     // LDE: coeffs = n = 2^k "h-scaled" coefficients (c_j h^j) in bit-reversed order; dst = N = n*2^logb natural-order
     // evaluations p(h w_N^i).  (zero-padded size-N DIT whose first log2(b) stages are replication.)
-    int lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride);
+    // shard_log/shard_rank: compute only the cosets c = c_loc * 2^shard_log + shard_rank (dst holds n * 2^(logb - shard_log)
+    // elements per vector, element (q, c_loc) at q * 2^(logb - shard_log) + c_loc).
+    int lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride,
+                        int shard_log = 0, int shard_rank = 0);
 
     // dst[i] = src[i] * base^i * c  (natural index), c nullable. Used by the coset variants of sp_ntt.
     int scale_by_powers(fe* data, uint64_t n, uint32_t batch, uint64_t stride, const fe& base, const fe* c);

@@ -44,7 +44,8 @@ __device__ __forceinline__ fe big_root(const fe* tw, uint32_t e, uint32_t logM) 
 template <bool DIF, int LOADM, int STOREM, bool CONTIG>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
-    const uint32_t r = a.r, g = a.g, s = a.s;
+    const uint32_t r = a.r, g = a.g;
+    const uint32_t s = a.s - a.shard_log;  // local (address) stride; a.s / a.s_prev / a.logM stay global for the twiddles
     const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
     uint4* Llo = smem;
     uint4* Lhi = smem + TILE;
@@ -76,7 +77,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     };
     auto lidx = [&](uint32_t t, uint32_t gl) -> uint32_t { return CONTIG ? (gl << r) + t : (t << g) + gl; };
     auto twiddle_exp = [&](uint32_t pos) -> uint32_t {
-        uint32_t e = (bitrev(pos >> s, logM - s) * ((pos >> a.s_prev) & ((1u << (s - a.s_prev)) - 1u))) << a.s_prev;
+        // pos is the LOCAL position; bits above the stride are identical in the global index
+        uint32_t u;
+        if (LOADM == NTT_LOAD_EXPAND) u = ((pos & ((1u << s) - 1u)) << a.shard_log) + a.shard_rank;  // global coset index
+        else u = (pos >> (a.s_prev - a.shard_log)) & ((1u << (a.s - a.s_prev)) - 1u);
+        uint32_t e = (bitrev(pos >> s, logM - a.s) * u) << a.s_prev;
         return a.big_neg ? ((0u - e) & ((1u << logM) - 1u)) : e;
     };
 
@@ -94,7 +99,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         } else {
             gl = e & (G - 1); t = e >> g;
             uint32_t pos = position(t, gl);
-            if (LOADM == NTT_LOAD_EXPAND) x = ld_fe(src + (pos >> a.log_expand));
+            if (LOADM == NTT_LOAD_EXPAND) x = ld_fe(src + (pos >> s));  // s = local log2(cosets held)
             else x = ld_fe(src + pos);
             if (!DIF) {
                 uint32_t ex = twiddle_exp(pos);
@@ -266,7 +271,7 @@ int NttEngine::inv_roots_small(int k, const fe** out) {
 template <bool DIF, int LM, int SM, bool CONTIG>
 static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
-    uint32_t tiles = 1u << (a.logM - tile_log);
+    uint32_t tiles = 1u << (a.logM - a.shard_log - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, a);
     SP_HIP_CHECK(hipGetLastError());
@@ -404,8 +409,10 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
     return SP_OK;
 }
 
-int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t ss, uint64_t ds) {
+int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t ss, uint64_t ds,
+                               int shard_log, int shard_rank) {
     int K = k + logb;
+    if (shard_log < 0 || shard_log > logb) { sp_set_error("lde: more shards than cosets"); return SP_E_INVALID_ARG; }
     if (logb == 0) {  // plain evaluation: copy then DIT in place
         for (uint32_t v = 0; v < batch; ++v)
             SP_HIP_CHECK(hipMemcpyAsync(dst + v * ds, coeffs + v * ss, sizeof(fe) << k, hipMemcpyDeviceToDevice, stream_));
@@ -423,7 +430,9 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
         a.src = first ? coeffs : dst; a.dst = dst;
         a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev; a.log_expand = logb;
+        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.s_prev = p.s_prev; a.log_expand = logb;
+        a.shard_log = (uint32_t)shard_log; a.shard_rank = (uint32_t)shard_rank;
+        a.g = (uint32_t)std::min<int>(p.g, p.s - shard_log);  // adjacent elements per row cannot exceed the local stride
         SP_TRY(launch_pass(false, first ? NTT_LOAD_EXPAND : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
         first = false;
     }

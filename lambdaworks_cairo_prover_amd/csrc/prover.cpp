@@ -43,8 +43,13 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
     if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c_->device));
+    if (c_->world < 1 || (c_->world & (c_->world - 1)) || c_->rank < 0 || c_->rank >= c_->world || c_->world > (1 << lb)) {
+        sp_set_error("setup: world size must be a power of two not exceeding the blowup factor (one or more LDE cosets per GPU)");
+        return SP_E_INVALID_ARG;
+    }
+    if (c_->world > 1 && !c_->allgather) { sp_set_error("setup: world > 1 needs sp_set_collective / sp_comm_init_rccl"); return SP_E_STATE; }
     if (!allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
-        opt.coset_offset == opt_.coset_offset) {
+        opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == rank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
         return SP_OK;
@@ -53,17 +58,23 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
+    world_ = (uint32_t)c_->world; rank_ = (uint32_t)c_->rank; logG_ = (uint32_t)sp_log2_exact(world_); Nl_ = N_ >> logG_;
     h_ = fe_from_u64(opt.coset_offset);
     if (fe_is_zero(h_)) return SP_E_INVALID_ARG;
     hinv_ = fe_inv(h_);
     g_ = host_primitive_root((int)logn_);
     SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
-    SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * N_ * C_));
+    SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * std::max<uint64_t>(Nl_, n_) * C_));  // >= n per column: also stages the raw rows
     SP_TRY(alloc((void**)&d_t1_, sizeof(fe) * n_));
     SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
     SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
-    SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * N_ * 2));
-    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * N_ * 7));
+    SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * Nl_ * 2));
+    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * std::max<uint64_t>(Nl_ * 7, 4 * n_)));
+    d_local_ = nullptr; d_gather_ = nullptr;
+    if (world_ > 1) {
+        SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
+        SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * N_));
+    }
     SP_TRY(alloc((void**)&d_tree_main_, sizeof(digest32) * (2 * N_ - 1)));
     SP_TRY(alloc((void**)&d_tree_aux_, sizeof(digest32) * (2 * N_ - 1)));
     SP_TRY(alloc((void**)&d_tree_comp_, sizeof(digest32) * (2 * N_ - 1)));
@@ -92,8 +103,24 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     return SP_OK;
 }
 
+// Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank].
+int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
+    if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+    return SP_OK;
+}
+
+// Leaves are hashed from this rank's cosets; with several ranks the 32-byte leaf digests are all-gathered and put back in
+// natural order, then every rank reduces the (replicated) tree.
 int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]) {
-    SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree));
+    if (world_ == 1) {
+        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree));
+    } else {
+        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, Nl_, reinterpret_cast<digest32*>(d_local_)));
+        SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(digest32)));
+        SP_TRY(interleave_shards(c_->stream, d_gather_, tree + (N_ - 1), n_, shard_map()));
+    }
     SP_TRY(merkle_reduce(c_->stream, tree, N_));
     SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
@@ -109,7 +136,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
-    uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * N_);
+    uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
     SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
@@ -125,10 +152,10 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_));
     // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
-    fe* lde = d_lde_ + (uint64_t)col0 * N_;
-    SP_TRY(c_->ntt->lde_from_bitrev(coeffs, lde, (int)logn_, (int)logb_, cols, n_, N_));
+    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
+    SP_TRY(c_->ntt->lde_from_bitrev(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     // batch_commit (reference prover.rs:96-104) straight from the column-major LDE
-    SP_TRY(commit_columns(lde, N_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
+    SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
     return SP_OK;
 }
@@ -199,14 +226,15 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     if (steps.size() > 3) { sp_set_error("composition: more than 3 distinct boundary steps"); return SP_E_UNSUPPORTED; }
     std::vector<fe> points;
     for (uint64_t s : steps) points.push_back(fe_pow_u64(g_, s));
-    fe* binv = d_scratch_;                 // [ndist][N]
-    fe* inv_scratch = d_scratch_ + 3 * N_;  // [3N]
-    fe* comp = d_scratch_ + 6 * N_;         // [N]
+    fe* binv = d_scratch_;                  // [ndist][Nl]
+    fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 Nl]
+    fe* comp = d_fri_evals_[0];              // [N] full composition evaluations (the FRI layer-0 buffer is free until round 4)
+    fe* comp_local = world_ == 1 ? comp : d_local_;
     const uint32_t nd = (uint32_t)points.size();
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     if (nd) {
-        SP_TRY(coset_minus_points(c_->stream, binv, N_, logN_, roots, h_, points.data(), nd));
-        SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-        SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * N_, c_->d_flag));
+        SP_TRY(coset_minus_points(c_->stream, binv, Nl_, logN_, roots, h_, points.data(), nd, shard_map()));
+        SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
     }
     // --- per-coset constants: x^n takes b values h^n w_b^c (reference evaluator.rs:156-171)
     K.h = h_;
@@ -249,12 +277,16 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     }
     SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
-    SP_TRY(cairo_composition(c_->stream, d_lde_, N_, logN_, logb_, roots, d_comp_consts_, binv, comp));
+    SP_TRY(cairo_composition(c_->stream, d_lde_, Nl_, logN_, logb_, roots, d_comp_consts_, binv, comp_local, logG_, rank_));
+    if (world_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
+        SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
+        SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
+    }
     // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
     SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
-    SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, N_));
-    SP_TRY(commit_columns(d_h12_, N_, 2, d_tree_comp_, root_out));
+    SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+    SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
     int flag = 0;
     SP_HIP_CHECK(hipMemcpy(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
@@ -327,12 +359,12 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     // stored coefficients are c_k h^k, so evaluate at y / h (reference prover.rs:301-304, frame.rs:67-83)
     std::vector<fe> ys = {fe_mul(z, hinv_), fe_mul(fe_mul(z, g_), hinv_)};
     std::vector<fe> tr;
-    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, 7 * N_, tr));
+    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), tr));
     trace_ood.resize(2 * (size_t)C_);
     for (uint32_t j = 0; j < C_; ++j) { trace_ood[j] = tr[j * 2 + 0]; trace_ood[C_ + j] = tr[j * 2 + 1]; }
     std::vector<fe> yh = {fe_mul(fe_sqr(z), hinv_)};
     std::vector<fe> hv;
-    SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, 7 * N_, hv));
+    SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
     h1_z2_ = hv[0]; h2_z2_ = hv[1];
     *h1_z2 = hv[0]; *h2_z2 = hv[1];
     trace_ood_ = trace_ood;
@@ -361,11 +393,16 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
     fe pts[3] = {z_, fe_mul(z_, g_), fe_sqr(z_)};
     fe* inv = d_scratch_;
-    fe* inv_scratch = d_scratch_ + 3 * N_;
-    SP_TRY(coset_minus_points(c_->stream, inv, N_, logN_, roots, h_, pts, 3));
+    fe* inv_scratch = d_scratch_ + 3 * Nl_;
+    SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, 3, shard_map()));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * N_, c_->d_flag));
-    SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + N_, N_, d_deep_consts_, inv, d_fri_evals_[0]));
+    SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * Nl_, c_->d_flag));
+    fe* p0_local = world_ == 1 ? d_fri_evals_[0] : d_local_;
+    SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, d_deep_consts_, inv, p0_local));
+    if (world_ > 1) {  // FRI runs replicated on the all-gathered DEEP evaluations
+        SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe)));
+        SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[0], n_, shard_map()));
+    }
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;
     fri_offset_ = h_;
@@ -445,8 +482,39 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     digest32* p_main = (digest32*)carve(sizeof(digest32) * q * d0);
     digest32* p_aux = (digest32*)carve(sizeof(digest32) * q * d0);
     digest32* p_comp = (digest32*)carve(sizeof(digest32) * q * d0);
-    SP_TRY(gather_rows(st, d_lde_, N_, C_, d_positions_, q, g_trace));
-    SP_TRY(gather_rows(st, d_h12_, N_, 2, d_positions_, q, g_comp));
+    if (world_ == 1) {
+        SP_TRY(gather_rows(st, d_lde_, N_, C_, d_positions_, q, g_trace));
+        SP_TRY(gather_rows(st, d_h12_, N_, 2, d_positions_, q, g_comp));
+    } else {
+        // the LDE rows live on the rank that owns the coset of each queried index: gather local rows (index 0 for rows
+        // owned elsewhere), all-gather the small row blocks and keep the owner's copy
+        const uint32_t b = 1u << logb_, b_loc = b >> logG_;
+        std::vector<uint64_t> lpos(q);
+        for (uint32_t s = 0; s < q; ++s) {
+            uint64_t cg = pos[s] & (b - 1), qq = pos[s] >> logb_;
+            lpos[s] = ((cg & (world_ - 1)) == rank_) ? qq * b_loc + (cg >> logG_) : 0;
+        }
+        uint64_t* d_lpos = d_positions_ + 2048;
+        SP_HIP_CHECK(hipMemcpyAsync(d_lpos, lpos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        const size_t blk = (size_t)q * (C_ + 2);
+        if (blk * world_ > N_ || blk > Nl_) { sp_set_error("open: too many queries for the staging buffers"); return SP_E_UNSUPPORTED; }
+        fe* send = d_local_;
+        SP_TRY(gather_rows(st, d_lde_, Nl_, C_, d_lpos, q, send));
+        SP_TRY(gather_rows(st, d_h12_, Nl_, 2, d_lpos, q, send + (size_t)q * C_));
+        SP_TRY(all_gather(send, d_gather_, blk * sizeof(fe)));
+        std::vector<fe> all(blk * world_);
+        SP_HIP_CHECK(hipMemcpy(all.data(), d_gather_, all.size() * sizeof(fe), hipMemcpyDeviceToHost));
+        std::vector<fe> tsel((size_t)q * C_), csel((size_t)q * 2);
+        for (uint32_t s = 0; s < q; ++s) {
+            uint32_t owner = (uint32_t)(pos[s] & (b - 1)) & (world_ - 1);
+            const fe* blkp = all.data() + (size_t)owner * blk;
+            std::copy(blkp + (size_t)s * C_, blkp + (size_t)(s + 1) * C_, tsel.begin() + (size_t)s * C_);
+            std::copy(blkp + (size_t)q * C_ + 2 * s, blkp + (size_t)q * C_ + 2 * s + 2, csel.begin() + 2 * s);
+        }
+        SP_HIP_CHECK(hipMemcpyAsync(g_trace, tsel.data(), tsel.size() * sizeof(fe), hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(hipMemcpyAsync(g_comp, csel.data(), csel.size() * sizeof(fe), hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(hipStreamSynchronize(st));  // tsel / csel are locals
+    }
     SP_TRY(merkle_gather_paths(st, d_tree_main_, N_, d_positions_, q, p_main));
     if (Ca_) SP_TRY(merkle_gather_paths(st, d_tree_aux_, N_, d_positions_, q, p_aux));
     SP_TRY(merkle_gather_paths(st, d_tree_comp_, N_, d_positions_, q, p_comp));

@@ -58,6 +58,12 @@ class StarkProver : public sp_deletable {
     ProofOptionsHost opt_{};
     uint64_t n_ = 0, N_ = 0;
     uint32_t logn_ = 0, logb_ = 0, logN_ = 0, Cm_ = 0, Ca_ = 0, C_ = 0;
+    // coset sharding: this rank holds the cosets c = c_loc * G + rank; Nl_ = N / G local LDE points
+    uint32_t world_ = 1, rank_ = 0, logG_ = 0;
+    uint64_t Nl_ = 0;
+    fe *d_local_ = nullptr, *d_gather_ = nullptr;   // 32-byte staging: local shard [Nl], all-gathered shards [G][Nl]
+    int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+    ShardMap shard_map() const { return ShardMap{logb_, logG_, rank_}; }
     bool has_rc_ = false;
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
     std::vector<void*> allocs_;

@@ -17,7 +17,14 @@ int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bit
 // den[d*N + i] = h*w_N^i - point[d]   for d < ndist  (then batch-inverted by the caller).
 // Replaces the N-long zerofier tables of reference src/starks/constraints/evaluator.rs:58-72 and the Ruffini
 // divisions of src/starks/prover.rs:436-473 (evaluation form).
-int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist);
+// Coset sharding: shard = {logb, shard_log, shard_rank}; N is then the LOCAL length n * 2^(logb - shard_log) and local index
+// q * b_loc + c_loc stands for the global LDE index q * b + c_loc * 2^shard_log + shard_rank.
+struct ShardMap { uint32_t logb, shard_log, shard_rank; };
+int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist,
+                       ShardMap shard = ShardMap{0, 0, 0});
+// out[q*b + c_loc*G + r] = gathered[r][q*b_loc + c_loc] for 32-byte items (field elements or digests): reassembles the
+// natural LDE order from the all-gathered per-rank coset shards.
+int interleave_shards(hipStream_t st, const void* gathered, void* out, uint64_t n, ShardMap shard);
 
 // Constants of one composition evaluation (device copy lives in CompositionConsts_dev).
 struct CompositionConsts {
@@ -37,7 +44,7 @@ struct CompositionConsts {
 // (src/cairo/air.rs:743-767, helpers :869-1160) fused per LDE point.  lde: column-major [C][N] natural order;
 // binv: [ndist][N] inverse boundary denominators; out: [N].
 int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, uint32_t logb, const fe* roots_N,
-                      const CompositionConsts* consts_dev, const fe* binv, fe* out);
+                      const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log = 0, uint32_t shard_rank = 0);
 
 // Split of the composition polynomial (reference src/starks/prover.rs:250-252, evaluation_table.rs:27-33):
 // X = unscaled bit-reversed size-N inverse transform of the N evaluations; writes the h-scaled bit-reversed coefficient

@@ -51,18 +51,23 @@ int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bit
 
 // ---------------------------------------------------------------------------------------------- x_i - point
 struct PointsArgs { fe h; fe pt[4]; };
-__global__ void __launch_bounds__(256) coset_minus_points_kernel(fe* den, uint64_t N, uint32_t logN, const fe* roots, uint32_t ndist, PointsArgs a) {
+__device__ __forceinline__ uint32_t shard_global_index(uint32_t i_loc, ShardMap m) {
+    const uint32_t lb_loc = m.logb - m.shard_log;
+    const uint32_t c_loc = i_loc & ((1u << lb_loc) - 1u), q = i_loc >> lb_loc;
+    return (q << m.logb) + (c_loc << m.shard_log) + m.shard_rank;
+}
+__global__ void __launch_bounds__(256) coset_minus_points_kernel(fe* den, uint64_t N, uint32_t logN, const fe* roots, uint32_t ndist, PointsArgs a, ShardMap sm) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    fe x = fe_mul(root_pow(roots, (uint32_t)i, logN), a.h);
+    fe x = fe_mul(root_pow(roots, shard_global_index((uint32_t)i, sm), logN), a.h);
     for (uint32_t d = 0; d < ndist; ++d) sk_st(den + (uint64_t)d * N + i, fe_sub(x, a.pt[d]));
 }
-int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist) {
+int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist, ShardMap sm) {
     if (ndist > 4) return SP_E_INVALID_ARG;
     PointsArgs a;
     a.h = h;
     for (uint32_t d = 0; d < ndist; ++d) a.pt[d] = points_host[d];
-    hipLaunchKernelGGL(coset_minus_points_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, den, N, logN, roots_N, ndist, a);
+    hipLaunchKernelGGL(coset_minus_points_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, den, N, logN, roots_N, ndist, a, sm);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -78,7 +83,7 @@ enum {
 
 __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __restrict__ lde, uint64_t N, uint32_t logN, uint32_t logb,
                                                                 const fe* __restrict__ roots, const CompositionConsts* __restrict__ K,
-                                                                const fe* __restrict__ binv, fe* __restrict__ out) {
+                                                                const fe* __restrict__ binv, fe* __restrict__ out, uint32_t shard_log, uint32_t shard_rank) {
     extern __shared__ __attribute__((aligned(16))) uint4 sh_raw[];
     fe* sh_coef = reinterpret_cast<fe*>(sh_raw);  // [b][T + B]
     const uint32_t b = 1u << logb;
@@ -90,8 +95,12 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
     __syncthreads();
     const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
-    const uint32_t c = (uint32_t)i & (b - 1);
-    const uint64_t inext = (i + b) & (N - 1);  // frame row offset 1 = LDE index + blowup (reference frame.rs:40-59)
+    // N and i are LOCAL under coset sharding (this rank holds b_loc = b >> shard_log cosets); logN, b, c are global
+    const uint32_t b_loc = b >> shard_log;
+    const ShardMap sm{logb, shard_log, shard_rank};
+    const uint32_t iglob = shard_global_index((uint32_t)i, sm);
+    const uint32_t c = iglob & (b - 1);
+    const uint64_t inext = (i + b_loc) & (N - 1);  // frame row offset 1 = LDE index + blowup (reference frame.rs:40-59): same coset
     const fe* coef = sh_coef + c * W;
     const uint32_t A = K->main_cols;
     auto cur = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + i); };
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
         S0 = S0 + coef[49] * (acc - cur(K_RCV));
     }
     // --- combine (evaluator.rs:205-253): zerofier * (sum + exemption * sum_exempted)
-    const fe x = root_pow(roots, (uint32_t)i, logN) * K->h;
+    const fe x = root_pow(roots, iglob, logN) * K->h;
     const fe sel = cur(K_SEL);
     fe total = K->zerofier[c] * ((S0 + sel * S2) + (x - K->g_last) * (S1 + sel * S3));
     // --- boundary term (evaluator.rs:58-115)
@@ -210,10 +219,10 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
 }
 
 int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, uint32_t logb, const fe* roots_N,
-                      const CompositionConsts* consts_dev, const fe* binv, fe* out) {
+                      const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log, uint32_t shard_rank) {
     if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
     size_t lds = (size_t)(1u << logb) * (CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY) * sizeof(fe);
-    hipLaunchKernelGGL(cairo_composition_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, st, lde, N, logN, logb, roots_N, consts_dev, binv, out);
+    hipLaunchKernelGGL(cairo_composition_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), lds, st, lde, N, logN, logb, roots_N, consts_dev, binv, out, shard_log, shard_rank);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -341,6 +350,26 @@ int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32
     uint32_t total = nrows * ncols;
     if (total == 0) return SP_OK;
     hipLaunchKernelGGL(gather_rows_kernel, dim3((total + 127) / 128), dim3(128), 0, st, cols_base, col_stride, ncols, rows_dev, nrows, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- shard reassembly
+__global__ void __launch_bounds__(256) interleave_shards_kernel(const uint4* gathered, uint4* out, uint64_t n, ShardMap m) {
+    const uint32_t lb_loc = m.logb - m.shard_log;
+    const uint64_t Nl = n << lb_loc, N = n << m.logb;
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;  // global index
+    if (i >= N) return;
+    uint32_t c = (uint32_t)i & ((1u << m.logb) - 1u);
+    uint64_t q = i >> m.logb;
+    uint32_t r = c & ((1u << m.shard_log) - 1u), c_loc = c >> m.shard_log;
+    uint64_t src = (uint64_t)r * Nl + (q << lb_loc) + c_loc;
+    out[2 * i] = gathered[2 * src];
+    out[2 * i + 1] = gathered[2 * src + 1];
+}
+int interleave_shards(hipStream_t st, const void* gathered, void* out, uint64_t n, ShardMap m) {
+    uint64_t N = n << m.logb;
+    hipLaunchKernelGGL(interleave_shards_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const uint4*)gathered, (uint4*)out, n, m);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
