@@ -190,6 +190,10 @@ int sp_open(sp_ctx* ctx, const uint64_t* iotas, uint32_t q, sp_openings* out);
  * context encoding. *proof_out is malloc'd; release it with sp_free. The bytes equal the reference prover's. */
 int sp_cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
                    const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
+/* Same with the main trace already resident in device memory (row-major, context encoding): the timed region of bench.py
+ * starts with its input in HBM; sp_cairo_prove additionally pays the PCIe copy of n*cols*32 bytes. */
+int sp_cairo_prove_dev(sp_ctx* ctx, const void* main_trace_dev, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                       const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
 void sp_free(void* p);
 /* Device time (ms, HIP events on the context stream) of rounds 0..4 of the last sp_cairo_prove. */
 int sp_last_round_ms(sp_ctx* ctx, float out[5]);

@@ -123,6 +123,17 @@ class Context:
         self._lib.sp_free(out)
         return proof
 
+    def cairo_prove_dev(self, trace_dev_ptr, n, cols, public_inputs_c, options):
+        """Same as cairo_prove with the (n, cols, 32)-byte main trace already in device memory at `trace_dev_ptr`."""
+        opt = options.to_c()
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_uint64()
+        check(self._lib.sp_cairo_prove_dev(self._h, ctypes.c_void_p(trace_dev_ptr), ctypes.c_uint64(n), ctypes.c_uint32(cols),
+                                           ctypes.byref(public_inputs_c), ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln)))
+        proof = ctypes.string_at(out, ln.value)
+        self._lib.sp_free(out)
+        return proof
+
     def last_round_ms(self):
         ms = (ctypes.c_float * 5)()
         check(self._lib.sp_last_round_ms(self._h, ms))

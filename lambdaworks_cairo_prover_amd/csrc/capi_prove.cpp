@@ -155,15 +155,27 @@ int sp_open(sp_ctx* c, const uint64_t* iotas, uint32_t q, sp_openings* out) {
     return SP_OK;
 }
 
+static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, bool on_device);
+
 int sp_cairo_prove(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
                    const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    return cairo_prove_impl(c, main_trace, n, cols, pub, opt, proof_out, proof_len, false);
+}
+int sp_cairo_prove_dev(sp_ctx* c, const void* main_trace_dev, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                       const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    return cairo_prove_impl(c, static_cast<const uint8_t*>(main_trace_dev), n, cols, pub, opt, proof_out, proof_len, true);
+}
+
+static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
+                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, bool on_device) {
     if (!c || !main_trace || !pub || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
     try {
         PublicInputs p = to_host_pub(pub);
         ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
         std::vector<uint8_t> bytes;
         float ms[5] = {0, 0, 0, 0, 0};
-        int rc = cairo_prove(c, main_trace, n, cols, p, o, bytes, ms);
+        int rc = cairo_prove(c, main_trace, n, cols, p, o, bytes, ms, on_device);
         if (rc != SP_OK) return rc;
         std::memcpy(c->round_ms, ms, sizeof(ms));
         *proof_out = (uint8_t*)std::malloc(bytes.size());

@@ -127,7 +127,7 @@ int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t nc
     return SP_OK;
 }
 
-int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], bool rows_on_device) {
     if (!rows_host || !root_out) return SP_E_INVALID_ARG;
     if (!((segment == 0 && stage_ == 1 && cols == Cm_) || (segment == 1 && stage_ == 2 && cols == Ca_))) {
         sp_set_error("commit_trace: wrong segment order or column count");
@@ -137,9 +137,13 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
-    SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
-    SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
+    if (rows_on_device) {
+        SP_TRY(rows_to_columns(c_->stream, c_->enc, rows_host, n_, cols, coeffs, n_));
+    } else {
+        SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
+        SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
+    }
     if (segment == 0 && cols >= 30)  // memory and offset columns feed the Cairo auxiliary trace
         SP_HIP_CHECK(hipMemcpyAsync(d_memcols_, coeffs + 19 * n_, sizeof(fe) * n_ * 11, hipMemcpyDeviceToDevice, c_->stream));
     return commit_segment_resident(segment, cols, root_out);
@@ -610,7 +614,7 @@ bool z_in_domains(const fe& z, const fe& hinv, uint32_t logn, uint32_t logN) {  
 }  // namespace
 
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
-                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5]) {
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device) {
     try {
         CairoAirInfo air = cairo_air_info(pub);
         if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
@@ -629,7 +633,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         uint8_t root[32];
         // ---- round 1 (reference prover.rs:187-224)
         SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
-        SP_TRY(P->commit_trace(0, main_trace, cols, root));
+        SP_TRY(P->commit_trace(0, main_trace, cols, root, trace_on_device));
         uint8_t main_root[32]; std::memcpy(main_root, root, 32);
         SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");
         tr.append(root, 32);

@@ -26,7 +26,8 @@ class StarkProver : public sp_deletable {
 
     int setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
     // round 1: interpolate + LDE + Merkle of one trace segment (0 = main, 1 = aux); rows = row-major n x cols, ABI encoding
-    int commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    // rows_on_device: `rows` is device memory (same row-major ABI encoding) — no PCIe copy inside the round
+    int commit_trace(int segment, const uint8_t* rows, uint32_t cols, uint8_t root_out[32], bool rows_on_device = false);
     // round 1, Cairo auxiliary segment built on the device from the resident main trace (reference cairo/air.rs:660-729)
     int commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]);
     // round 2: constraint composition, H1/H2 split, LDE and commitment
@@ -89,6 +90,6 @@ class StarkProver : public sp_deletable {
 // Whole proof on the device: generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + serialize
 // (src/starks/proof/stark.rs:161-218). main_trace: row-major n x cols in the context encoding.
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
-                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5]);
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device = false);
 
 }  // namespace sp
