@@ -55,7 +55,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
         return SP_OK;
     }
     free_all();
-    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0;
+    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; h_full_ = false;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
     world_ = (uint32_t)c_->world; rank_ = (uint32_t)c_->rank; logG_ = (uint32_t)sp_log2_exact(world_); Nl_ = N_ >> logG_;
@@ -288,12 +288,29 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     }
     // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
-    SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
-    SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
-    SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
+    // A trace that satisfies its constraints gives deg H < 2n; otherwise the reference still proves (with longer H1/H2):
+    // detect that case and fall back to the general split so the bytes stay identical for every input.
     int flag = 0;
-    SP_HIP_CHECK(hipMemcpy(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost));
+    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
     if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+    SP_TRY(high_coeff_check(c_->stream, comp, N_, logb_, c_->d_flag));
+    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    h_full_ = flag != 0;
+    if (!h_full_) {
+        SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
+        SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+    } else {
+        if (world_ > 1) { sp_set_error("composition: the trace violates its constraints (deg H >= 2n); unsupported with coset sharding"); return SP_E_UNSUPPORTED; }
+        if (!d_hfull_) SP_TRY(alloc((void**)&d_hfull_, sizeof(fe) * N_));
+        fe* t_half = d_scratch_;  // N/2 entries: N^-1 h^(-rev_{N/2}(q))
+        fe Ninv = fe_inv(fe_from_u64(N_));
+        SP_TRY(gen_power_table(c_->stream, t_half, N_ >> 1, logN_ - 1, hinv_, Ninv));
+        SP_TRY(split_composition_full(c_->stream, comp, N_, t_half, hinv_, d_hfull_, d_hfull_ + (N_ >> 1)));
+        SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_h12_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
+    }
+    SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
     stage_ = 4;
     return SP_OK;
 }
@@ -368,7 +385,8 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     for (uint32_t j = 0; j < C_; ++j) { trace_ood[j] = tr[j * 2 + 0]; trace_ood[C_ + j] = tr[j * 2 + 1]; }
     std::vector<fe> yh = {fe_mul(fe_sqr(z), hinv_)};
     std::vector<fe> hv;
-    SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
+    if (!h_full_) SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
+    else SP_TRY(eval_bitrev(c_, d_hfull_, N_ >> 1, 2, logN_ - 1, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
     h1_z2_ = hv[0]; h2_z2_ = hv[1];
     *h1_z2 = hv[0]; *h2_z2 = hv[1];
     trace_ood_ = trace_ood;
@@ -442,9 +460,16 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
         fri_layer_ += 1;
         *is_last = 0;
     } else {
-        // the log2(n)-th fold leaves a constant polynomial: every remaining evaluation equals it (fri/mod.rs:58-67)
-        SP_HIP_CHECK(hipMemcpyAsync(last_value, d_fri_evals_[k + 1], sizeof(fe), hipMemcpyDeviceToHost, c_->stream));
+        // fri_last_value is coefficient 0 of the last folded polynomial (fri/mod.rs:58-67). Its degree is below the b
+        // remaining evaluation points, so c_0 = (1/b) * sum of the evaluations on the coset (for a valid trace the
+        // polynomial is constant and every evaluation already equals it).
+        const uint32_t bb = 1u << logb_;
+        std::vector<fe> ev(bb);
+        SP_HIP_CHECK(hipMemcpyAsync(ev.data(), d_fri_evals_[k + 1], sizeof(fe) * bb, hipMemcpyDeviceToHost, c_->stream));
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        fe sum = fe_zero();
+        for (auto& e : ev) sum = fe_add(sum, e);
+        *last_value = fe_mul(sum, fe_inv(fe_from_u64(bb)));
         *is_last = 1;
         stage_ = 7;
     }

@@ -82,6 +82,7 @@ class StarkProver : public sp_deletable {
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
     AuxWorkspace auxws_{};
+    fe* d_hfull_ = nullptr; bool h_full_ = false;  // general (degree >= 2n) composition polynomial: N/2 coefficients per half
     fe z_; fe h1_z2_, h2_z2_;
     std::vector<fe> trace_ood_;
     int stage_ = 0;  // 0 new, 1 setup, 2 main committed, 3 aux committed, 4 composition, 5 ood, 6 fri running, 7 fri done

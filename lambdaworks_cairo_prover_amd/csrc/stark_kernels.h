@@ -52,6 +52,11 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, 
 // t2[q] = N^-1 h^(-rev_n(q)).
 int split_composition(hipStream_t st, const fe* X, uint64_t n, uint32_t logb, const fe* t2, const fe& hinv, fe* H1s, fe* H2s);
 
+// Degree check and general split for traces that violate their constraints (the reference still emits a proof for them,
+// reference src/starks/prover.rs:106-123 subsamples the longer FFT): see stark_kernels.hip.
+int high_coeff_check(hipStream_t st, const fe* X, uint64_t N, uint32_t logb, int* flag_dev);
+int split_composition_full(hipStream_t st, const fe* X, uint64_t N, const fe* t_half, const fe& hinv, fe* H1f, fe* H2f);
+
 // One level of the out-of-domain evaluation (reference src/starks/prover.rs:301-304, frame.rs:67-83; Horner replaced
 // by a bit-reversed-order fold): out[v][p][q'] = sum_t in[v][(p)][q' + t*M/2^l] * yp[p][t]   for q' < M/2^l.
 // first level: in has no point dimension (in_points = 1), later levels have in_points = points.

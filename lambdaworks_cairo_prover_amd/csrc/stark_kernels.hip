@@ -19,14 +19,7 @@ __device__ __forceinline__ void sk_st(fe* p, const fe& a) {
 }
 __device__ __forceinline__ fe operator+(const fe& a, const fe& b) { return fe_add(a, b); }
 __device__ __forceinline__ fe operator-(const fe& a, const fe& b) { return fe_sub(a, b); }
-__device__ __forceinline__ fe operator*(const fe& a, const fe& b) {
-    // keep each 256-bit product contiguous in the schedule: interleaving independent products for ILP multiplies the
-    // live carry / partial-product registers
-    __builtin_amdgcn_sched_barrier(0);
-    fe r = fe_mul(a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    return r;
-}
+__device__ __forceinline__ fe operator*(const fe& a, const fe& b) { return fe_mul(a, b); }
 
 // w_N^e (e in [0, N)) from the half table
 __device__ __forceinline__ fe root_pow(const fe* tw, uint32_t e, uint32_t logN) {
@@ -88,9 +81,6 @@ enum {
     K_RC0 = 34, K_RCV = 42
 };
 
-// keeps the loads of one constraint group from being hoisted above the previous group (register pressure)
-#define SP_PHASE_FENCE() asm volatile("" ::: "memory")
-
 __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __restrict__ lde, uint64_t N, uint32_t logN, uint32_t logb,
                                                                 const fe* __restrict__ roots, const CompositionConsts* __restrict__ K,
                                                                 const fe* __restrict__ binv, fe* __restrict__ out, uint32_t shard_log, uint32_t shard_rank) {
@@ -119,66 +109,59 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
     const fe one = fe_one();
     fe S0 = fe_zero(), S1 = fe_zero(), S2 = fe_zero(), S3 = fe_zero();
     // S0: no selector, no exemption; S1: exempted; S2: selector; S3: selector and exempted.
-    // Every accumulation is followed by a compiler fence: the column loads of one constraint must not be hoisted above
-    // the previous constraint, otherwise ~50 live 256-bit values spill (latency is hidden by occupancy instead).
-#define SP_ACC(S, k, expr) { S = S + coef[k] * (expr); SP_PHASE_FENCE(); }
 
     // --- flags (air.rs:869-881) and the instruction word (air.rs:883-896)
     fe f0s = fe_zero();
-#pragma unroll 1
     for (int k = 14; k >= 0; --k) {
         fe f = cur(k);
         S0 = S0 + coef[k] * (f * f - f);
         f0s = f + (f0s + f0s);
     }
-    SP_ACC(S0, 15, cur(15));
+    S0 = S0 + coef[15] * cur(15);
     {
-        fe c16 = K->b48 * f0s - cur(K_INST);
-        c16 = c16 + cur(K_OFF_DST);
-        c16 = c16 + K->b16 * cur(K_OFF_OP0);
-        c16 = c16 + K->b32 * cur(K_OFF_OP1);
-        SP_ACC(S2, 16, c16);
+        fe c16 = cur(K_OFF_DST) + K->b16 * cur(K_OFF_OP0) + K->b32 * cur(K_OFF_OP1) + K->b48 * f0s - cur(K_INST);
+        S2 = S2 + coef[16] * c16;
     }
     const fe ap = cur(K_AP), fp = cur(K_FP), pc = cur(K_PC);
     // --- operand constraints (air.rs:899-924)
     {
-        const fe d = fp - ap;
-        SP_ACC(S2, 17, ap + cur(0) * d + (cur(K_OFF_DST) - K->b15) - cur(K_DST_ADDR));
-        SP_ACC(S2, 18, ap + cur(1) * d + (cur(K_OFF_OP0) - K->b15) - cur(K_OP0_ADDR));
+        fe f_dst_fp = cur(0), f_op0_fp = cur(1);
+        fe d = fp - ap;
+        S2 = S2 + coef[17] * (ap + f_dst_fp * d + (cur(K_OFF_DST) - K->b15) - cur(K_DST_ADDR));
+        S2 = S2 + coef[18] * (ap + f_op0_fp * d + (cur(K_OFF_OP0) - K->b15) - cur(K_OP0_ADDR));
         fe f2 = cur(2), f3 = cur(3), f4 = cur(4);
-        fe c19 = f2 * pc + f4 * ap + f3 * fp + (one - f2 - f4 - f3) * cur(K_OP0);
-        SP_PHASE_FENCE();
-        SP_ACC(S2, 19, c19 + (cur(K_OFF_OP1) - K->b15) - cur(K_OP1_ADDR));
+        fe op0 = cur(K_OP0);
+        fe c19 = f2 * pc + f4 * ap + f3 * fp + (one - f2 - f4 - f3) * op0 + (cur(K_OFF_OP1) - K->b15) - cur(K_OP1_ADDR);
+        S2 = S2 + coef[19] * c19;
     }
     // --- register constraints (air.rs:926-959)
     {
-        const fe pc_size = pc + cur(2) + one;  // pc + frame_inst_size (air.rs:1137-1139)
-        {
-            fe f12 = cur(12);
-            SP_ACC(S3, 20, ap + cur(10) * cur(K_RES) + cur(11) + (f12 + f12) - nxt(K_AP));
-            fe f13 = cur(13);
-            SP_ACC(S3, 21, f13 * cur(K_DST) + f12 * (ap + K->two) + (one - f13 - f12) * fp - nxt(K_FP));
-            SP_ACC(S2, 28, f12 * (cur(K_DST) - fp));
-            SP_ACC(S2, 29, f12 * (cur(K_OP0) - pc_size));
-        }
-        {
-            const fe f9 = cur(9), t0 = cur(K_T0), npc = nxt(K_PC);
-            SP_ACC(S3, 22, (cur(K_T1) - f9) * (npc - pc_size));
-            {
-                fe f7 = cur(7), f8 = cur(8), res = cur(K_RES);
-                fe c23 = t0 * (npc - (pc + cur(K_OP1))) + (one - f9) * npc -
-                         ((one - f7 - f8 - f9) * pc_size + f7 * res + f8 * (pc + res));
-                SP_ACC(S3, 23, c23);
-            }
-            SP_ACC(S2, 24, f9 * cur(K_DST) - t0);
-            SP_ACC(S2, 25, t0 * cur(K_RES) - cur(K_T1));
-            // --- opcode constraints (air.rs:961-978)
-            fe op0 = cur(K_OP0), op1 = cur(K_OP1), mul = cur(K_MUL);
-            SP_ACC(S2, 26, mul - op0 * op1);
-            fe f5 = cur(5), f6 = cur(6);
-            SP_ACC(S2, 27, f5 * (op0 + op1) + f6 * mul + (one - f5 - f6 - f9) * op1 - (one - f9) * cur(K_RES));
-        }
-        SP_ACC(S2, 30, cur(14) * (cur(K_DST) - cur(K_RES)));
+        fe res = cur(K_RES), dst = cur(K_DST);
+        fe f9 = cur(9), f12 = cur(12), f13 = cur(13);
+        fe size = cur(2) + one;  // frame_inst_size (air.rs:1137-1139)
+        fe npc = nxt(K_PC);
+        fe c20 = ap + cur(10) * res + cur(11) + (f12 + f12) - nxt(K_AP);
+        S3 = S3 + coef[20] * c20;
+        fe c21 = f13 * dst + f12 * (ap + K->two) + (one - f13 - f12) * fp - nxt(K_FP);
+        S3 = S3 + coef[21] * c21;
+        fe t0 = cur(K_T0), t1 = cur(K_T1);
+        fe pc_size = pc + size;
+        S3 = S3 + coef[22] * ((t1 - f9) * (npc - pc_size));
+        fe f7 = cur(7), f8 = cur(8);
+        fe c23 = t0 * (npc - (pc + cur(K_OP1))) + (one - f9) * npc -
+                 ((one - f7 - f8 - f9) * pc_size + f7 * res + f8 * (pc + res));
+        S3 = S3 + coef[23] * c23;
+        S2 = S2 + coef[24] * (f9 * dst - t0);
+        S2 = S2 + coef[25] * (t0 * res - t1);
+        // --- opcode constraints (air.rs:961-978)
+        fe op0 = cur(K_OP0), op1 = cur(K_OP1), mul = cur(K_MUL);
+        fe f5 = cur(5), f6 = cur(6);
+        S2 = S2 + coef[26] * (mul - op0 * op1);
+        fe c27 = f5 * (op0 + op1) + f6 * mul + (one - f5 - f6 - f9) * op1 - (one - f9) * res;
+        S2 = S2 + coef[27] * c27;
+        S2 = S2 + coef[28] * (f12 * (dst - fp));
+        S2 = S2 + coef[29] * (f12 * (op0 - pc_size));
+        S2 = S2 + coef[30] * (cur(14) * (dst - res));
     }
     // --- memory (air.rs:987-1043) and permutation argument (air.rs:1045-1090)
     {
@@ -205,30 +188,24 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
             a_prev = a_k; v_prev = v_k; p_prev = p_k;
         }
     }
-    SP_PHASE_FENCE();
     // --- range check (air.rs:1092-1135)
     {
         const fe zrc = K->rap[2];
-        const fe rc1 = cur(A + 1), rc2 = cur(A + 2), rc0n = nxt(A + 0);
-        {
-            fe rc0 = cur(A + 0);
-            SP_ACC(S0, 43, (rc0 - rc1) * (rc1 - rc0 - one));
-        }
-        SP_ACC(S0, 44, (rc1 - rc2) * (rc2 - rc1 - one));
-        SP_ACC(S1, 45, (rc2 - rc0n) * (rc0n - rc2 - one));
-        const fe q1 = cur(A + 16), q2 = cur(A + 17);
-        SP_ACC(S0, 46, (zrc - rc1) * q1 - (zrc - cur(K_OFF_OP0)) * cur(A + 15));
-        SP_ACC(S0, 47, (zrc - rc2) * q2 - (zrc - cur(K_OFF_OP1)) * q1);
-        SP_ACC(S0, 48, (zrc - rc0n) * nxt(A + 15) - (zrc - nxt(K_OFF_DST)) * q2);
+        fe rc0 = cur(A + 0), rc1 = cur(A + 1), rc2 = cur(A + 2), rc0n = nxt(A + 0);
+        S0 = S0 + coef[43] * ((rc0 - rc1) * (rc1 - rc0 - one));
+        S0 = S0 + coef[44] * ((rc1 - rc2) * (rc2 - rc1 - one));
+        S1 = S1 + coef[45] * ((rc2 - rc0n) * (rc0n - rc2 - one));
+        fe q0 = cur(A + 15), q1 = cur(A + 16), q2 = cur(A + 17), q0n = nxt(A + 15);
+        S0 = S0 + coef[46] * ((zrc - rc1) * q1 - (zrc - cur(K_OFF_OP0)) * q0);
+        S0 = S0 + coef[47] * ((zrc - rc2) * q2 - (zrc - cur(K_OFF_OP1)) * q1);
+        S0 = S0 + coef[48] * ((zrc - rc0n) * q0n - (zrc - nxt(K_OFF_DST)) * q2);
     }
     // --- range-check builtin (air.rs:1141-1160)
     if (K->has_rc_builtin) {
         fe acc = fe_zero();
-#pragma unroll 1
         for (int k = 7; k >= 0; --k) acc = acc * K->b16 + cur(K_RC0 + k);
-        SP_ACC(S0, 49, acc - cur(K_RCV));
+        S0 = S0 + coef[49] * (acc - cur(K_RCV));
     }
-    SP_PHASE_FENCE();
     // --- combine (evaluator.rs:205-253): zerofier * (sum + exemption * sum_exempted)
     const fe x = root_pow(roots, iglob, logN) * K->h;
     const fe sel = cur(K_SEL);
@@ -269,6 +246,39 @@ int split_composition(hipStream_t st, const fe* X, uint64_t n, uint32_t logb, co
     if (logb == 0) { sp_set_error("split_composition: blowup factor must be >= 2"); return SP_E_UNSUPPORTED; }
     SplitArgs a; a.hinv = hinv;
     hipLaunchKernelGGL(split_composition_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, X, n, logb, t2, a, H1s, H2s);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// flag |= 1 when the composition polynomial has a non-zero coefficient of degree >= 2n (a trace that violates its
+// constraints): X = unscaled bit-reversed size-N inverse transform; coefficient k sits at rev_N(k), so "k >= 2n" means
+// "some of the low log2(b)-1 bits of the position inside its half are set".
+__global__ void __launch_bounds__(256) high_coeff_check_kernel(const fe* X, uint64_t N, uint32_t logb, int* flag) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= N) return;
+    if (logb < 2) return;  // b = 2: every coefficient index below N is < 2n
+    uint64_t low = q & ((1ULL << (logb - 1)) - 1ULL);
+    if (low == 0) return;
+    if (!fe_is_zero(sk_ld(X + q))) atomicOr(flag, 1);
+}
+int high_coeff_check(hipStream_t st, const fe* X, uint64_t N, uint32_t logb, int* flag_dev) {
+    hipLaunchKernelGGL(high_coeff_check_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, X, N, logb, flag_dev);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+// General split (no degree assumption): H1f[q] = X[q] * t[q], H2f[q] = X[N/2 + q] * t[q] * hinv for q < N/2,
+// t[q] = N^-1 h^(-rev_{N/2}(q)); both are h-scaled bit-reversed coefficient arrays of N/2 entries.
+__global__ void __launch_bounds__(256) split_full_kernel(const fe* X, uint64_t half, const fe* t, SplitArgs a, fe* H1f, fe* H2f) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= half) return;
+    fe tq = sk_ld(t + q);
+    sk_st(H1f + q, fe_mul(sk_ld(X + q), tq));
+    sk_st(H2f + q, fe_mul(fe_mul(sk_ld(X + half + q), tq), a.hinv));
+}
+int split_composition_full(hipStream_t st, const fe* X, uint64_t N, const fe* t_half, const fe& hinv, fe* H1f, fe* H2f) {
+    SplitArgs a; a.hinv = hinv;
+    uint64_t half = N >> 1;
+    hipLaunchKernelGGL(split_full_kernel, dim3((unsigned)((half + 255) / 256)), dim3(256), 0, st, X, half, t_half, a, H1f, H2f);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
