@@ -219,6 +219,14 @@ int sp_cairo_run_main_trace(const sp_cairo_run* run, int fe_encoding, uint8_t* o
 /* Fills `pi`; the pointers inside stay valid until sp_cairo_run_free(run). */
 int sp_cairo_run_public_inputs(const sp_cairo_run* run, sp_cairo_public_inputs* pi);
 
+/* verify_cairo_proof (reference src/cairo/air.rs:1176-1182, src/starks/verifier.rs:559-657) on the host CPU: returns 1 when the
+ * proof is accepted, 0 when it is rejected or malformed. Ships with the library so that proofs of shapes without a golden
+ * file can be checked where they are produced. */
+int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* pub, const sp_proof_options* opt);
+/* CLI proof file of the reference (src/main.rs:98-102): u64_be(len(proof)) || proof || PublicInputs::serialize
+ * (src/cairo/air.rs:223-276). *out is malloc'd; release with sp_free. */
+int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cairo_run* run, uint8_t** out, uint64_t* out_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -229,6 +229,24 @@ class CairoRun:
             pass
 
 
+def cairo_verify(proof, public_inputs_c, options):
+    """verify_cairo_proof (reference src/cairo/air.rs:1176-1182) on the host CPU through the library (no GPU needed)."""
+    lib = _lib.load()
+    opt = options.to_c()
+    return lib.sp_cairo_verify(proof, ctypes.c_uint64(len(proof)), ctypes.byref(public_inputs_c), ctypes.byref(opt)) == 1
+
+
+def proof_file_bytes(proof, run):
+    """u64_be(len) || proof || PublicInputs, the file format of the reference CLI (src/main.rs:98-102)."""
+    lib = _lib.load()
+    out = ctypes.POINTER(ctypes.c_uint8)()
+    ln = ctypes.c_uint64()
+    check(lib.sp_proof_file_encode(proof, ctypes.c_uint64(len(proof)), run._h, ctypes.byref(out), ctypes.byref(ln)))
+    b = ctypes.string_at(out, ln.value)
+    lib.sp_free(out)
+    return b
+
+
 def generate_prover_args_fibonacci(fib_index):
     """(main_trace, public_inputs) for fib(1, 1, fib_index), the shape of the reference's benches."""
     return CairoRun.fibonacci(fib_index)
@@ -316,4 +334,4 @@ def _ctx_init_rccl(self, group=None):
 
 Context.set_collective = _ctx_set_collective
 Context.init_rccl = _ctx_init_rccl
-__all__ += ["StagedAllGather", "shard_global_index", "interleave_shards"]
+__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards"]

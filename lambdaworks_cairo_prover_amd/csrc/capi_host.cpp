@@ -3,6 +3,7 @@
 #include "cairo_host.h"
 #include "common.h"
 #include <cstring>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -20,6 +21,7 @@ struct sp_cairo_run {
 
 static thread_local std::string g_last_error;
 void sp_set_error(const std::string& s) { g_last_error = s; }
+namespace sp { int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding); }
 
 extern "C" {
 
@@ -121,6 +123,40 @@ int sp_cairo_run_public_inputs(const sp_cairo_run* crun, sp_cairo_public_inputs*
     pi->n_public_memory = p.public_memory.size();
     pi->public_memory = run->pm_bytes.data();
     pi->num_steps = p.num_steps;
+    return SP_OK;
+}
+
+// verify_cairo_proof (reference src/cairo/air.rs:1176-1182): 1 = accept, 0 = reject (also for malformed proofs).
+int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* p, const sp_proof_options* opt) {
+    if (!proof || !p || !opt) return SP_E_INVALID_ARG;
+    try {
+        sp::PublicInputs r;
+        r.pc_init = fe_from_bytes_be(p->pc_init); r.ap_init = fe_from_bytes_be(p->ap_init); r.fp_init = fe_from_bytes_be(p->fp_init);
+        r.pc_final = fe_from_bytes_be(p->pc_final); r.ap_final = fe_from_bytes_be(p->ap_final);
+        r.has_rc_min = r.has_rc_max = true;
+        r.range_check_min = p->range_check_min; r.range_check_max = p->range_check_max;
+        for (uint32_t i = 0; i < p->n_segments; ++i) r.memory_segments.push_back({p->segment_types[i], p->segment_ranges[2 * i], p->segment_ranges[2 * i + 1]});
+        for (uint64_t i = 0; i < p->n_public_memory; ++i) {
+            fe a = fe_from_mont(fe_from_bytes_be(p->public_memory + 64 * i));
+            r.public_memory.push_back({(uint64_t)a.v[0] | ((uint64_t)a.v[1] << 32), fe_from_bytes_be(p->public_memory + 64 * i + 32)});
+        }
+        r.num_steps = p->num_steps;
+        return sp::cairo_verify_host(proof, proof_len, r, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
+}
+
+// CLI proof file of the reference (src/main.rs:98-102): u64_be(len(proof)) || proof || PublicInputs::serialize.
+// *out is malloc'd (sp_free). The public-memory order of the reference is HashMap order; this writer uses address order.
+int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cairo_run* run, uint8_t** out, uint64_t* out_len) {
+    if (!proof || !run || !out || !out_len) return SP_E_INVALID_ARG;
+    std::vector<uint8_t> pi = sp::serialize_public_inputs(run->pub);
+    uint64_t total = 8 + proof_len + pi.size();
+    uint8_t* b = (uint8_t*)std::malloc(total);
+    if (!b) return SP_E_ALLOC;
+    for (int i = 0; i < 8; ++i) b[i] = (uint8_t)(proof_len >> (56 - 8 * i));
+    std::memcpy(b + 8, proof, proof_len);
+    std::memcpy(b + 8 + proof_len, pi.data(), pi.size());
+    *out = b; *out_len = total;
     return SP_OK;
 }
 

@@ -1,0 +1,297 @@
+// CPU verifier shipped with the library: `verify` of reference src/starks/verifier.rs:559-657
+// (steps 1-4 :59-557) for the Cairo AIR, plus the CLI proof-file framing of reference src/main.rs:98-102.
+// O(queries * log N) hashes — host code, no device work. Unlike the reference (verifier.rs:411-422 discards the fold
+// result) the trace-opening Merkle checks are enforced.
+#include "cairo_air_host.h"
+#include "common.h"
+#include "keccak.h"
+#include <array>
+#include <cstring>
+#include <stdexcept>
+
+namespace sp {
+
+// CairoAIR::compute_transition on a 2-row out-of-domain frame (reference src/cairo/air.rs:743-767, helpers :869-1160)
+void cairo_transition_host(const fe* frame, uint32_t cols, bool has_rc, const fe rap[3], fe* c) {
+    const fe* cur = frame;
+    const fe* nxt = frame + cols;
+    const uint32_t A = has_rc ? 43 : 34;
+    const fe one = fe_one(), two = fe_from_u64(2);
+    auto add = [](const fe& a, const fe& b) { return fe_add(a, b); };
+    auto sub = [](const fe& a, const fe& b) { return fe_sub(a, b); };
+    auto mul = [](const fe& a, const fe& b) { return fe_mul(a, b); };
+    for (int k = 0; k < 15; ++k) c[k] = mul(cur[k], sub(cur[k], one));
+    c[15] = cur[15];
+    const fe b16 = fe_from_u64(1ULL << 16), b32 = fe_from_u64(1ULL << 32), b48 = fe_from_u64(1ULL << 48), b15 = fe_from_u64(1ULL << 15);
+    fe f0s = fe_zero();
+    for (int k = 14; k >= 0; --k) f0s = add(cur[k], add(f0s, f0s));
+    c[16] = sub(add(add(add(cur[27], mul(b16, cur[28])), mul(b32, cur[29])), mul(b48, f0s)), cur[23]);
+    const fe &ap = cur[17], &fp = cur[18], &pc = cur[19];
+    c[17] = sub(add(add(mul(cur[0], fp), mul(sub(one, cur[0]), ap)), sub(cur[27], b15)), cur[20]);
+    c[18] = sub(add(add(mul(cur[1], fp), mul(sub(one, cur[1]), ap)), sub(cur[28], b15)), cur[21]);
+    c[19] = sub(add(add(add(add(mul(cur[2], pc), mul(cur[4], ap)), mul(cur[3], fp)),
+                        mul(sub(sub(sub(one, cur[2]), cur[4]), cur[3]), cur[25])), sub(cur[29], b15)), cur[22]);
+    const fe size = add(cur[2], one);
+    c[20] = sub(add(add(add(ap, mul(cur[10], cur[16])), cur[11]), mul(cur[12], two)), nxt[17]);
+    c[21] = sub(add(add(mul(cur[13], cur[24]), mul(cur[12], add(ap, two))), mul(sub(sub(one, cur[13]), cur[12]), fp)), nxt[18]);
+    c[22] = mul(sub(cur[31], cur[9]), sub(nxt[19], add(pc, size)));
+    c[23] = sub(add(mul(cur[30], sub(nxt[19], add(pc, cur[26]))), mul(sub(one, cur[9]), nxt[19])),
+                add(add(mul(sub(sub(sub(one, cur[7]), cur[8]), cur[9]), add(pc, size)), mul(cur[7], cur[16])), mul(cur[8], add(pc, cur[16]))));
+    c[24] = sub(mul(cur[9], cur[24]), cur[30]);
+    c[25] = sub(mul(cur[30], cur[16]), cur[31]);
+    c[26] = sub(cur[32], mul(cur[25], cur[26]));
+    c[27] = sub(add(add(mul(cur[5], add(cur[25], cur[26])), mul(cur[6], cur[32])), mul(sub(sub(sub(one, cur[5]), cur[6]), cur[9]), cur[26])),
+                mul(sub(one, cur[9]), cur[16]));
+    c[28] = mul(cur[12], sub(cur[24], fp));
+    c[29] = mul(cur[12], sub(cur[25], add(pc, size)));
+    c[30] = mul(cur[14], sub(cur[24], cur[16]));
+    for (int k = 16; k <= 30; ++k) c[k] = mul(c[k], cur[33]);
+    const fe &alpha = rap[0], &z = rap[1], &zrc = rap[2];
+    const fe* as = cur + A + 3; const fe* vs = cur + A + 7; const fe* pp = cur + A + 11;
+    const fe &as0n = nxt[A + 3], &vs0n = nxt[A + 7], &p0n = nxt[A + 11];
+    for (int k = 0; k < 3; ++k) {
+        fe step = sub(sub(as[k + 1], as[k]), one);
+        c[31 + k] = mul(sub(as[k], as[k + 1]), step);
+        c[35 + k] = mul(sub(vs[k], vs[k + 1]), step);
+        c[39 + k] = sub(mul(sub(z, add(as[k + 1], mul(alpha, vs[k + 1]))), pp[k + 1]), mul(sub(z, add(cur[20 + k], mul(alpha, cur[24 + k]))), pp[k]));
+    }
+    {
+        fe step = sub(sub(as0n, as[3]), one);
+        c[34] = mul(sub(as[3], as0n), step);
+        c[38] = mul(sub(vs[3], vs0n), step);
+        c[42] = sub(mul(sub(z, add(as0n, mul(alpha, vs0n))), p0n), mul(sub(z, add(nxt[19], mul(alpha, nxt[23]))), pp[3]));
+    }
+    const fe* rc = cur + A; const fe& rc0n = nxt[A]; const fe* q = cur + A + 15; const fe& q0n = nxt[A + 15];
+    c[43] = mul(sub(rc[0], rc[1]), sub(sub(rc[1], rc[0]), one));
+    c[44] = mul(sub(rc[1], rc[2]), sub(sub(rc[2], rc[1]), one));
+    c[45] = mul(sub(rc[2], rc0n), sub(sub(rc0n, rc[2]), one));
+    c[46] = sub(mul(sub(zrc, rc[1]), q[1]), mul(sub(zrc, cur[28]), q[0]));
+    c[47] = sub(mul(sub(zrc, rc[2]), q[2]), mul(sub(zrc, cur[29]), q[1]));
+    c[48] = sub(mul(sub(zrc, rc0n), q0n), mul(sub(zrc, nxt[27]), q[2]));
+    if (has_rc) {
+        fe acc = fe_zero();
+        for (int k = 7; k >= 0; --k) acc = add(mul(acc, b16), cur[34 + k]);
+        c[49] = sub(acc, cur[42]);
+    }
+}
+
+namespace {
+typedef std::array<uint8_t, 32> Dig;
+struct Reader {
+    const uint8_t* p; size_t n, pos = 0;
+    Reader(const uint8_t* d, size_t len) : p(d), n(len) {}
+    void need(size_t k) { if (k > n - pos) throw std::runtime_error("InvalidAmountOfBytes"); }
+    uint64_t u64() { need(8); uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[pos + i]; pos += 8; return v; }
+    uint64_t count(size_t unit) { uint64_t k = u64(); if (k > (n - pos) / (unit ? unit : 1)) throw std::runtime_error("length field exceeds the proof"); return k; }
+    fe felt() {
+        need(32);
+        // reject non-canonical encodings (>= p)
+        static const uint8_t PBE[32] = {0x08, 0, 0, 0, 0, 0, 0, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
+        if (std::memcmp(p + pos, PBE, 32) >= 0) throw std::runtime_error("field element out of range");
+        fe x = fe_from_bytes_be(p + pos); pos += 32; return x;
+    }
+    Dig dig() { need(32); Dig d; std::memcpy(d.data(), p + pos, 32); pos += 32; return d; }
+    std::vector<Dig> path() { uint64_t k = count(32); std::vector<Dig> v(k); for (auto& d : v) d = dig(); return v; }
+};
+struct FriDecommitment { std::vector<std::vector<Dig>> paths_sym, paths; std::vector<fe> evals_sym, evals; };
+struct Opening { std::vector<Dig> comp_path; fe h1, h2; std::vector<std::vector<Dig>> trace_paths; std::vector<fe> trace_evals; };
+struct Proof {
+    uint64_t trace_length; std::vector<Dig> trace_roots; std::vector<fe> ood; uint64_t row_width; Dig comp_root; fe h1z, h2z;
+    std::vector<Dig> fri_roots; fe fri_last; std::vector<FriDecommitment> queries; std::vector<Opening> openings; uint64_t nonce;
+};
+Proof parse(const uint8_t* data, size_t len) {
+    Reader r(data, len);
+    Proof p;
+    p.trace_length = r.u64();
+    uint64_t nr = r.count(32);
+    for (uint64_t i = 0; i < nr; ++i) p.trace_roots.push_back(r.dig());
+    r.u64();
+    uint64_t ne = r.count(32); r.u64();
+    for (uint64_t i = 0; i < ne; ++i) p.ood.push_back(r.felt());
+    p.row_width = r.u64();
+    p.comp_root = r.dig(); r.u64();
+    p.h1z = r.felt(); p.h2z = r.felt();
+    uint64_t nf = r.count(32);
+    for (uint64_t i = 0; i < nf; ++i) p.fri_roots.push_back(r.dig());
+    p.fri_last = r.felt();
+    uint64_t nq = r.count(8);
+    for (uint64_t i = 0; i < nq; ++i) {
+        r.u64();
+        FriDecommitment q;
+        uint64_t k = r.count(8); for (uint64_t j = 0; j < k; ++j) q.paths_sym.push_back(r.path());
+        r.u64();
+        k = r.count(32); for (uint64_t j = 0; j < k; ++j) q.evals_sym.push_back(r.felt());
+        k = r.count(32); for (uint64_t j = 0; j < k; ++j) q.evals.push_back(r.felt());
+        k = r.count(8); for (uint64_t j = 0; j < k; ++j) q.paths.push_back(r.path());
+        p.queries.push_back(std::move(q));
+    }
+    uint64_t no = r.count(8);
+    for (uint64_t i = 0; i < no; ++i) {
+        r.u64();
+        Opening o;
+        o.comp_path = r.path(); r.u64();
+        o.h1 = r.felt(); o.h2 = r.felt();
+        uint64_t k = r.count(8); for (uint64_t j = 0; j < k; ++j) o.trace_paths.push_back(r.path());
+        k = r.count(32); for (uint64_t j = 0; j < k; ++j) o.trace_evals.push_back(r.felt());
+        p.openings.push_back(std::move(o));
+    }
+    p.nonce = r.u64();
+    if (r.pos != len) throw std::runtime_error("trailing bytes");
+    return p;
+}
+struct Tr {
+    std::vector<uint8_t> buf;
+    void append(const uint8_t* d, size_t n) { buf.insert(buf.end(), d, d + n); }
+    void felt(const fe& x) { uint8_t b[32]; fe_to_bytes_be(x, b); append(b, 32); }
+    void challenge(uint8_t out[32]) { uint8_t d[32]; sp_keccak256_host(buf.data(), buf.size(), d); for (int i = 0; i < 32; ++i) out[i] = d[31 - i]; buf.assign(out, out + 32); }
+    fe field() { uint8_t r[32]; challenge(r); r[0] &= 0x07; return fe_from_bytes_be(r); }
+    uint64_t usize() { uint8_t r[32]; challenge(r); uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | r[i]; return v; }
+};
+Dig hash_felts(const fe* v, size_t k) {
+    std::vector<uint8_t> b(32 * k);
+    for (size_t i = 0; i < k; ++i) fe_to_bytes_be(v[i], &b[32 * i]);
+    Dig d; sp_keccak256_host(b.data(), b.size(), d.data()); return d;
+}
+bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, const fe* v, size_t k) {
+    Dig h = hash_felts(v, k);
+    for (const Dig& s : path) {
+        uint8_t b[64];
+        if (index & 1) { std::memcpy(b, s.data(), 32); std::memcpy(b + 32, h.data(), 32); } else { std::memcpy(b, h.data(), 32); std::memcpy(b + 32, s.data(), 32); }
+        sp_keccak256_host(b, 64, h.data());
+        index >>= 1;
+    }
+    return h == root;
+}
+}  // namespace
+
+// returns 1 accept, 0 reject; throws on malformed input
+int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
+    Proof pr = parse(proof_bytes, len);
+    if (pr.queries.size() < queries) return 0;
+    const uint64_t n = pr.trace_length;
+    int k = sp_log2_exact(n), lb = sp_log2_exact(blowup);
+    if (k < 1 || lb < 1 || k + lb > 40) return 0;
+    CairoAirInfo air = cairo_air_info(pub);
+    const uint32_t C = air.trace_columns, T = air.num_transition_constraints;
+    const uint64_t N = n << lb;
+    if (pr.ood.size() != 2 * (size_t)C || pr.trace_roots.size() != 2 || pr.fri_roots.size() != (size_t)k) return 0;
+    const fe h = fe_from_u64(coset_offset), hinv = fe_inv(h);
+    auto root_of = [&](int order) { fe w = fe_from_bytes_be((const uint8_t*)"\x00\x52\x82\xdb\x87\x52\x9c\xfa\x3f\x04\x64\x51\x9c\x8b\x0f\xa5\xad\x18\x71\x48\xe1\x1a\x61\x61\x60\x70\x02\x4f\x42\xf8\xef\x94"); for (int i = order; i < 192; ++i) w = fe_sqr(w); return w; };
+    const fe g = root_of(k), w = root_of(k + lb);
+    // ---- step 1: replay the transcript (verifier.rs:59-206)
+    Tr t;
+    t.append(pr.trace_roots[0].data(), 32);
+    fe rap[3] = {t.field(), t.field(), t.field()};
+    t.append(pr.trace_roots[1].data(), 32);
+    std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
+    std::vector<fe> ba(bcs.size()), bb(bcs.size()), ta(T), tb(T);
+    for (auto& x : ba) x = t.field();
+    for (auto& x : bb) x = t.field();
+    for (auto& x : ta) x = t.field();
+    for (auto& x : tb) x = t.field();
+    t.append(pr.comp_root.data(), 32);
+    fe z;
+    for (;;) {
+        z = t.field();
+        fe a = fe_mul(z, hinv), b = z;
+        for (int i = 0; i < k + lb; ++i) a = fe_sqr(a);
+        for (int i = 0; i < k; ++i) b = fe_sqr(b);
+        if (!fe_eq(a, fe_one()) && !fe_eq(b, fe_one())) break;
+    }
+    t.felt(pr.h1z); t.felt(pr.h2z);
+    for (auto& e : pr.ood) t.felt(e);
+    fe gamma = t.field(), gamma_p = t.field();
+    std::vector<fe> tg(2 * (size_t)C);
+    for (auto& x : tg) x = t.field();
+    std::vector<fe> zetas;
+    for (auto& r : pr.fri_roots) { t.append(r.data(), 32); zetas.push_back(t.field()); }
+    t.felt(pr.fri_last);
+    uint8_t gch[32];
+    t.challenge(gch);
+    {
+        uint8_t data[40], dg[32];
+        std::memcpy(data, gch, 32);
+        for (int i = 0; i < 8; ++i) data[32 + i] = (uint8_t)(pr.nonce >> (8 * i));
+        sp_keccak256_host(data, 40, dg);
+        uint64_t head = 0;
+        for (int i = 0; i < 8; ++i) head = (head << 8) | dg[i];
+        int tz = head == 0 ? 64 : __builtin_ctzll(head);
+        uint8_t nb[8];
+        for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(pr.nonce >> (56 - 8 * i));
+        t.append(nb, 8);
+        if (tz < (int)grinding) return 0;
+    }
+    std::vector<uint64_t> iotas(queries);
+    for (auto& x : iotas) x = t.usize() % N;
+    // ---- step 2: composition polynomial at z (verifier.rs:208-317)
+    {
+        fe zn = fe_pow_u64(z, n);
+        fe bq = fe_zero();
+        for (size_t j = 0; j < bcs.size(); ++j) {
+            fe den = fe_sub(z, fe_pow_u64(g, bcs[j].step));
+            if (fe_is_zero(den)) return 0;
+            fe num = fe_sub(pr.ood[bcs[j].col], bcs[j].value);
+            bq = fe_add(bq, fe_mul(fe_mul(num, fe_inv(den)), fe_add(fe_mul(ba[j], zn), bb[j])));
+        }
+        std::vector<fe> cons(T);
+        cairo_transition_host(pr.ood.data(), C, air.has_rc_builtin, rap, cons.data());
+        fe zden = fe_sub(zn, fe_one());
+        if (fe_is_zero(zden)) return 0;
+        fe zf = fe_inv(zden);
+        fe ex = fe_sub(z, fe_pow_u64(g, n - 1));
+        fe pw[4] = {fe_one(), zn, fe_sqr(zn), fe_mul(fe_sqr(zn), zn)};
+        fe sum = fe_zero();
+        for (uint32_t c = 0; c < T; ++c) {
+            fe term = fe_mul(fe_mul(zf, cons[c]), fe_add(fe_mul(ta[c], pw[3 - air.transition_degrees[c]]), tb[c]));
+            if (air.transition_exemptions[c]) term = fe_mul(term, ex);
+            sum = fe_add(sum, term);
+        }
+        if (!fe_eq(fe_add(pr.h1z, fe_mul(z, pr.h2z)), fe_add(bq, sum))) return 0;
+    }
+    // ---- step 3: FRI (verifier.rs:319-356, :443-523)
+    const fe half = fe_inv(fe_from_u64(2));
+    const size_t L = pr.fri_roots.size();
+    bool ok = true;
+    for (size_t s = 0; s < queries; ++s) {
+        const FriDecommitment& q = pr.queries[s];
+        if (q.paths.size() != L || q.paths_sym.size() != L || q.evals.size() != L || q.evals_sym.size() != L) return 0;
+        fe xinv = fe_inv(fe_mul(h, fe_pow_u64(w, iotas[s])));
+        fe v = q.evals[0];
+        for (size_t l = 0; l < L; ++l) {
+            uint64_t dl = N >> l, isym = (iotas[s] + dl / 2) % dl;
+            ok &= merkle_ok(q.paths_sym[l], pr.fri_roots[l], isym, &q.evals_sym[l], 1);
+            ok &= merkle_ok(q.paths[l], pr.fri_roots[l], iotas[s], &q.evals[l], 1);
+            const fe& es = q.evals_sym[l];
+            v = fe_add(fe_mul(fe_add(v, es), half), fe_mul(fe_mul(fe_mul(zetas[l], fe_sub(v, es)), half), xinv));
+            xinv = fe_sqr(xinv);
+            ok &= fe_eq(v, l + 1 < L ? q.evals[l + 1] : pr.fri_last);
+        }
+    }
+    if (!ok) return 0;
+    // ---- step 4: DEEP consistency and openings (verifier.rs:358-441, :525-557)
+    if (pr.openings.size() < queries) return 0;
+    const fe z2 = fe_sqr(z);
+    for (size_t s = 0; s < queries; ++s) {
+        const Opening& o = pr.openings[s];
+        if (o.trace_evals.size() != C || o.trace_paths.size() != 2) return 0;
+        fe hh[2] = {o.h1, o.h2};
+        ok &= merkle_ok(o.comp_path, pr.comp_root, iotas[s], hh, 2);
+        ok &= merkle_ok(o.trace_paths[0], pr.trace_roots[0], iotas[s], o.trace_evals.data(), air.main_columns);
+        ok &= merkle_ok(o.trace_paths[1], pr.trace_roots[1], iotas[s], o.trace_evals.data() + air.main_columns, air.aux_columns);
+        fe x = fe_mul(h, fe_pow_u64(w, iotas[s]));
+        fe d2 = fe_sub(x, z2), d0 = fe_sub(x, z), d1 = fe_sub(x, fe_mul(z, g));
+        if (fe_is_zero(d0) || fe_is_zero(d1) || fe_is_zero(d2)) return 0;
+        fe i0 = fe_inv(d0), i1 = fe_inv(d1), i2 = fe_inv(d2);
+        fe acc = fe_zero();
+        for (uint32_t j = 0; j < C; ++j) {
+            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[j]), i0), tg[2 * j]));
+            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[C + j]), i1), tg[2 * j + 1]));
+        }
+        acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h1, pr.h1z), i2), gamma));
+        acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h2, pr.h2z), i2), gamma_p));
+        ok &= fe_eq(acc, pr.queries[s].evals[0]);
+    }
+    return ok ? 1 : 0;
+}
+
+}  // namespace sp
