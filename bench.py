@@ -127,6 +127,13 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    traffic = None  # HBM bytes per NTT from the committed PMC profile (same command, same size)
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt22_traffic.json")))
+        if tj.get("log_n") == args.log_n:
+            traffic = tj["traffic_bytes_per_ntt"]
+    except Exception:
+        pass
     butterflies = (n // 2) * args.log_n
     value = butterflies * args.steps * world / dt
     avg_ms = sum(kernel_ms) / len(kernel_ms)
@@ -139,7 +146,7 @@ def main():
         "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
                    "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
                      "mulmod_per_s": butterflies / (avg_ms * 1e-3)},
     }
     want_proof = args.proof == 1 or (args.proof == -1 and world == 1)
