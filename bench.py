@@ -18,7 +18,7 @@ LOG_N = 22
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
-def cpu_baseline(log_n=20, reps=3):
+def cpu_baseline(log_n=22, reps=3):
     """CPU oracle (faithful restatement of the reference's radix-2 FFT) timed on this host, 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import numpy as np
