@@ -21,6 +21,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def cpu_baseline(log_n=22, reps=3):
     """CPU oracle (faithful restatement of the reference's radix-2 FFT) timed on this host, 1 thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "1"  # the oracle's codec loops are OpenMP-parallel; the reported baseline is 1 core
     import numpy as np
     import oracle_lib as oracle
     n = 1 << log_n
