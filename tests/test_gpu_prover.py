@@ -50,3 +50,38 @@ def test_device_proof_equals_reference_golden_70000(hip_ctx):
     got = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions.default_test_options())
     assert hashlib.sha256(got).hexdigest() == "da962bd4513d991c39a0e0cc11cc76d25b9ec405cebcdaaf1449184d4b54cd6b"
     assert got == golden
+
+
+def test_context_reuse_across_shapes(hip_ctx, oracle):
+    """One context proves traces of changing length / blowup / queries back to back (device buffers are re-shaped or
+    reused): every proof still equals the oracle's."""
+    seq = [(20, (4, 3, 3, 1)), (20, (4, 3, 3, 1)), (200, (4, 3, 3, 1)), (20, (8, 6, 3, 0)), (20, (8, 2, 5, 3)), (120, (2, 3, 3, 1)),
+           (120, (2, 3, 3, 1)), (20, (4, 3, 3, 1))]
+    cache = {}
+    for fib_index, options in seq:
+        if fib_index not in cache:
+            run = api.CairoRun.fibonacci(fib_index)
+            cache[fib_index] = (run, run.main_trace())
+        run, trace = cache[fib_index]
+        want = oracle.cairo_prove(trace, run.public_inputs_c, options)
+        assert hip_ctx.cairo_prove(trace, run.public_inputs_c, api.ProofOptions(*options)) == want, (fib_index, options)
+
+
+def test_two_contexts_in_threads(hip_lib, oracle):
+    """Different contexts may be used from different threads (include/stark252_hip.h conventions)."""
+    import threading
+    runs = [api.CairoRun.fibonacci(k) for k in (30, 90)]
+    want = [oracle.cairo_prove(r.main_trace(), r.public_inputs_c, (4, 3, 3, 1)) for r in runs]
+    got = [None, None]
+
+    def work(i):
+        with api.Context(device=0) as ctx:
+            for _ in range(3):
+                got[i] = ctx.cairo_prove(runs[i].main_trace(), runs[i].public_inputs_c, api.ProofOptions(4, 3, 3, 1))
+
+    ts = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert got == want
