@@ -205,6 +205,8 @@ typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public i
 /* run_program + PublicInputs::from_regs_and_mem + build_main_trace for a hint-free, builtin-free program given as
  * `n_words` canonical-BE field elements (reference src/cairo/runner/run.rs:242-263). */
 int sp_cairo_run_program(const uint8_t* program_words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out);
+/* Same with main's entry point at address `entry_pc` (1-based; the compiled program's "main" identifier pc + 1). */
+int sp_cairo_run_program_at(const uint8_t* program_words, uint64_t n_words, uint64_t entry_pc, uint64_t max_steps, sp_cairo_run** out);
 /* The 22-word fibonacci program of benches/proofs/fibonacci_70000.proof with index `fib_index`. */
 int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out);
 /* From cairo-run's binary dumps: .trace (24 B/row LE, register_states.rs:51-78) and .memory (8+32 B/row LE,

@@ -191,11 +191,12 @@ class CairoRun:
         return CairoRun(h)
 
     @staticmethod
-    def from_program(words, max_steps=1 << 26):
+    def from_program(words, max_steps=1 << 26, entry_pc=1):
         lib = _lib.load()
         h = ctypes.c_void_p()
         a = felts_to_bytes(words)
-        check(lib.sp_cairo_run_program(_u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.c_uint64(max_steps), ctypes.byref(h)))
+        check(lib.sp_cairo_run_program_at(_u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.c_uint64(entry_pc),
+                                          ctypes.c_uint64(max_steps), ctypes.byref(h)))
         return CairoRun(h)
 
     @staticmethod

@@ -215,7 +215,7 @@ std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const C
     return t;
 }
 
-void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps) {
+void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps, uint64_t entry_pc) {
     const uint64_t L = program.size();
     // Two passes: the two initial stack cells hold the address one past the execution segment (= final ap),
     // which is only known after the run; their VALUE is only consumed by main's final `ret`.
@@ -226,7 +226,7 @@ void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState
         for (uint64_t i = 0; i < L; ++i) mem.data[i + 1] = program[i];
         mem.data[L + 1] = fe_from_u64(end_marker);  // return fp
         mem.data[L + 2] = fe_from_u64(end_marker);  // return pc
-        uint64_t pc = 1, ap = L + 3, fp = L + 3;
+        uint64_t pc = entry_pc, ap = L + 3, fp = L + 3;
         const uint64_t fp0 = fp;
         bool done = false;
         while (!done) {

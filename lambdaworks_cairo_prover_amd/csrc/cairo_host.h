@@ -51,7 +51,7 @@ std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const C
 
 // Runs `program` (field elements, address 1..L) from pc = 1 in cairo-run's non-proof-mode layout until main returns.
 // Fills the relocated register trace and memory. Supports every hint-free, builtin-free instruction.
-void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps);
+void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps, uint64_t entry_pc = 1);
 
 // The 22-word fibonacci program of tests/golden/fibonacci_70000.proof with the index replaced by `fib_index`
 // (fib(1, 1, fib_index), no final assert): 7*fib_index + 9 steps.

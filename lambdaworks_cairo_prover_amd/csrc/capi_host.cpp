@@ -56,15 +56,19 @@ static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out) 
     return SP_OK;
 }
 
-int sp_cairo_run_program(const uint8_t* words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out) {
-    if (!words || !out || n_words == 0) return SP_E_INVALID_ARG;
+int sp_cairo_run_program_at(const uint8_t* words, uint64_t n_words, uint64_t entry_pc, uint64_t max_steps, sp_cairo_run** out) {
+    if (!words || !out || n_words == 0 || entry_pc == 0 || entry_pc > n_words) return SP_E_INVALID_ARG;
     sp_cairo_run* r = new sp_cairo_run();
     try {
         std::vector<fe> prog(n_words);
         for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
-        sp::run_program_plain(prog, r->regs, r->mem, max_steps);
+        sp::run_program_plain(prog, r->regs, r->mem, max_steps, entry_pc);
         return finish_run(r, n_words, out);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+int sp_cairo_run_program(const uint8_t* words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out) {
+    return sp_cairo_run_program_at(words, n_words, 1, max_steps, out);
 }
 
 int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out) {
