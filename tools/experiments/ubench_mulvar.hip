@@ -1,5 +1,5 @@
 // Variants of the Montgomery product to find where its ~910 cycles go (registers only, 8 waves per SIMD).
-#include "../lambdaworks_cairo_prover_amd/csrc/fp.h"
+#include "../../lambdaworks_cairo_prover_amd/csrc/fp.h"
 #include <cstdio>
 #define ITERS 256
 // (b) lazy: no final conditional subtraction (result in [0, 2p))
