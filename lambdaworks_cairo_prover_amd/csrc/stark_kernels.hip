@@ -81,7 +81,22 @@ enum {
     K_RC0 = 34, K_RCV = 42
 };
 
-__global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __restrict__ lde, uint64_t N, uint32_t logN, uint32_t logb,
+// Register pressure: left alone, the compiler hoists every column load of this kernel (> 60 field elements) to the
+// top, needs all 256 VGPRs plus scratch and runs at one wave per SIMD (round-1 profile: 16.5 ms at n = 2^20, b = 8,
+// i.e. < half of the arithmetic rate).  The constraint groups are therefore evaluated as PHASES: the loads of a
+// phase are addressed through an offset that is an opaque function (always zero) of the previous phase's
+// accumulators, so they cannot be scheduled before that phase has finished; values shared between phases are
+// simply re-loaded (L1/L2 hits).
+__device__ __forceinline__ uint32_t phase_gate(const fe& a, const fe& b) {
+    uint32_t z;
+    asm volatile("v_and_b32 %0, 0, %1" : "=v"(z) : "v"(a.v[0] ^ b.v[0]));
+    return z;  // == 0, but only the hardware knows
+}
+
+#ifndef SP_COMP_WAVES
+#define SP_COMP_WAVES 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SP_COMP_WAVES, SP_COMP_WAVES))) cairo_composition_kernel(const fe* __restrict__ lde, uint64_t N, uint32_t logN, uint32_t logb,
                                                                 const fe* __restrict__ roots, const CompositionConsts* __restrict__ K,
                                                                 const fe* __restrict__ binv, fe* __restrict__ out, uint32_t shard_log, uint32_t shard_rank) {
     extern __shared__ __attribute__((aligned(16))) uint4 sh_raw[];
@@ -103,82 +118,96 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
     const uint64_t inext = (i + b_loc) & (N - 1);  // frame row offset 1 = LDE index + blowup (reference frame.rs:40-59): same coset
     const fe* coef = sh_coef + c * W;
     const uint32_t A = K->main_cols;
-    auto cur = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + i); };
-    auto nxt = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + inext); };
+    uint32_t gate = 0;  // see phase_gate
+    auto cur = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + i + gate); };
+    auto nxt = [&](uint32_t col) { return sk_ld(lde + (uint64_t)col * N + inext + gate); };
 
     const fe one = fe_one();
     fe S0 = fe_zero(), S1 = fe_zero(), S2 = fe_zero(), S3 = fe_zero();
     // S0: no selector, no exemption; S1: exempted; S2: selector; S3: selector and exempted.
 
-    // --- flags (air.rs:869-881) and the instruction word (air.rs:883-896)
-    fe f0s = fe_zero();
-    for (int k = 14; k >= 0; --k) {
-        fe f = cur(k);
-        S0 = S0 + coef[k] * (f * f - f);
-        f0s = f + (f0s + f0s);
-    }
-    S0 = S0 + coef[15] * cur(15);
+    // --- phase 0: flags (air.rs:869-881) and the instruction word (air.rs:883-896)
     {
+        fe f0s = fe_zero();
+#pragma unroll 1
+        for (int k = 14; k >= 0; --k) {
+            fe f = cur(k);
+            S0 = S0 + coef[k] * (f * f - f);
+            f0s = f + (f0s + f0s);
+        }
+        S0 = S0 + coef[15] * cur(15);
         fe c16 = cur(K_OFF_DST) + K->b16 * cur(K_OFF_OP0) + K->b32 * cur(K_OFF_OP1) + K->b48 * f0s - cur(K_INST);
         S2 = S2 + coef[16] * c16;
     }
-    const fe ap = cur(K_AP), fp = cur(K_FP), pc = cur(K_PC);
-    // --- operand constraints (air.rs:899-924)
+    gate = phase_gate(S0, S2);
+    // --- phase 1: operand constraints (air.rs:899-924)
     {
-        fe f_dst_fp = cur(0), f_op0_fp = cur(1);
+        const fe ap = cur(K_AP), fp = cur(K_FP);
         fe d = fp - ap;
-        S2 = S2 + coef[17] * (ap + f_dst_fp * d + (cur(K_OFF_DST) - K->b15) - cur(K_DST_ADDR));
-        S2 = S2 + coef[18] * (ap + f_op0_fp * d + (cur(K_OFF_OP0) - K->b15) - cur(K_OP0_ADDR));
+        S2 = S2 + coef[17] * (ap + cur(0) * d + (cur(K_OFF_DST) - K->b15) - cur(K_DST_ADDR));
+        S2 = S2 + coef[18] * (ap + cur(1) * d + (cur(K_OFF_OP0) - K->b15) - cur(K_OP0_ADDR));
         fe f2 = cur(2), f3 = cur(3), f4 = cur(4);
-        fe op0 = cur(K_OP0);
-        fe c19 = f2 * pc + f4 * ap + f3 * fp + (one - f2 - f4 - f3) * op0 + (cur(K_OFF_OP1) - K->b15) - cur(K_OP1_ADDR);
+        fe c19 = f2 * cur(K_PC) + f4 * ap + f3 * fp + (one - f2 - f4 - f3) * cur(K_OP0) + (cur(K_OFF_OP1) - K->b15) - cur(K_OP1_ADDR);
         S2 = S2 + coef[19] * c19;
     }
-    // --- register constraints (air.rs:926-959)
+    gate = phase_gate(S2, S2);
+    // --- phase 2: register constraints ap, fp (air.rs:926-938)
     {
-        fe res = cur(K_RES), dst = cur(K_DST);
-        fe f9 = cur(9), f12 = cur(12), f13 = cur(13);
-        fe size = cur(2) + one;  // frame_inst_size (air.rs:1137-1139)
-        fe npc = nxt(K_PC);
-        fe c20 = ap + cur(10) * res + cur(11) + (f12 + f12) - nxt(K_AP);
+        const fe ap = cur(K_AP), fp = cur(K_FP);
+        fe f12 = cur(12), f13 = cur(13);
+        fe c20 = ap + cur(10) * cur(K_RES) + cur(11) + (f12 + f12) - nxt(K_AP);
         S3 = S3 + coef[20] * c20;
-        fe c21 = f13 * dst + f12 * (ap + K->two) + (one - f13 - f12) * fp - nxt(K_FP);
+        fe c21 = f13 * cur(K_DST) + f12 * (ap + K->two) + (one - f13 - f12) * fp - nxt(K_FP);
         S3 = S3 + coef[21] * c21;
+    }
+    gate = phase_gate(S3, S3);
+    // --- phase 3: register constraints pc, t0, t1 (air.rs:940-959)
+    {
+        const fe pc = cur(K_PC), res = cur(K_RES), f9 = cur(9);
+        const fe pc_size = pc + (cur(2) + one);  // frame_inst_size (air.rs:1137-1139)
+        fe npc = nxt(K_PC);
         fe t0 = cur(K_T0), t1 = cur(K_T1);
-        fe pc_size = pc + size;
         S3 = S3 + coef[22] * ((t1 - f9) * (npc - pc_size));
         fe f7 = cur(7), f8 = cur(8);
         fe c23 = t0 * (npc - (pc + cur(K_OP1))) + (one - f9) * npc -
                  ((one - f7 - f8 - f9) * pc_size + f7 * res + f8 * (pc + res));
         S3 = S3 + coef[23] * c23;
-        S2 = S2 + coef[24] * (f9 * dst - t0);
+        S2 = S2 + coef[24] * (f9 * cur(K_DST) - t0);
         S2 = S2 + coef[25] * (t0 * res - t1);
-        // --- opcode constraints (air.rs:961-978)
+    }
+    gate = phase_gate(S2, S3);
+    // --- phase 4: opcode constraints (air.rs:961-978)
+    {
+        const fe res = cur(K_RES), f9 = cur(9);
         fe op0 = cur(K_OP0), op1 = cur(K_OP1), mul = cur(K_MUL);
         fe f5 = cur(5), f6 = cur(6);
         S2 = S2 + coef[26] * (mul - op0 * op1);
         fe c27 = f5 * (op0 + op1) + f6 * mul + (one - f5 - f6 - f9) * op1 - (one - f9) * res;
         S2 = S2 + coef[27] * c27;
-        S2 = S2 + coef[28] * (f12 * (dst - fp));
-        S2 = S2 + coef[29] * (f12 * (op0 - pc_size));
+        fe f12 = cur(12), dst = cur(K_DST);
+        S2 = S2 + coef[28] * (f12 * (dst - cur(K_FP)));
+        S2 = S2 + coef[29] * (f12 * (op0 - (cur(K_PC) + (cur(2) + one))));
         S2 = S2 + coef[30] * (cur(14) * (dst - res));
     }
-    // --- memory (air.rs:987-1043) and permutation argument (air.rs:1045-1090)
+    gate = phase_gate(S2, S2);
+    // --- phase 5: memory (air.rs:987-1043) and permutation argument (air.rs:1045-1090)
     {
         const fe alpha = K->rap[0], z = K->rap[1];
         fe a_prev = cur(A + 3), v_prev = cur(A + 7), p_prev = cur(A + 11);
 #pragma unroll 1
         for (uint32_t k = 1; k <= 4; ++k) {
             // k = 1..3: next sorted cell of this row; k = 4: first sorted cell of the next row
-            fe a_k = (k < 4) ? cur(A + 3 + k) : nxt(A + 3);
-            fe v_k = (k < 4) ? cur(A + 7 + k) : nxt(A + 7);
-            fe p_k = (k < 4) ? cur(A + 11 + k) : nxt(A + 11);
+            const uint64_t row = ((k < 4) ? i : inext) + gate;
+            const uint32_t kk = (k < 4) ? k : 0;
+            fe a_k = sk_ld(lde + (uint64_t)(A + 3 + kk) * N + row);
+            fe v_k = sk_ld(lde + (uint64_t)(A + 7 + kk) * N + row);
+            fe p_k = sk_ld(lde + (uint64_t)(A + 11 + kk) * N + row);
             fe step = a_k - a_prev - one;
             fe inc = (a_prev - a_k) * step;           // MEMORY_INCREASING_{k-1}
             fe cons = (v_prev - v_k) * step;          // MEMORY_CONSISTENCY_{k-1}
             // original (unsorted) access k: (dst_addr,dst), (op0_addr,op0), (op1_addr,op1), then next row's (pc,inst)
-            fe a_o = (k < 4) ? cur(K_PC + k) : nxt(K_PC);
-            fe v_o = (k < 4) ? cur(K_INST + k) : nxt(K_INST);
+            fe a_o = sk_ld(lde + (uint64_t)(K_PC + kk) * N + row);
+            fe v_o = sk_ld(lde + (uint64_t)(K_INST + kk) * N + row);
             fe perm = (z - (a_k + alpha * v_k)) * p_k - (z - (a_o + alpha * v_o)) * p_prev;  // PERMUTATION_ARGUMENT_{k-1}
             if (k < 4) {
                 S0 = S0 + coef[31 + k - 1] * inc + coef[35 + k - 1] * cons + coef[39 + k - 1] * perm;
@@ -188,7 +217,8 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
             a_prev = a_k; v_prev = v_k; p_prev = p_k;
         }
     }
-    // --- range check (air.rs:1092-1135)
+    gate = phase_gate(S0, S1);
+    // --- phase 6: range check (air.rs:1092-1135)
     {
         const fe zrc = K->rap[2];
         fe rc0 = cur(A + 0), rc1 = cur(A + 1), rc2 = cur(A + 2), rc0n = nxt(A + 0);
@@ -200,17 +230,21 @@ __global__ void __launch_bounds__(256) cairo_composition_kernel(const fe* __rest
         S0 = S0 + coef[47] * ((zrc - rc2) * q2 - (zrc - cur(K_OFF_OP1)) * q1);
         S0 = S0 + coef[48] * ((zrc - rc0n) * q0n - (zrc - nxt(K_OFF_DST)) * q2);
     }
+    gate = phase_gate(S0, S1);
     // --- range-check builtin (air.rs:1141-1160)
     if (K->has_rc_builtin) {
         fe acc = fe_zero();
+#pragma unroll 1
         for (int k = 7; k >= 0; --k) acc = acc * K->b16 + cur(K_RC0 + k);
         S0 = S0 + coef[49] * (acc - cur(K_RCV));
+        gate = phase_gate(S0, S0);
     }
     // --- combine (evaluator.rs:205-253): zerofier * (sum + exemption * sum_exempted)
     const fe x = root_pow(roots, iglob, logN) * K->h;
     const fe sel = cur(K_SEL);
     fe total = K->zerofier[c] * ((S0 + sel * S2) + (x - K->g_last) * (S1 + sel * S3));
     // --- boundary term (evaluator.rs:58-115)
+#pragma unroll 1
     for (uint32_t j = 0; j < B; ++j) {
         fe num = cur(K->bcol[j]) - K->bvalue[j];
         total = total + coef[T + j] * num * sk_ld(binv + (uint64_t)K->bden[j] * N + i);
