@@ -106,7 +106,9 @@ SP_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
 // Row i:  u = t + a_i * b  (eight v_mad_u64_u32, D_j = a_i b_j + t_j),  m = -u_0 (p = 1 mod 2^32, so -p^-1 = -1),
 //         u += m * p  with  m * p = m + 17 m 2^192 + m 2^251  (one mad and two shifts),  t = u >> 32.
 // t stays < 2p < 2^253, so eight limbs suffice between rows; one conditional subtraction at the end.
-SP_HD fe fe_mul(const fe& a, const fe& b) {
+// fe_mul_lazy omits that subtraction: for ANY a < 2^256 and b < p the result is a*b/R mod p in [0, 2p)
+// (t < a*b/R + p < p + p).
+SP_HD fe fe_mul_lazy(const fe& a, const fe& b) {
     uint32_t t[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) t[j] = 0;
@@ -132,8 +134,55 @@ SP_HD fe fe_mul(const fe& a, const fe& b) {
     fe r;
 #pragma unroll
     for (int j = 0; j < 8; ++j) r.v[j] = t[j];
-    return fe_reduce_once(r);
+    return r;
 }
+SP_HD fe fe_mul(const fe& a, const fe& b) { return fe_reduce_once(fe_mul_lazy(a, b)); }
+
+// ---- lazily reduced arithmetic for the NTT butterflies (Harvey): values live in [0, 4p) (4p < 2^254), products come
+// back in [0, 2p) from fe_mul_lazy, and one conditional subtraction of 2p per butterfly replaces the three
+// conditional corrections of fe_mul + fe_add + fe_sub.
+#define SP_2P0 0x00000002u
+#define SP_2P6 0x00000022u
+#define SP_2P7 0x10000000u
+// a >= 2p ? a - 2p : a        (a < 4p  ->  result < 2p)
+SP_HD fe fe_reduce_2p(const fe& a) {
+    fe d;
+    unsigned br = 0, bo;
+    d.v[0] = SP_SUBC(a.v[0], SP_2P0, br, bo); br = bo;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { d.v[i] = SP_SUBC(a.v[i], 0u, br, bo); br = bo; }
+    d.v[6] = SP_SUBC(a.v[6], SP_2P6, br, bo); br = bo;
+    d.v[7] = SP_SUBC(a.v[7], SP_2P7, br, bo); br = bo;
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+// a + b as 256-bit integers (caller guarantees a + b < 2^256)
+SP_HD fe fe_add_raw(const fe& a, const fe& b) {
+    fe s;
+    unsigned c = 0, co;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { s.v[i] = SP_ADDC(a.v[i], b.v[i], c, co); c = co; }
+    return s;
+}
+// a - b + 2p  (a, b < 2p  ->  result in (0, 4p); exact modulo 2^256 whatever the intermediate borrow)
+SP_HD fe fe_sub_add_2p(const fe& a, const fe& b) {
+    fe d;
+    unsigned br = 0, bo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d.v[i] = SP_SUBC(a.v[i], b.v[i], br, bo); br = bo; }
+    fe r;
+    unsigned c = 0, co;
+    r.v[0] = SP_ADDC(d.v[0], SP_2P0, c, co); c = co;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { r.v[i] = SP_ADDC(d.v[i], 0u, c, co); c = co; }
+    r.v[6] = SP_ADDC(d.v[6], SP_2P6, c, co); c = co;
+    r.v[7] = SP_ADDC(d.v[7], SP_2P7, c, co);
+    return r;
+}
+// [0, 4p) -> canonical [0, p)
+SP_HD fe fe_canonical_4p(const fe& a) { return fe_reduce_once(fe_reduce_2p(a)); }
 
 SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 

@@ -40,6 +40,9 @@ struct NttPassArgs {
     // Coset sharding across GPUs (LDE only): this rank holds the cosets c = c_loc * 2^shard_log + shard_rank of the
     // 2^(log_expand + shard_log) cosets; arrays are local (2^(logM - shard_log) elements), twiddles use global indices.
     uint32_t shard_log, shard_rank;
+    // 1 on every pass but the last one of a transform: the stored data stays lazily reduced ([0, 4p) after a DIT pass,
+    // [0, 2p) after a DIF pass); 0: the pass stores canonical values.
+    uint32_t weak_out;
 };
 
 enum NttLoadMode { NTT_LOAD_INPLACE = 0, NTT_LOAD_GATHER_BITREV = 1, NTT_LOAD_EXPAND = 2 };

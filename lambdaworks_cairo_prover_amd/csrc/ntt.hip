@@ -41,6 +41,9 @@ __device__ __forceinline__ fe big_root(const fe* tw, uint32_t e, uint32_t logM) 
 }
 
 // One four-step pass. Template flags are compile-time so each instantiation keeps only its own address math.
+// Lazy reduction (Harvey butterflies, fp.h): inside a transform the data lives in [0, 4p) for DIT passes and in
+// [0, 2p) for DIF passes, also in HBM between the passes of one transform (a.weak_out = 1); only the last pass of a
+// transform stores canonical values.  Twiddles are always canonical, so every product is fe_mul_lazy(data, twiddle).
 template <bool DIF, int LOADM, int STOREM, bool CONTIG>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -103,7 +106,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
             else x = ld_fe(src + pos);
             if (!DIF) {
                 uint32_t ex = twiddle_exp(pos);
-                if (ex != 0) x = fe_mul(x, big_root(a.big_tw, ex, logM));
+                if (ex != 0) x = fe_mul_lazy(x, big_root(a.big_tw, ex, logM));
             }
         }
         lds_st(Llo, Lhi, lidx(t, gl), x);
@@ -121,11 +124,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 uint32_t i = bf & (half - 1);
                 uint32_t t0 = ((bf >> (j - 1)) << j) | i;
                 uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
-                fe u = lds_ld(Llo, Lhi, i0), v = lds_ld(Llo, Lhi, i1);
+                // u, v in [0, 4p)  ->  t = v w in [0, 2p), u' = u mod 2p;  outputs u' + t and u' - t + 2p in [0, 4p)
+                fe u = fe_reduce_2p(lds_ld(Llo, Lhi, i0)), v = lds_ld(Llo, Lhi, i1);
                 uint32_t twi = i << (r - j);
-                if (twi != 0) v = fe_mul(v, lds_ld(Twl, Twh, twi));
-                lds_st(Llo, Lhi, i0, fe_add(u, v));
-                lds_st(Llo, Lhi, i1, fe_sub(u, v));
+                if (twi != 0) v = fe_mul_lazy(v, lds_ld(Twl, Twh, twi));
+                else v = fe_reduce_2p(v);
+                lds_st(Llo, Lhi, i0, fe_add_raw(u, v));
+                lds_st(Llo, Lhi, i1, fe_sub_add_2p(u, v));
             }
             __syncthreads();
         }
@@ -138,11 +143,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 uint32_t i = bf & (half - 1);
                 uint32_t t0 = ((bf >> (j - 1)) << j) | i;
                 uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
+                // x, y in [0, 2p)  ->  x + y mod 2p and (x - y + 2p) w, both in [0, 2p)
                 fe x = lds_ld(Llo, Lhi, i0), y = lds_ld(Llo, Lhi, i1);
-                fe d = fe_sub(x, y);
+                fe d = fe_sub_add_2p(x, y);
                 uint32_t twi = i << (r - j);
-                if (twi != 0) d = fe_mul(d, lds_ld(Twl, Twh, twi));
-                lds_st(Llo, Lhi, i0, fe_add(x, y));
+                if (twi != 0) d = fe_mul_lazy(d, lds_ld(Twl, Twh, twi));
+                else d = fe_reduce_2p(d);
+                lds_st(Llo, Lhi, i0, fe_reduce_2p(fe_add_raw(x, y)));
                 lds_st(Llo, Lhi, i1, d);
             }
             __syncthreads();
@@ -163,10 +170,11 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         if (CONTIG && STOREM == NTT_STORE_SCATTER_BITREV) didx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
         if (DIF && !CONTIG) {
             uint32_t ex = twiddle_exp(pos);
-            if (ex != 0) x = fe_mul(x, big_root(a.big_tw, ex, logM));
+            if (ex != 0) x = fe_mul_lazy(x, big_root(a.big_tw, ex, logM));
         }
-        if (DIF && a.post_table) x = fe_mul(x, ld_fe(a.post_table + didx));
-        if (has_scalar) x = fe_mul(x, scal);
+        if (DIF && a.post_table) x = fe_mul_lazy(x, ld_fe(a.post_table + didx));
+        if (has_scalar) x = fe_mul_lazy(x, scal);
+        if (!a.weak_out) x = DIF ? fe_reduce_once(x) : fe_canonical_4p(x);  // last pass of the transform: canonical
         st_fe(dst + didx, x);
     }
 }
@@ -324,11 +332,14 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
     if (k == 0) return SP_OK;
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    for (const PassGeom& p : geometry(k, 0, NTT_MAX_CONTIG_LOG)) {
+    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG);
+    for (size_t i = 0; i < geo.size(); ++i) {
+        const PassGeom& p = geo[i];
         NttPassArgs a{};
         a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(roots(p.r, &a.small_tw));
         a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.weak_out = i + 1 < geo.size();
         SP_TRY(launch_pass(false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
     }
     return SP_OK;
@@ -345,6 +356,7 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
         a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
         a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.weak_out = i != 0;
         if (i == 0) a.post_table = post_table;
         SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
     }
@@ -370,6 +382,7 @@ int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, ui
         cur = out; cur_stride = out_stride; ++pi;
         SP_TRY(roots(p.r, &a.small_tw));
         a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.weak_out = pi < geo.size();
         SP_TRY(launch_pass(false, first ? NTT_LOAD_GATHER_BITREV : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
         first = false;
     }
@@ -402,6 +415,7 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
         a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
         a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.weak_out = i != 0;
         int sm = NTT_STORE_INPLACE;
         if (i == 0) { sm = NTT_STORE_SCATTER_BITREV; a.scalar = d_scalar_; }
         SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, sm, a, batch));
@@ -425,10 +439,12 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
         geo.push_back({logb, 0, std::min(logb, NTT_STRIDED_G_LOG), 0});
     }
     bool first = true;
+    size_t pi = 0;
     for (const PassGeom& p : geo) {
         NttPassArgs a{};
         a.src = first ? coeffs : dst; a.dst = dst;
         a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
+        a.weak_out = ++pi < geo.size();
         SP_TRY(roots(p.r, &a.small_tw));
         a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.s_prev = p.s_prev; a.log_expand = logb;
         a.shard_log = (uint32_t)shard_log; a.shard_rank = (uint32_t)shard_rank;
