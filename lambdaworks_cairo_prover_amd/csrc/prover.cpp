@@ -414,16 +414,36 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     SP_HIP_CHECK(hipMemcpyAsync(d_deep_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
     fe pts[3] = {z_, fe_mul(z_, g_), fe_sqr(z_)};
-    fe* inv = d_scratch_;
-    fe* inv_scratch = d_scratch_ + 3 * Nl_;
-    SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, 3, shard_map()));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * Nl_, c_->d_flag));
-    fe* p0_local = world_ == 1 ? d_fri_evals_[0] : d_local_;
-    SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, d_deep_consts_, inv, p0_local));
-    if (world_ > 1) {  // FRI runs replicated on the all-gathered DEEP evaluations
-        SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe)));
-        SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[0], n_, shard_map()));
+    if (!h_full_) {
+        // deg p0 <= n - 2 (every term is a quotient of a polynomial of degree < n by a linear factor), so p0 is fixed by
+        // its values on ONE coset of n points: evaluate the quotient form there only (coset c0 = first coset this rank
+        // holds), interpolate, and extend with the same LDE as every other column - 1/b of the pointwise work and of
+        // the inversions, the same field elements.  Under coset sharding every rank gets the identical polynomial from
+        // its own coset, so FRI layer 0 needs no all-gather.
+        const uint32_t shift = logb_ - logG_;                 // local elements per row of the LDE matrix
+        const fe* roots_n = nullptr;
+        SP_TRY(c_->ntt->roots((int)logn_, &roots_n));
+        const fe wN = host_primitive_root((int)logN_);
+        const fe hp = fe_mul(h_, fe_pow_u64(wN, rank_));      // offset of that coset: h w_N^c0
+        fe* inv = d_scratch_;                                  // [3][n]
+        fe* inv_scratch = d_scratch_ + 3 * n_;                 // [3 n]
+        fe* p0n = d_scratch_ + 6 * n_;                         // [n]
+        SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, 3, ShardMap{0, 0, 0}));
+        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * n_, c_->d_flag));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n));
+        // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
+        fe* post = d_scratch_;                                 // [n], the inverses are dead now
+        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, fe_inv(fe_pow_u64(wN, rank_)), fe_inv(fe_from_u64(n_))));
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, post));
+        SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
+    } else {
+        // deg H >= 2n (constraint-violating trace, single GPU only): the quotient form on the whole domain
+        fe* inv = d_scratch_;
+        fe* inv_scratch = d_scratch_ + 3 * Nl_;
+        SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, 3, shard_map()));
+        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * Nl_, c_->d_flag));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0]));
     }
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;

@@ -73,7 +73,9 @@ struct DeepConsts {
 // compute_deep_composition_poly (reference src/starks/prover.rs:410-482) in evaluation form:
 // p0(x) = (sum_j g_j0 t_j(x) - c_t0) / (x - z) + (sum_j g_j1 t_j(x) - c_t1) / (x - z g) + (g H1 + g' H2 - c_h) / (x - z^2);
 // inv: [3][N] = 1/(x - z), 1/(x - z g), 1/(x - z^2).
-int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t N, const DeepConsts* consts_dev, const fe* inv, fe* out);
+// `count` points, point q = element (q << shift) of every column (columns at col_stride); inv = [3][count].
+int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
+                     const DeepConsts* consts_dev, const fe* inv, fe* out);
 
 // fold_polynomial + FriLayer::new (reference src/starks/fri/fri_functions.rs:4-27, fri_commitment.rs:30-47) in evaluation
 // form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.

@@ -340,23 +340,28 @@ int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32
 }
 
 // ---------------------------------------------------------------------------------------------- DEEP composition
-__global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, const fe* __restrict__ h1, const fe* __restrict__ h2, uint64_t N,
-                                                   const DeepConsts* __restrict__ K, const fe* __restrict__ inv, fe* __restrict__ out) {
-    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+// Point q of the launch is element (q << shift) of every column (shift > 0: one coset of the LDE domain only);
+// inv holds the three inverse arrays with `count` entries each, out[q] the value.
+__global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, const fe* __restrict__ h1, const fe* __restrict__ h2, uint64_t count,
+                                                   uint64_t col_stride, uint32_t shift, const DeepConsts* __restrict__ K,
+                                                   const fe* __restrict__ inv, fe* __restrict__ out) {
+    uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (q >= count) return;
+    const uint64_t i = q << shift;
     fe a0 = fe_zero(), a1 = fe_zero();
     const uint32_t C = K->cols;
     for (uint32_t j = 0; j < C; ++j) {
-        fe t = sk_ld(lde + (uint64_t)j * N + i);
+        fe t = sk_ld(lde + (uint64_t)j * col_stride + i);
         a0 = a0 + K->gammas[0][j] * t;
         a1 = a1 + K->gammas[1][j] * t;
     }
     fe hh = K->gamma_h1 * sk_ld(h1 + i) + K->gamma_h2 * sk_ld(h2 + i) - K->c_h;
-    fe r = (a0 - K->c_t[0]) * sk_ld(inv + i) + (a1 - K->c_t[1]) * sk_ld(inv + N + i) + hh * sk_ld(inv + 2 * N + i);
-    sk_st(out + i, r);
+    fe r = (a0 - K->c_t[0]) * sk_ld(inv + q) + (a1 - K->c_t[1]) * sk_ld(inv + count + q) + hh * sk_ld(inv + 2 * count + q);
+    sk_st(out + q, r);
 }
-int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t N, const DeepConsts* consts_dev, const fe* inv, fe* out) {
-    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, lde, h1, h2, N, consts_dev, inv, out);
+int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
+                     const DeepConsts* consts_dev, const fe* inv, fe* out) {
+    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
