@@ -61,7 +61,8 @@ class NttEngine {
     int dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t stride);
     // natural input -> bit-reversed output, inverse roots, UNSCALED (x 2^k), in place;
     // post_table (nullable, device, 2^k entries indexed by output position) multiplies the result.
-    int dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table);
+    // src (nullable): read the input from another array with the same layout and leave it untouched.
+    int dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table, const fe* src = nullptr);
     // natural -> natural forward DFT (evaluate_fft), out of place (src != dst).
     int forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t src_stride, uint64_t dst_stride, fe* final_dst = nullptr);
     // natural -> natural inverse DFT including the 1/2^k factor (interpolate_fft); result in `data`, tmp = same-size scratch.

@@ -345,7 +345,7 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
     return SP_OK;
 }
 
-int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table) {
+int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table, const fe* src) {
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
     std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG);
@@ -353,7 +353,8 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];
         NttPassArgs a{};
-        a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
+        a.src = (src && i + 1 == geo.size()) ? src : data;  // the first pass executed may read another array (same stride)
+        a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
         a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
         a.weak_out = i != 0;

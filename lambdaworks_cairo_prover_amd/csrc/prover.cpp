@@ -64,6 +64,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     hinv_ = fe_inv(h_);
     g_ = host_primitive_root((int)logn_);
     SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
+    SP_TRY(alloc((void**)&d_trace_, sizeof(fe) * n_ * C_));
     SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * std::max<uint64_t>(Nl_, n_) * C_));  // >= n per column: also stages the raw rows
     SP_TRY(alloc((void**)&d_t1_, sizeof(fe) * n_));
     SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
@@ -82,7 +83,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
     SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
     SP_TRY(alloc((void**)&d_positions_, sizeof(uint64_t) * 4096));
-    SP_TRY(alloc((void**)&d_memcols_, sizeof(fe) * n_ * 11));
+    d_memcols_ = d_trace_ + 19 * n_;  // pc .. off_op1 columns of the main trace (input of the Cairo auxiliary trace)
     d_fri_evals_.clear(); d_fri_trees_.clear();
     for (uint32_t l = 0; l <= logn_; ++l) {
         fe* e = nullptr; digest32* t = nullptr;
@@ -137,24 +138,22 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
-    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
+    fe* trace = d_trace_ + (uint64_t)col0 * n_;
     if (rows_on_device) {
-        SP_TRY(rows_to_columns(c_->stream, c_->enc, rows_host, n_, cols, coeffs, n_));
+        SP_TRY(rows_to_columns(c_->stream, c_->enc, rows_host, n_, cols, trace, n_));
     } else {
         SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
-        SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, coeffs, n_));
+        SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, trace, n_));
     }
-    if (segment == 0 && cols >= 30)  // memory and offset columns feed the Cairo auxiliary trace
-        SP_HIP_CHECK(hipMemcpyAsync(d_memcols_, coeffs + 19 * n_, sizeof(fe) * n_ * 11, hipMemcpyDeviceToDevice, c_->stream));
     return commit_segment_resident(segment, cols, root_out);
 }
 
-// Second half of interpolate_and_commit: the segment's columns sit in natural order in the coefficient area.
+// Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.
 int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
-    // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients
-    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_));
+    // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients (the trace stays intact)
+    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
     // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     SP_TRY(c_->ntt->lde_from_bitrev(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
@@ -196,7 +195,7 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
         }
     }
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_coeffs_ + (uint64_t)Cm_ * n_, c_->d_flag));
+    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag));
     int flag = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // pa / pv are locals; flag
@@ -225,21 +224,15 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
         K.bden[j] = (uint32_t)(it - steps.begin());
         K.bcol[j] = bcs[j].col;
         K.bvalue[j] = bcs[j].value;
+        K.bstep[j] = bcs[j].step;
         if (bcs[j].col >= C_) return SP_E_INVALID_ARG;
     }
     if (steps.size() > 3) { sp_set_error("composition: more than 3 distinct boundary steps"); return SP_E_UNSUPPORTED; }
     std::vector<fe> points;
     for (uint64_t s : steps) points.push_back(fe_pow_u64(g_, s));
-    fe* binv = d_scratch_;                  // [ndist][Nl]
-    fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 Nl]
     fe* comp = d_fri_evals_[0];              // [N] full composition evaluations (the FRI layer-0 buffer is free until round 4)
     fe* comp_local = world_ == 1 ? comp : d_local_;
     const uint32_t nd = (uint32_t)points.size();
-    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    if (nd) {
-        SP_TRY(coset_minus_points(c_->stream, binv, Nl_, logN_, roots, h_, points.data(), nd, shard_map()));
-        SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
-    }
     // --- per-coset constants: x^n takes b values h^n w_b^c (reference evaluator.rs:156-171)
     K.h = h_;
     K.rap[0] = rap[0]; K.rap[1] = rap[1]; K.rap[2] = rap[2];
@@ -280,35 +273,79 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
         }
     }
     SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
-    SP_TRY(cairo_composition(c_->stream, d_lde_, Nl_, logN_, logb_, roots, d_comp_consts_, binv, comp_local, logG_, rank_));
-    if (world_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
-        SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
-        SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
-    }
-    // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
-    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
-    // A trace that satisfies its constraints gives deg H < 2n; otherwise the reference still proves (with longer H1/H2):
-    // detect that case and fall back to the general split so the bytes stay identical for every input.
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    // A trace that satisfies its constraints gives deg H < 2n, and then 2n evaluations fix H.  Decide that EXACTLY by
+    // checking the constraints on the trace itself (n rows, no divisions): clean -> evaluate the composition on the 2n
+    // points of the cosets 0 and b/2 only; otherwise (the reference still proves such traces, with longer H1/H2) fall
+    // back to the whole domain and the general split, so the bytes are identical for every input.
     int flag = 0;
-    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
-    if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
-    SP_TRY(high_coeff_check(c_->stream, comp, N_, logb_, c_->d_flag));
-    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
-    h_full_ = flag != 0;
-    if (!h_full_) {
-        SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
+    bool sub_coset = world_ == 1 && logb_ >= 1;
+    if (sub_coset) {
+        SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // (also: K is a stack object)
+        sub_coset = flag == 0;
+        SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    } else {
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
+    }
+    if (sub_coset) {
+        const uint64_t M = 2 * n_;
+        const fe* roots_m = nullptr;
+        SP_TRY(c_->ntt->roots((int)logn_ + 1, &roots_m));
+        fe* binv = d_scratch_;                    // [ndist][2n]
+        fe* inv_scratch = d_scratch_ + 3 * M;     // [3 * 2n]
+        if (nd) {
+            SP_TRY(coset_minus_points(c_->stream, binv, M, logn_ + 1, roots_m, h_, points.data(), nd, ShardMap{0, 0, 0}));
+            SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * M, c_->d_flag));
+        }
+        fe* comp2 = d_h12s_;                      // [2n] evaluations H(h w_2n^i), then [H1s | H2s]
+        SP_TRY(cairo_composition(c_->stream, d_lde_, M, Nl_, logb_ - 1, logN_, logb_, roots, d_comp_consts_, binv, comp2, 0, 0));
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        // interpolate_offset_fft + even/odd split in one inverse transform: position q < n of the bit-reversed output is
+        // coefficient 2 rev_n(q), position n + q coefficient 2 rev_n(q) + 1; the post factors leave a_k h^k and b_k h^k.
+        fe* post = d_scratch_;                    // [2n], the inverses are dead once the kernel above has run
+        const fe minv = fe_inv(fe_from_u64(M));
+        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, hinv_, minv));
+        SP_TRY(gen_power_table(c_->stream, post + n_, n_, logn_, hinv_, fe_mul(minv, hinv_)));
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, post));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        h_full_ = false;
         SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else {
-        if (world_ > 1) { sp_set_error("composition: the trace violates its constraints (deg H >= 2n); unsupported with coset sharding"); return SP_E_UNSUPPORTED; }
-        if (!d_hfull_) SP_TRY(alloc((void**)&d_hfull_, sizeof(fe) * N_));
-        fe* t_half = d_scratch_;  // N/2 entries: N^-1 h^(-rev_{N/2}(q))
-        fe Ninv = fe_inv(fe_from_u64(N_));
-        SP_TRY(gen_power_table(c_->stream, t_half, N_ >> 1, logN_ - 1, hinv_, Ninv));
-        SP_TRY(split_composition_full(c_->stream, comp, N_, t_half, hinv_, d_hfull_, d_hfull_ + (N_ >> 1)));
-        SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_h12_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
+        fe* binv = d_scratch_;                  // [ndist][Nl]
+        fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 Nl]
+        if (nd) {
+            SP_TRY(coset_minus_points(c_->stream, binv, Nl_, logN_, roots, h_, points.data(), nd, shard_map()));
+            SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
+        }
+        SP_TRY(cairo_composition(c_->stream, d_lde_, Nl_, Nl_, 0, logN_, logb_, roots, d_comp_consts_, binv, comp_local, logG_, rank_));
+        if (world_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
+            SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
+            SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
+        }
+        // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        SP_TRY(high_coeff_check(c_->stream, comp, N_, logb_, c_->d_flag));
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        h_full_ = flag != 0;
+        if (!h_full_) {
+            SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
+            SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+        } else {
+            if (world_ > 1) { sp_set_error("composition: the trace violates its constraints (deg H >= 2n); unsupported with coset sharding"); return SP_E_UNSUPPORTED; }
+            if (!d_hfull_) SP_TRY(alloc((void**)&d_hfull_, sizeof(fe) * N_));
+            fe* t_half = d_scratch_;  // N/2 entries: N^-1 h^(-rev_{N/2}(q))
+            fe Ninv = fe_inv(fe_from_u64(N_));
+            SP_TRY(gen_power_table(c_->stream, t_half, N_ >> 1, logN_ - 1, hinv_, Ninv));
+            SP_TRY(split_composition_full(c_->stream, comp, N_, t_half, hinv_, d_hfull_, d_hfull_ + (N_ >> 1)));
+            SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_h12_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
+        }
     }
     SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
     stage_ = 4;

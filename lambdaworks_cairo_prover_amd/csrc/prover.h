@@ -69,6 +69,7 @@ class StarkProver : public sp_deletable {
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
     std::vector<void*> allocs_;
     fe *d_coeffs_ = nullptr, *d_lde_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr;
+    fe* d_trace_ = nullptr;  // [C][n] the trace itself, natural order (kept for the constraint check of round 2)
     fe *d_h12s_ = nullptr, *d_h12_ = nullptr, *d_scratch_ = nullptr;  // scratch: 4N elements
     digest32 *d_tree_main_ = nullptr, *d_tree_aux_ = nullptr, *d_tree_comp_ = nullptr;
     std::vector<fe*> d_fri_evals_;          // layer k: N >> k elements

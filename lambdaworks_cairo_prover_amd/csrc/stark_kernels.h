@@ -37,14 +37,20 @@ struct CompositionConsts {
     fe bvalue[CAIRO_MAX_BOUNDARY];                                          // boundary values
     uint32_t bcol[CAIRO_MAX_BOUNDARY];                                      // boundary columns
     uint32_t bden[CAIRO_MAX_BOUNDARY];                                      // index of the inverse-denominator array
+    uint64_t bstep[CAIRO_MAX_BOUNDARY];                                     // boundary rows (trace check only)
     uint32_t n_boundary, n_transitions, main_cols, has_rc_builtin;
 };
 
 // ConstraintEvaluator::evaluate (reference src/starks/constraints/evaluator.rs:38-260) with CairoAIR::compute_transition
-// (src/cairo/air.rs:743-767, helpers :869-1160) fused per LDE point.  lde: column-major [C][N] natural order;
-// binv: [ndist][N] inverse boundary denominators; out: [N].
-int cairo_composition(hipStream_t st, const fe* lde, uint64_t N, uint32_t logN, uint32_t logb, const fe* roots_N,
-                      const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log = 0, uint32_t shard_rank = 0);
+// (src/cairo/air.rs:743-767, helpers :869-1160) fused per LDE point.  lde: column-major [C][col_len] natural order;
+// point i of the `count` points is element i << stride_log of every column; binv: [ndist][count] inverse boundary
+// denominators; out: [count].  (stride_log = 0: the whole local LDE domain; stride_log = logb - 1: the 2n points of the
+// cosets 0 and b/2.)
+int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
+                      const fe* roots_N, const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log = 0, uint32_t shard_rank = 0);
+// validate_trace (reference src/starks/debug.rs:13-104) on the device: *flag_dev |= 1 unless every transition
+// constraint vanishes on every row it is enforced on and every boundary value matches.  trace: [C][n] natural order.
+int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev);
 
 // Split of the composition polynomial (reference src/starks/prover.rs:250-252, evaluation_table.rs:27-33):
 // X = unscaled bit-reversed size-N inverse transform of the N evaluations; writes the h-scaled bit-reversed coefficient
