@@ -41,3 +41,46 @@ def test_random_trace_proof_bytes_equal_oracle(hip_ctx, oracle, n, has_rc, optio
     assert len(got) == len(want)
     assert got == want
     assert not oracle.cairo_verify(got, pub, options)  # a random trace does not satisfy the AIR
+
+
+def _pub_from_run(oracle, run, **override):
+    pi = run.public_inputs_c
+    kw = dict(pc_init=int.from_bytes(bytes(pi.pc_init), "big"), ap_init=int.from_bytes(bytes(pi.ap_init), "big"),
+              fp_init=int.from_bytes(bytes(pi.fp_init), "big"), pc_final=int.from_bytes(bytes(pi.pc_final), "big"),
+              ap_final=int.from_bytes(bytes(pi.ap_final), "big"))
+    kw.update(override)
+    return oracle.make_public_inputs(kw["pc_init"], kw["ap_init"], kw["fp_init"], kw["pc_final"], kw["ap_final"],
+                                     pi.range_check_min, pi.range_check_max, run.public_memory(), pi.num_steps)
+
+
+@pytest.mark.parametrize("case", ["one_cell", "last_row_exempt_cell", "boundary_only", "selector_row"])
+def test_nearly_valid_traces_take_the_exact_path(hip_ctx, oracle, case):
+    """The composition round decides between its 2n-point path and the whole-domain path with an exact constraint check
+    of the trace; traces that are valid except for one detail must still give the oracle's bytes (and an invalid proof)."""
+    run = api.CairoRun.fibonacci(40)
+    trace = run.main_trace().copy()
+    n = trace.shape[0]
+    options = (4, 5, 3, 2)
+    pub, keep = _pub_from_run(oracle, run)
+    if case == "one_cell":
+        trace[5, 24, 31] ^= 1                       # dst of step 5: breaks a handful of constraints on one row
+    elif case == "last_row_exempt_cell":
+        trace[n - 1, 17, 31] ^= 1                   # ap of the last row: only non-exempt constraints can notice
+    elif case == "boundary_only":
+        pub, keep = _pub_from_run(oracle, run, pc_final=int.from_bytes(bytes(run.public_inputs_c.pc_final), "big") + 1)
+    elif case == "selector_row":
+        trace[n - 2, 16, 31] ^= 1                   # res on a padding row
+    want = oracle.cairo_prove(trace, pub, options)
+    got = hip_ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+    assert got == want
+    if case in ("one_cell", "boundary_only"):   # (cells of selector-free padding rows are not constrained: those stay valid)
+        assert not oracle.cairo_verify(got, pub, options)
+
+
+def test_valid_trace_still_verifies_after_the_sub_coset_path(hip_ctx, oracle):
+    run = api.CairoRun.fibonacci(40)
+    options = (4, 5, 3, 2)
+    pub, keep = _pub_from_run(oracle, run)
+    got = hip_ctx.cairo_prove(run.main_trace(), pub, api.ProofOptions(*options))
+    assert got == oracle.cairo_prove(run.main_trace(), pub, options)
+    assert oracle.cairo_verify(got, pub, options)
