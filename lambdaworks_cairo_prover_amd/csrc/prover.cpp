@@ -279,7 +279,7 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     // points of the cosets 0 and b/2 only; otherwise (the reference still proves such traces, with longer H1/H2) fall
     // back to the whole domain and the general split, so the bytes are identical for every input.
     int flag = 0;
-    bool sub_coset = world_ == 1 && logb_ >= 1;
+    bool sub_coset = logb_ >= logG_ + 1;  // this rank holds both cosets c0 = rank and c0 + b/2 (always on one GPU)
     if (sub_coset) {
         SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
@@ -293,21 +293,28 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
         const uint64_t M = 2 * n_;
         const fe* roots_m = nullptr;
         SP_TRY(c_->ntt->roots((int)logn_ + 1, &roots_m));
+        // the 2n points are x_i = hp w_2n^i with hp = h w_N^c0 (c0 = rank: under coset sharding every rank works on its own
+        // pair of cosets and obtains the same polynomial, so the composition evaluations need no all-gather)
+        const fe wN = host_primitive_root((int)logN_);
+        const fe hp = fe_mul(h_, fe_pow_u64(wN, rank_));
+        const fe u = fe_inv(fe_pow_u64(wN, rank_));  // w_N^-c0
         fe* binv = d_scratch_;                    // [ndist][2n]
         fe* inv_scratch = d_scratch_ + 3 * M;     // [3 * 2n]
         if (nd) {
-            SP_TRY(coset_minus_points(c_->stream, binv, M, logn_ + 1, roots_m, h_, points.data(), nd, ShardMap{0, 0, 0}));
+            SP_TRY(coset_minus_points(c_->stream, binv, M, logn_ + 1, roots_m, hp, points.data(), nd, ShardMap{0, 0, 0}));
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * M, c_->d_flag));
         }
         fe* comp2 = d_h12s_;                      // [2n] evaluations H(h w_2n^i), then [H1s | H2s]
-        SP_TRY(cairo_composition(c_->stream, d_lde_, M, Nl_, logb_ - 1, logN_, logb_, roots, d_comp_consts_, binv, comp2, 0, 0));
+        SP_TRY(cairo_composition(c_->stream, d_lde_, M, Nl_, logb_ - logG_ - 1, logN_, logb_, roots, d_comp_consts_, binv, comp2, logG_, rank_));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         // interpolate_offset_fft + even/odd split in one inverse transform: position q < n of the bit-reversed output is
-        // coefficient 2 rev_n(q), position n + q coefficient 2 rev_n(q) + 1; the post factors leave a_k h^k and b_k h^k.
+        // 2n c_j hp^j for j = 2k, position n + q for j = 2k + 1 (k = rev_n(q)); the post factors leave a_k h^k = c_2k h^k
+        // and b_k h^k = c_(2k+1) h^k:  (2n)^-1 (h^-1 u^2)^k  and  (2n)^-1 (h^-1 u) (h^-1 u^2)^k,  u = w_N^-c0.
         fe* post = d_scratch_;                    // [2n], the inverses are dead once the kernel above has run
         const fe minv = fe_inv(fe_from_u64(M));
-        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, hinv_, minv));
-        SP_TRY(gen_power_table(c_->stream, post + n_, n_, logn_, hinv_, fe_mul(minv, hinv_)));
+        const fe base = fe_mul(hinv_, fe_sqr(u));
+        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, base, minv));
+        SP_TRY(gen_power_table(c_->stream, post + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, post));
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
