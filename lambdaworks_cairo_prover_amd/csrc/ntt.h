@@ -43,6 +43,7 @@ struct NttPassArgs {
     // 1 on every pass but the last one of a transform: the stored data stays lazily reduced ([0, 4p) after a DIT pass,
     // [0, 2p) after a DIF pass); 0: the pass stores canonical values.
     uint32_t weak_out;
+    uint32_t batch;       // vectors per launch (filled in by the launcher)
 };
 
 enum NttLoadMode { NTT_LOAD_INPLACE = 0, NTT_LOAD_GATHER_BITREV = 1, NTT_LOAD_EXPAND = 2 };

@@ -55,9 +55,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     uint4* Twl = smem + 2 * TILE;            // small twiddles, R/2 entries (two planes)
     uint4* Twh = Twl + (R >> 1);
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    const fe* src = a.src + (uint64_t)blockIdx.y * a.src_vec_stride;
-    fe* dst = a.dst + (uint64_t)blockIdx.y * a.dst_vec_stride;
+    // vector index fastest: consecutive work-groups run the same tile of different vectors, so the inter-pass twiddles
+    // they gather (the same table entries for every vector) are L2 hits for all but the first of them
+    const uint32_t tile = blockIdx.x / a.batch;
+    const uint32_t vec = blockIdx.x - tile * a.batch;
+    const fe* src = a.src + (uint64_t)vec * a.src_vec_stride;
+    fe* dst = a.dst + (uint64_t)vec * a.dst_vec_stride;
     const uint32_t logM = a.logM;
 
     for (uint32_t i = tid; i < (R >> 1); i += NTT_THREADS) lds_st(Twl, Twh, i, ld_fe(a.small_tw + i));
@@ -281,7 +284,10 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
     uint32_t tiles = 1u << (a.logM - a.shard_log - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
-    hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles, batch), dim3(NTT_THREADS), lds, st, a);
+    NttPassArgs b = a;
+    b.batch = batch;
+    if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
+    hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
