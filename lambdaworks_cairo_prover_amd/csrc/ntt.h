@@ -44,6 +44,7 @@ struct NttPassArgs {
     // [0, 2p) after a DIF pass); 0: the pass stores canonical values.
     uint32_t weak_out;
     uint32_t batch;       // vectors per launch (filled in by the launcher)
+    uint32_t xcd_map;     // 1: XCD-aware block -> (tile, vector) mapping (needs tiles % 8 == 0)
 };
 
 enum NttLoadMode { NTT_LOAD_INPLACE = 0, NTT_LOAD_GATHER_BITREV = 1, NTT_LOAD_EXPAND = 2 };

@@ -57,8 +57,18 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     const uint32_t tid = threadIdx.x;
     // vector index fastest: consecutive work-groups run the same tile of different vectors, so the inter-pass twiddles
     // they gather (the same table entries for every vector) are L2 hits for all but the first of them
-    const uint32_t tile = blockIdx.x / a.batch;
-    const uint32_t vec = blockIdx.x - tile * a.batch;
+    // Work-groups are dealt round-robin to the 8 XCDs (each with its own L2): pin tile t to XCD t mod 8 and let that XCD
+    // run the tile for all vectors back to back  (id = slot * 8 + t % 8, slot = (t / 8) * batch + vec).
+    uint32_t tile, vec;
+    if (a.xcd_map) {
+        const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+        const uint32_t tg = slot / a.batch;
+        vec = slot - tg * a.batch;
+        tile = (tg << 3) | xcd;
+    } else {
+        tile = blockIdx.x / a.batch;
+        vec = blockIdx.x - tile * a.batch;
+    }
     const fe* src = a.src + (uint64_t)vec * a.src_vec_stride;
     fe* dst = a.dst + (uint64_t)vec * a.dst_vec_stride;
     const uint32_t logM = a.logM;
@@ -286,6 +296,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
     NttPassArgs b = a;
     b.batch = batch;
+    b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
