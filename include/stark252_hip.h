@@ -111,9 +111,14 @@ int sp_fe_to_device(int fe_encoding, const uint8_t* in, uint64_t n, uint8_t* out
 int sp_fe_from_device(int fe_encoding, const uint8_t* in_device_layout, uint64_t n, uint8_t* out);
 
 int sp_sync(sp_ctx* ctx);
-/* Average duration in milliseconds of the kernels launched by the last sp_*_dev call, measured with HIP events
- * on the context stream (bench.py roofline). */
+/* Duration in milliseconds of the kernels launched by the last sp_*_dev call, measured with HIP events on the context
+ * stream; waits for that call to finish. */
 int sp_last_kernel_ms(sp_ctx* ctx, float* ms_out);
+/* HIP-event timer on the context stream around any sequence of asynchronous calls: sp_timer_start records an event,
+ * sp_timer_stop records a second one, waits for it and returns the elapsed device time in milliseconds. bench.py
+ * brackets its timed region with these, so the per-launch figure contains no host round trips. */
+int sp_timer_start(sp_ctx* ctx);
+int sp_timer_stop(sp_ctx* ctx, float* ms_out);
 
 /* PublicInputs — reference src/cairo/air.rs:163-181 (HashMaps flattened to arrays). Field elements in
  * SP_FE_CANON_BE regardless of the context encoding. */

@@ -148,6 +148,14 @@ class Context:
         check(self._lib.sp_last_kernel_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def timer_start(self):
+        check(self._lib.sp_timer_start(self._h))
+
+    def timer_stop(self):
+        ms = ctypes.c_float()
+        check(self._lib.sp_timer_stop(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def sync(self):
         check(self._lib.sp_sync(self._h))
 

@@ -41,7 +41,8 @@ int sp_ctx_create(sp_ctx** out, const sp_config* cfg) {
     c->enc = cfg->fe_encoding;
     if (hipStreamCreate(&c->stream) != hipSuccess) { delete c; sp_set_error("hipStreamCreate failed"); return SP_E_HIP; }
     c->ntt = new NttEngine(c->stream);
-    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess) { sp_ctx_destroy(c); return SP_E_HIP; }
+    if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
+        hipEventCreate(&c->tev0) != hipSuccess || hipEventCreate(&c->tev1) != hipSuccess) { sp_ctx_destroy(c); return SP_E_HIP; }
     if (hipMalloc(&c->d_flag, sizeof(int)) != hipSuccess) { sp_ctx_destroy(c); return SP_E_ALLOC; }
     *out = c;
     return SP_OK;
@@ -56,6 +57,8 @@ void sp_ctx_destroy(sp_ctx* c) {
     delete c->ntt;
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->tev0) (void)hipEventDestroy(c->tev0);
+    if (c->tev1) (void)hipEventDestroy(c->tev1);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -113,6 +116,11 @@ int sp_sync(sp_ctx* c) {
 
 int sp_last_kernel_ms(sp_ctx* c, float* ms) {
     if (!c || !ms) return SP_E_INVALID_ARG;
+    if (c->last_pending) {
+        SP_HIP_CHECK(hipEventSynchronize(c->ev1));
+        SP_HIP_CHECK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+        c->last_pending = false;
+    }
     *ms = c->last_ms;
     return SP_OK;
 }
@@ -191,8 +199,23 @@ int sp_ntt_dev(sp_ctx* c, void* data_dev, uint64_t n, uint32_t batch, int invers
     int rc = ntt_dev_impl(c, reinterpret_cast<fe*>(data_dev), n, batch, inverse, coset, reinterpret_cast<fe*>(c->scratch));
     SP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     if (rc != SP_OK) return rc;
-    SP_HIP_CHECK(hipEventSynchronize(c->ev1));
-    SP_HIP_CHECK(hipEventElapsedTime(&c->last_ms, c->ev0, c->ev1));
+    c->last_pending = true;  // resolved by sp_last_kernel_ms (the call itself stays asynchronous)
+    return SP_OK;
+}
+
+// HIP-event timer on the context stream around an arbitrary sequence of asynchronous calls (bench.py's timed region).
+int sp_timer_start(sp_ctx* c) {
+    if (!c) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    SP_HIP_CHECK(hipEventRecord(c->tev0, c->stream));
+    return SP_OK;
+}
+int sp_timer_stop(sp_ctx* c, float* ms) {
+    if (!c || !ms) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    SP_HIP_CHECK(hipEventRecord(c->tev1, c->stream));
+    SP_HIP_CHECK(hipEventSynchronize(c->tev1));
+    SP_HIP_CHECK(hipEventElapsedTime(ms, c->tev0, c->tev1));
     return SP_OK;
 }
 

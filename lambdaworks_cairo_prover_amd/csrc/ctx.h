@@ -12,7 +12,9 @@ struct sp_ctx {
     int enc = SP_FE_CANON_BE;
     hipStream_t stream = nullptr;
     sp::NttEngine* ntt = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;    // around the last sp_*_dev call
+    hipEvent_t tev0 = nullptr, tev1 = nullptr;  // sp_timer_start / sp_timer_stop
+    bool last_pending = false;
     int* d_flag = nullptr;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;

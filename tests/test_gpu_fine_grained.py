@@ -87,3 +87,53 @@ def test_batch_inverse(hip_ctx, oracle):
         assert np.array_equal(hip_ctx.batch_inverse(x), oracle.batch_inverse(x))
     with pytest.raises(api.SpError):
         hip_ctx.batch_inverse(api.felts_to_bytes([5, 0, 7]))
+
+
+class _HipBuffer:
+    """Device memory through the HIP runtime the library itself is linked against (importing torch after the library has
+    initialised HIP would bring a second runtime into the process)."""
+
+    def __init__(self, host: np.ndarray):
+        import ctypes
+        self._ct = ctypes
+        self._hip = ctypes.CDLL("libamdhip64.so")
+        self.nbytes = host.nbytes
+        self.ptr = ctypes.c_void_p()
+        assert self._hip.hipMalloc(ctypes.byref(self.ptr), ctypes.c_size_t(self.nbytes)) == 0
+        assert self._hip.hipMemcpy(self.ptr, host.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(self.nbytes), 1) == 0
+
+    def to_host(self, dtype=np.uint8):
+        out = np.empty(self.nbytes, dtype=np.uint8)
+        assert self._hip.hipMemcpy(out.ctypes.data_as(self._ct.c_void_p), self.ptr, self._ct.c_size_t(self.nbytes), 2) == 0
+        return out
+
+    def free(self):
+        self._hip.hipFree(self.ptr)
+
+
+@pytest.mark.parametrize("k,batch", [(10, 1), (13, 5), (22, 1)])
+def test_ntt_dev_batched_device_entry_point(hip_ctx, oracle, k, batch):
+    """sp_ntt_dev (the entry point bench.py times): asynchronous, batched, device layout in place - same values as
+    sp_ntt on host buffers, which the tests above pin to the oracle; the event timers return plausible durations."""
+    n = 1 << k
+    rng = random.Random(100 + k)
+    cols = [api.felts_to_bytes([rng.randrange(api.P) for _ in range(n)]) if k <= 13 else
+            api.felts_to_bytes(np.random.default_rng(k + v).integers(0, 2**62, size=n).tolist()) for v in range(batch)]
+    dev_layout = np.ascontiguousarray(np.concatenate([api.fe_to_device(c) for c in cols]))
+    d = _HipBuffer(dev_layout)
+    try:
+        hip_ctx.timer_start()
+        hip_ctx.ntt_dev(d.ptr.value, n, batch)
+        region_ms = hip_ctx.timer_stop()
+        call_ms = hip_ctx.last_kernel_ms()
+        hip_ctx.sync()
+        got = api.fe_from_device(d.to_host().reshape(-1, 32)).reshape(batch, n, 32)
+        for v in range(batch):
+            want = hip_ctx.ntt(cols[v]) if k > 13 else oracle.ntt(cols[v])
+            assert np.array_equal(got[v], want)
+        assert 0.0 < call_ms <= region_ms * 1.5 + 0.05
+        hip_ctx.ntt_dev(d.ptr.value, n, batch, inverse=True)   # the inverse restores the input
+        hip_ctx.sync()
+        assert np.array_equal(d.to_host().reshape(-1, 32), dev_layout.reshape(-1, 32))
+    finally:
+        d.free()
