@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_BUTTERFLY_CEILING = 1.49e11  # measured, one MI355X, kernels >= 20 ms (tools/experiments/ubench_mul9.hip)
 
 
 def cpu_baseline(log_n=22, reps=3):
@@ -148,7 +149,11 @@ def main():
                    "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
-                     "mulmod_per_s": butterflies / (avg_ms * 1e-3)},
+                     "mulmod_per_s": butterflies / (avg_ms * 1e-3),
+                     # the pass kernels are VALU-issue bound: the honest ceiling is the sustained rate
+                     # of a registers-only butterfly (mul + add + sub) chain, profiles/r01_mul9_ubench.txt
+                     "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING,
+                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING},
     }
     want_proof = args.proof == 1 or (args.proof == -1 and world == 1)
     if want_proof:
