@@ -74,6 +74,79 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
     nodes[p] = d;
 }
 
+// ---- lane-parallel permutation for the small tree levels -------------------------------------------------------------
+// A level with few nodes is latency-bound in node_hash_kernel: one lane needs 24 x 180 dependent-issue instructions
+// (~11 us) however few nodes there are, and a proof has ~300 such levels.  Here 25 lanes share one permutation, lane
+// (x, y) = (l % 5, l / 5) holding state word A[x][y]; a round is two exchanges through a 200-byte LDS block:
+//   write A; read the columns x-1 and x+1 (ten words) -> D[x];  t = rotl(A ^ D[x], rho[x][y]);  write t at pi(x, y);
+//   read B[x][y], B[x+1][y], B[x+2][y] -> chi; iota on lane 0.
+// Two permutations per wave (lanes 0-24 and 32-56).  ~2.5x lower latency, ~8x more lane-instructions per permutation:
+// used only below MK_LANES_MAX_NODES nodes; levels of <= 32 nodes are fused into one launch (MK_LANES_FUSED).
+constexpr uint32_t MK_LANES_MAX_NODES = 4096;
+constexpr uint32_t MK_LANES_FUSED = 32;   // slots of the fused launch (1024 threads)
+__device__ __constant__ const uint8_t SP_KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+
+__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t n) { return (v << n) | (v >> ((64u - n) & 63u)); }
+
+// one permutation slot = 32 consecutive lanes (25 active); buf = 50 words of LDS owned by the slot
+__device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool active, uint64_t* buf) {
+    const uint32_t x = l % 5u, y = l / 5u;
+    uint64_t* A = buf;
+    uint64_t* B = buf + 25;
+    const uint32_t xm = (x + 4u) % 5u, xp = (x + 1u) % 5u, xpp = (x + 2u) % 5u;
+    const uint32_t rho = active ? SP_KECCAK_RHO[l] : 0u;
+    const uint32_t dst = y + 5u * ((2u * x + 3u * y) % 5u);   // pi: B[y][2x + 3y] = rotl(A[x][y], rho[x][y])
+#pragma unroll 1
+    for (int r = 0; r < 24; ++r) {
+        if (active) A[l] = a;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint64_t cm = 0, cp = 0;
+        if (active) {
+#pragma unroll
+            for (uint32_t k = 0; k < 5; ++k) { cm ^= A[xm + 5u * k]; cp ^= A[xp + 5u * k]; }
+            const uint64_t t = rotl64_var(a ^ cm ^ rotl64_var(cp, 1), rho);
+            B[dst] = t;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (active) {
+            const uint64_t b0 = B[l], b1 = B[xp + 5u * y], b2 = B[xpp + 5u * y];
+            a = b0 ^ (~b1 & b2);
+            if (l == 0) a ^= SP_KECCAK_RC_DEV[r];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return a;
+}
+
+// nodes[first + i] for i < count; with fused = true (one work-group, count <= its slots) continues with count/2, ... 1.
+__global__ void __launch_bounds__(1024) node_hash_lanes_kernel(digest32* nodes, uint64_t first, uint32_t count, int fused) {
+    __shared__ uint64_t lds[MK_LANES_FUSED * 50];
+    const uint32_t slots = blockDim.x >> 5;
+    const uint32_t slot = threadIdx.x >> 5, l = threadIdx.x & 31u;
+    const bool lane_active = l < 25u;
+    uint64_t* buf = lds + slot * 50;
+    uint64_t* words = reinterpret_cast<uint64_t*>(nodes);
+    for (;;) {
+        const uint32_t i = blockIdx.x * slots + slot;
+        if (i < count) {   // uniform per slot (32 lanes), slots never straddle a wave
+            const uint64_t p = first + i;
+            uint64_t a = 0;
+            if (l < 8u) a = words[(2 * p + 1) * 4 + l];          // left digest then right digest: 8 consecutive words
+            else if (l == 8u) a = 0x01ULL;                       // original Keccak padding of a 64-byte message
+            else if (l == 16u) a = 0x8000000000000000ULL;
+            a = keccak_f_lanes(a, l, lane_active, buf);
+            if (l < 4u) words[p * 4 + l] = a;
+        }
+        if (!fused || count == 1) break;
+        __threadfence();
+        __syncthreads();
+        count >>= 1;
+        first = count - 1;
+    }
+}
+
 __global__ void gather_paths_kernel(const digest32* nodes, uint64_t n_leaves, uint32_t depth, const uint64_t* positions, uint32_t q, digest32* out) {
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= q * depth) return;
@@ -103,8 +176,16 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
     for (uint64_t count = n_leaves >> 1; count >= 1; count >>= 1) {
         uint64_t first = count - 1;
-        unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
-        hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, first, count);
+        if (count > MK_LANES_MAX_NODES) {
+            unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
+            hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, first, count);
+        } else if (count > MK_LANES_FUSED) {
+            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, st, nodes, first, (uint32_t)count, 0);
+        } else {   // the remaining levels count, count/2, ... 1 in one launch
+            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3(1), dim3(32 * MK_LANES_FUSED), 0, st, nodes, first, (uint32_t)count, 1);
+            SP_HIP_CHECK(hipGetLastError());
+            break;
+        }
         SP_HIP_CHECK(hipGetLastError());
     }
     return SP_OK;
