@@ -337,7 +337,9 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
         int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
         for (int i = 0; i < np; ++i) {
             int take = (rem + (np - i) - 1) / (np - i);
-            int g = std::min(NTT_STRIDED_G_LOG, s);
+            // adjacent elements per row: at least 4 (128 B), more for short passes so that a tile never has fewer
+            // elements than NTT_STRIDED_MIN_TILE_LOG (a 2^5-row pass with 4 columns would leave half the work-group idle)
+            int g = std::min(std::max(NTT_STRIDED_G_LOG, NTT_STRIDED_MIN_TILE_LOG - take), s);
             out.push_back({s, take, g, s_prev});
             s_prev = s; s += take; rem -= take;
         }
