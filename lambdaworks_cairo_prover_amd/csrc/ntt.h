@@ -23,9 +23,6 @@ constexpr int NTT_THREADS = 256;
 constexpr int NTT_MAX_CONTIG_LOG = NTT_TILE_LOG; // s = 0 pass: one row of up to 2^10 contiguous elements
 constexpr int NTT_STRIDED_G_LOG = 2;             // strided passes: 4 adjacent elements (128 B) per row
 constexpr int NTT_MAX_STRIDED_LOG = NTT_TILE_LOG - NTT_STRIDED_G_LOG;
-#ifndef NTT_STRIDED_MIN_TILE_LOG
-#define NTT_STRIDED_MIN_TILE_LOG 9               // strided passes: at least 512 elements per tile
-#endif
 
 struct NttPassArgs {
     const fe* src;

@@ -322,7 +322,12 @@ int NttEngine::launch_pass(bool dif, int lm, int sm, const NttPassArgs& a, uint3
 // Builds the pass list for a size-2^k transform. first_contig_max limits the s = 0 pass (gather/scatter passes
 // want G >= 4 rows per tile so that their strided side is coalesced).
 struct PassGeom { int s, r, g, s_prev; };
-static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max) {
+// footprint = bytes the whole batched transform touches: beyond the 256 MB infinity cache the strided passes read HBM, where
+// 256-byte rows (8 elements, 1024-element tiles) beat 128-byte rows; cache-resident transforms prefer the smaller tiles
+// (more work-groups in flight).  Measured: single 2^22 NTT 3 % faster with 512-element tiles, the proof's large batches
+// indifferent to slightly better with 1024.
+static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max, uint64_t footprint) {
+    const int min_tile_log = footprint > (256ull << 20) ? 10 : 9;
     std::vector<PassGeom> out;
     int s = first_stride_log, s_prev = 0;
     int rem = k - first_stride_log;
@@ -338,8 +343,8 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
         for (int i = 0; i < np; ++i) {
             int take = (rem + (np - i) - 1) / (np - i);
             // adjacent elements per row: at least 4 (128 B), more for short passes so that a tile never has fewer
-            // elements than NTT_STRIDED_MIN_TILE_LOG (a 2^5-row pass with 4 columns would leave half the work-group idle)
-            int g = std::min(std::max(NTT_STRIDED_G_LOG, NTT_STRIDED_MIN_TILE_LOG - take), s);
+            // than 2^min_tile_log elements (a 2^5-row pass with 4 columns would leave half the work-group idle)
+            int g = std::min(std::max(NTT_STRIDED_G_LOG, min_tile_log - take), s);
             out.push_back({s, take, g, s_prev});
             s_prev = s; s += take; rem -= take;
         }
@@ -351,7 +356,7 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
     if (k == 0) return SP_OK;
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG);
+    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG, ((uint64_t)batch << k) * sizeof(fe));
     for (size_t i = 0; i < geo.size(); ++i) {
         const PassGeom& p = geo[i];
         NttPassArgs a{};
@@ -367,7 +372,7 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
 int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table, const fe* src) {
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG);
+    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0, 0});
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];
@@ -386,7 +391,7 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
 int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, uint64_t ss, uint64_t ds, fe* final_dst) {
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0, 0});
     bool first = true;
     // ping-pong: pass 1 src -> dst (gather, must be out of place); if final_dst is given (same stride as src), pass 2
@@ -417,7 +422,7 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
     // bit-reversal scatter goes tmp -> data (a scatter must never run in place: other tiles still read their rows).
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG);
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0, 0});
     if (!d_scalar_) SP_HIP_CHECK(hipMalloc(&d_scalar_, sizeof(fe)));
     fe ninv = fe_inv(fe_from_u64(1ULL << k));
@@ -454,7 +459,7 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
     }
     const fe* big = nullptr;
     SP_TRY(roots(K, &big));
-    std::vector<PassGeom> geo = geometry(K, logb, NTT_MAX_CONTIG_LOG);
+    std::vector<PassGeom> geo = geometry(K, logb, NTT_MAX_CONTIG_LOG, ((uint64_t)batch << (K - shard_log)) * sizeof(fe));
     if (geo.empty()) {  // k == 0: constant polynomial replicated
         geo.push_back({logb, 0, std::min(logb, NTT_STRIDED_G_LOG), 0});
     }
