@@ -372,7 +372,9 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
 int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, uint64_t stride, const fe* post_table, const fe* src) {
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, NTT_MAX_CONTIG_LOG, ((uint64_t)batch << k) * sizeof(fe));
+    // beyond one tile the contiguous pass is kept short (2^7 rows x 8 contiguous runs): a 2^10-row pass stages a 16 KB
+    // twiddle table per 32 KB tile and fits only three work-groups per CU (measured 55 % of the strided passes' rate)
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : 7, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0, 0});
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];
