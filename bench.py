@@ -16,6 +16,7 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_MUL_CEILING = 1.86e11
 VALU_BUTTERFLY_CEILING = 1.49e11  # measured, one MI355X, kernels >= 20 ms (tools/experiments/ubench_mul9.hip)
 
 
@@ -153,7 +154,10 @@ def main():
                      # the pass kernels are VALU-issue bound: the honest ceiling is the sustained rate
                      # of a registers-only butterfly (mul + add + sub) chain, profiles/r01_mul9_ubench.txt
                      "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING,
-                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING},
+                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING,
+                     # the same, also counting the one product per element at each of the two pass boundaries
+                     # (sustained fe_mul rate 1.86e11/s): time the arithmetic alone needs / time measured
+                     "valu_frac_incl_twiddles": (butterflies / VALU_BUTTERFLY_CEILING + 2 * n / VALU_MUL_CEILING) / (avg_ms * 1e-3)},
     }
     want_proof = args.proof == 1 or (args.proof == -1 and world == 1)
     if want_proof:
