@@ -70,7 +70,7 @@ def test_lde_matches_oracle(hip_ctx, oracle, k, blowup, cols):
         assert np.array_equal(got[j], oracle.lde(coeffs[j], blowup, 3)), (k, blowup, j)
 
 
-@pytest.mark.parametrize("n,width", [(1, 1), (2, 1), (8, 2), (64, 18), (256, 34), (1024, 1), (512, 43), (128, 5)])
+@pytest.mark.parametrize("n,width", [(1, 1), (2, 1), (4, 1), (8, 2), (64, 18), (256, 34), (1024, 1), (512, 43), (128, 5), (16384, 2), (32768, 1)])
 def test_merkle_matches_oracle(hip_ctx, oracle, n, width):
     rng = random.Random(4000 + n + width)
     rows = rand_felts(rng, n * width).reshape(n, width, 32)
@@ -137,3 +137,36 @@ def test_ntt_dev_batched_device_entry_point(hip_ctx, oracle, k, batch):
         assert np.array_equal(d.to_host().reshape(-1, 32), dev_layout.reshape(-1, 32))
     finally:
         d.free()
+
+
+@pytest.mark.parametrize("k", [13, 18])
+def test_ntt_extreme_values_across_passes(hip_ctx, oracle, k):
+    """The passes keep their data lazily reduced ([0, 4p) / [0, 2p)) between stages and passes: inputs at the top of the
+    range (p - 1 everywhere, alternating 0 / p - 1, p - 1 on one residue class) must still come out canonical and
+    equal to the oracle through two- and three-pass transforms, forward, inverse and on a coset."""
+    n = 1 << k
+    pm1 = api.felts_to_bytes([P - 1])[0]
+    zero = api.felts_to_bytes([0])[0]
+    patterns = []
+    patterns.append(np.tile(pm1, (n, 1)))
+    alt = np.tile(zero, (n, 1)); alt[::2] = pm1
+    patterns.append(alt)
+    sparse = np.tile(zero, (n, 1)); sparse[3::64] = pm1
+    patterns.append(sparse)
+    h = api.felts_to_bytes([3])
+    for x in patterns:
+        assert np.array_equal(hip_ctx.ntt(x), oracle.ntt(x))
+        assert np.array_equal(hip_ctx.ntt(x, inverse=True), oracle.ntt(x, inverse=True))
+        assert np.array_equal(hip_ctx.ntt(x, coset=h), oracle.ntt(x, coset=3))
+
+
+def test_lde_extreme_coefficients(hip_ctx, oracle):
+    k, blowup, cols = 12, 8, 3
+    n = 1 << k
+    pm1 = api.felts_to_bytes([P - 1])[0]
+    coeffs = np.tile(pm1, (cols * n, 1)).reshape(cols, n, 32).copy()
+    coeffs[1, ::2] = 0
+    coeffs[2, 1:] = 0
+    got = hip_ctx.lde(coeffs, blowup, api.felts_to_bytes([3]))
+    want = np.stack([oracle.lde(coeffs[c], blowup, 3) for c in range(cols)])
+    assert np.array_equal(got, want)
