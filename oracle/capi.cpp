@@ -8,6 +8,8 @@
 #include "air.hpp"
 #include "cairo_air.hpp"
 #include "stark.hpp"
+#include "example_airs.hpp"
+#include <memory>
 #include <cstdlib>
 #include <cstdio>
 
@@ -202,4 +204,117 @@ int oracle_cairo_transition(const uint8_t* frame, uint32_t cols, int has_rc_buil
 
 void oracle_free(void* p) { std::free(p); }
 
+
+// ---- example AIRs of the reference (src/starks/example) and the "program" AIR -----------------------------------------
+// kind: 0 simple_fibonacci, 1 fibonacci_2_columns, 2 quadratic, 3 fibonacci_rap, 4 dummy.
+// params: up to two 32-byte BE field elements (a0, a1 / a0); steps only for fibonacci_rap.
+static std::unique_ptr<Air> make_example(int kind, size_t n, const uint8_t* params, uint64_t steps, const ProofOptions& o) {
+    Fp a0 = params ? Fp::from_bytes_be(params) : Fp::one();
+    Fp a1 = params ? Fp::from_bytes_be(params + 32) : Fp::one();
+    switch (kind) {
+        case 0: return std::unique_ptr<Air>(new FibonacciAir(n, a0, a1, o));
+        case 1: return std::unique_ptr<Air>(new Fibonacci2ColsAir(n, a0, a1, o));
+        case 2: return std::unique_ptr<Air>(new QuadraticAir(n, a0, o));
+        case 3: return std::unique_ptr<Air>(new FibonacciRapAir(n, (size_t)steps, o));
+        case 4: return std::unique_ptr<Air>(new DummyAir(n, o));
+        default: throw std::runtime_error("unknown example AIR");
+    }
+}
+static int finish_proof(const StarkProof& proof, uint8_t** proof_out, uint64_t* proof_len) {
+    std::vector<uint8_t> bytes = serialize_proof(proof);
+    *proof_out = (uint8_t*)std::malloc(bytes.size());
+    std::memcpy(*proof_out, bytes.data(), bytes.size());
+    *proof_len = bytes.size();
+    return 0;
+}
+
+// The reference's trace generators; out = n x cols row-major BE.  Returns the number of rows (0 on error); call with
+// out = nullptr to query the size.  `len` = trace length (steps for fibonacci_rap).
+uint64_t oracle_example_trace(int kind, const uint8_t* params, uint64_t len, uint8_t* out, uint32_t* cols_out) {
+    try {
+        Fp a0 = params ? Fp::from_bytes_be(params) : Fp::one();
+        Fp a1 = params ? Fp::from_bytes_be(params + 32) : Fp::one();
+        std::vector<Fp> rows; size_t n = len; uint32_t cols = 1;
+        switch (kind) {
+            case 0: rows = fibonacci_trace(a0, a1, len); break;
+            case 1: rows = fibonacci_trace_2_columns(a0, a1, len); cols = 2; break;
+            case 2: rows = quadratic_trace(a0, len); break;
+            case 3: rows = fibonacci_rap_trace(a0, a1, len, &n); cols = 2; break;
+            case 4: rows = dummy_trace(len); cols = 2; break;
+            default: return 0;
+        }
+        if (cols_out) *cols_out = cols;
+        if (out) store_felts(rows, out);
+        return n;
+    } catch (...) { return 0; }
+}
+
+int oracle_example_prove(int kind, const uint8_t* params, uint64_t steps, const uint8_t* main_trace, uint64_t n, uint32_t main_cols,
+                         const oracle_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    try {
+        ProofOptions o{opt->blowup_factor, (size_t)opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+        std::unique_ptr<Air> air = make_example(kind, n, params, steps, o);
+        std::vector<Fp> tr = load_felts(main_trace, n * main_cols);
+        Prover pr(*air, false);
+        return finish_proof(pr.prove(tr, main_cols), proof_out, proof_len);
+    } catch (const std::exception& e) { std::fprintf(stderr, "oracle_example_prove: %s\n", e.what()); return -2; }
+}
+int oracle_example_verify(int kind, const uint8_t* params, uint64_t steps, const uint8_t* proof, uint64_t proof_len, const oracle_proof_options* opt) {
+    try {
+        StarkProof p = deserialize_proof(proof, proof_len);
+        ProofOptions o{opt->blowup_factor, (size_t)opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+        if (p.trace_length == 0 || (p.trace_length & (p.trace_length - 1)) || p.trace_length > (1ULL << 30)) return 0;
+        std::unique_ptr<Air> air = make_example(kind, p.trace_length, params, steps, o);
+        return verify(*air, p) ? 1 : 0;
+    } catch (...) { return -3; }
+}
+
+// Program AIR descriptor: must match sp_air_desc of include/stark252_hip.h field for field.
+struct oracle_air_boundary { uint32_t col; uint32_t pad; uint64_t step; uint8_t value[32]; };
+struct oracle_air_desc {
+    uint32_t main_cols, aux_cols;
+    uint32_t n_offsets; uint32_t offsets[4];
+    uint32_t n_transitions; uint32_t degrees[16]; uint32_t exemptions[16];
+    uint32_t num_transition_exemptions;
+    uint32_t degree_bound_factor;
+    uint32_t n_ops; const AirOp* ops;
+    uint32_t n_consts; const uint8_t* consts;
+    uint32_t n_rap;
+    uint32_t aux_kind;
+    uint32_t n_boundary; const oracle_air_boundary* boundary;
+};
+static std::unique_ptr<ProgramAir> make_program_air(const oracle_air_desc* d, size_t n, const ProofOptions& o) {
+    std::unique_ptr<ProgramAir> a(new ProgramAir());
+    a->trace_len = n;
+    a->ctx.proof_options = o;
+    a->ctx.trace_columns = d->main_cols + d->aux_cols;
+    for (uint32_t i = 0; i < d->n_offsets; ++i) a->ctx.transition_offsets.push_back(d->offsets[i]);
+    for (uint32_t i = 0; i < d->n_transitions; ++i) { a->ctx.transition_degrees.push_back(d->degrees[i]); a->ctx.transition_exemptions.push_back(d->exemptions[i]); }
+    a->ctx.num_transition_constraints = d->n_transitions;
+    a->ctx.num_transition_exemptions = d->num_transition_exemptions;
+    a->ops.assign(d->ops, d->ops + d->n_ops);
+    a->consts = load_felts(d->consts, d->n_consts);
+    a->n_rap = d->n_rap; a->aux_cols = d->aux_cols; a->aux_kind = d->aux_kind; a->bound_factor = d->degree_bound_factor;
+    for (uint32_t i = 0; i < d->n_boundary; ++i) a->bcs.push_back({d->boundary[i].col, (size_t)d->boundary[i].step, Fp::from_bytes_be(d->boundary[i].value)});
+    return a;
+}
+int oracle_program_air_prove(const oracle_air_desc* d, const uint8_t* main_trace, uint64_t n, const oracle_proof_options* opt,
+                             uint8_t** proof_out, uint64_t* proof_len) {
+    try {
+        ProofOptions o{opt->blowup_factor, (size_t)opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+        std::unique_ptr<ProgramAir> air = make_program_air(d, n, o);
+        std::vector<Fp> tr = load_felts(main_trace, n * d->main_cols);
+        Prover pr(*air, false);
+        return finish_proof(pr.prove(tr, d->main_cols), proof_out, proof_len);
+    } catch (const std::exception& e) { std::fprintf(stderr, "oracle_program_air_prove: %s\n", e.what()); return -2; }
+}
+int oracle_program_air_verify(const oracle_air_desc* d, const uint8_t* proof, uint64_t proof_len, const oracle_proof_options* opt) {
+    try {
+        StarkProof p = deserialize_proof(proof, proof_len);
+        ProofOptions o{opt->blowup_factor, (size_t)opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+        if (p.trace_length == 0 || (p.trace_length & (p.trace_length - 1)) || p.trace_length > (1ULL << 30)) return 0;
+        std::unique_ptr<ProgramAir> air = make_program_air(d, p.trace_length, o);
+        return verify(*air, p) ? 1 : 0;
+    } catch (...) { return -3; }
+}
 }  // extern "C"

@@ -202,3 +202,61 @@ def cairo_transition(frame, rap, has_rc_builtin=False):
     rc = load().oracle_cairo_transition(_u8p(a), ctypes.c_uint32(cols), int(has_rc_builtin), b"".join(fe(x) for x in rap), _u8p(out))
     assert rc == 0
     return out
+
+
+# ---- example AIRs (reference src/starks/example) and the program AIR ----------------------------------------------------
+EXAMPLE_KINDS = {"simple_fibonacci": 0, "fibonacci_2_columns": 1, "quadratic": 2, "fibonacci_rap": 3, "dummy": 4}
+
+
+def _params(values):
+    return b"".join(fe(v) for v in (list(values) + [1, 1])[:2])
+
+
+def example_trace(kind, length, params=(1, 1)):
+    """The reference's trace generator for the example; (rows, cols, 32) uint8. `length` = trace length (steps for fibonacci_rap)."""
+    l = load()
+    l.oracle_example_trace.restype = ctypes.c_uint64
+    cols = ctypes.c_uint32()
+    n = l.oracle_example_trace(EXAMPLE_KINDS[kind], _params(params), ctypes.c_uint64(length), None, ctypes.byref(cols))
+    assert n > 0
+    out = np.empty((n, cols.value, 32), dtype=np.uint8)
+    assert l.oracle_example_trace(EXAMPLE_KINDS[kind], _params(params), ctypes.c_uint64(length), _u8p(out), ctypes.byref(cols)) == n
+    return out
+
+
+def _take_proof(out, ln):
+    proof = ctypes.string_at(out, ln.value)
+    load().oracle_free(out)
+    return proof
+
+
+def example_prove(kind, trace, options, params=(1, 1), steps=0):
+    a = np.ascontiguousarray(trace, dtype=np.uint8)
+    opt = ProofOptionsC(*options)
+    out, ln = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_uint64()
+    rc = load().oracle_example_prove(EXAMPLE_KINDS[kind], _params(params), ctypes.c_uint64(steps), _u8p(a), ctypes.c_uint64(a.shape[0]),
+                                     ctypes.c_uint32(a.shape[1]), ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln))
+    if rc != 0:
+        raise RuntimeError(f"oracle_example_prove failed: {rc}")
+    return _take_proof(out, ln)
+
+
+def example_verify(kind, proof, options, params=(1, 1), steps=0):
+    opt = ProofOptionsC(*options)
+    return load().oracle_example_verify(EXAMPLE_KINDS[kind], _params(params), ctypes.c_uint64(steps), proof, ctypes.c_uint64(len(proof)), ctypes.byref(opt)) == 1
+
+
+def program_air_prove(desc, trace, options):
+    """desc: lambdaworks_cairo_prover_amd.air.AirDescC (same layout as oracle_air_desc)."""
+    a = np.ascontiguousarray(trace, dtype=np.uint8)
+    opt = ProofOptionsC(*options)
+    out, ln = ctypes.POINTER(ctypes.c_uint8)(), ctypes.c_uint64()
+    rc = load().oracle_program_air_prove(ctypes.byref(desc), _u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln))
+    if rc != 0:
+        raise RuntimeError(f"oracle_program_air_prove failed: {rc}")
+    return _take_proof(out, ln)
+
+
+def program_air_verify(desc, proof, options):
+    opt = ProofOptionsC(*options)
+    return load().oracle_program_air_verify(ctypes.byref(desc), proof, ctypes.c_uint64(len(proof)), ctypes.byref(opt)) == 1
