@@ -39,6 +39,7 @@ int StarkProver::alloc(void** p, size_t bytes) {
 }
 
 int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc, const ProofOptionsHost& opt) {
+    offsets_ = {0, 1};
     int k = sp_log2_exact(n), lb = sp_log2_exact(opt.blowup_factor);
     if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
     if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
@@ -422,11 +423,14 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     SP_HIP_CHECK(hipSetDevice(c_->device));
     z_ = z;
     // stored coefficients are c_k h^k, so evaluate at y / h (reference prover.rs:301-304, frame.rs:67-83)
-    std::vector<fe> ys = {fe_mul(z, hinv_), fe_mul(fe_mul(z, g_), hinv_)};
+    const uint32_t R = (uint32_t)offsets_.size();   // frame rows: z g^ofs for every transition offset (frame.rs:67-83)
+    std::vector<fe> ys;
+    for (uint32_t k = 0; k < R; ++k) ys.push_back(fe_mul(fe_mul(z, fe_pow_u64(g_, offsets_[k])), hinv_));
     std::vector<fe> tr;
     SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), tr));
-    trace_ood.resize(2 * (size_t)C_);
-    for (uint32_t j = 0; j < C_; ++j) { trace_ood[j] = tr[j * 2 + 0]; trace_ood[C_ + j] = tr[j * 2 + 1]; }
+    trace_ood.resize((size_t)R * C_);
+    for (uint32_t j = 0; j < C_; ++j)
+        for (uint32_t k = 0; k < R; ++k) trace_ood[(size_t)k * C_ + j] = tr[(size_t)j * R + k];
     std::vector<fe> yh = {fe_mul(fe_sqr(z), hinv_)};
     std::vector<fe> hv;
     if (!h_full_) SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
@@ -440,7 +444,8 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
 
 int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::vector<fe>& tg, uint8_t root0_out[32]) {
     if (stage_ != 5) { sp_set_error("deep_fri_begin: out-of-domain evaluations missing"); return SP_E_STATE; }
-    if (tg.size() != 2 * (size_t)C_) return SP_E_INVALID_ARG;
+    const uint32_t R = (uint32_t)offsets_.size();
+    if (tg.size() != (size_t)R * C_) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const fe* roots = nullptr;
     SP_TRY(c_->ntt->roots((int)logN_, &roots));
@@ -448,16 +453,19 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     std::memset(&K, 0, sizeof(K));
     K.gamma_h1 = gamma; K.gamma_h2 = gamma_p;
     K.c_h = fe_add(fe_mul(gamma, h1_z2_), fe_mul(gamma_p, h2_z2_));
-    K.cols = C_;
-    K.c_t[0] = fe_zero(); K.c_t[1] = fe_zero();
+    K.cols = C_; K.rows = R;
+    for (uint32_t k = 0; k < AIR_MAX_OFFSETS; ++k) K.c_t[k] = fe_zero();
     for (uint32_t j = 0; j < C_; ++j)
-        for (uint32_t k = 0; k < 2; ++k) {
-            K.gammas[k][j] = tg[j * 2 + k];  // reference prover.rs:457-476: gamma index = j * frame_len + k
-            K.c_t[k] = fe_add(K.c_t[k], fe_mul(tg[j * 2 + k], trace_ood_[k * C_ + j]));
+        for (uint32_t k = 0; k < R; ++k) {
+            K.gammas[k][j] = tg[(size_t)j * R + k];  // reference prover.rs:457-476: gamma index = j * frame_len + k
+            K.c_t[k] = fe_add(K.c_t[k], fe_mul(tg[(size_t)j * R + k], trace_ood_[(size_t)k * C_ + j]));
         }
     SP_HIP_CHECK(hipMemcpyAsync(d_deep_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
-    fe pts[3] = {z_, fe_mul(z_, g_), fe_sqr(z_)};
+    fe pts[AIR_MAX_OFFSETS + 1];                       // z g^ofs_k for every frame row, then z^2
+    for (uint32_t k = 0; k < R; ++k) pts[k] = fe_mul(z_, fe_pow_u64(g_, offsets_[k]));
+    pts[R] = fe_sqr(z_);
+    const uint32_t npts = R + 1;
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     if (!h_full_) {
         // deg p0 <= n - 2 (every term is a quotient of a polynomial of degree < n by a linear factor), so p0 is fixed by
@@ -470,11 +478,12 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(c_->ntt->roots((int)logn_, &roots_n));
         const fe wN = host_primitive_root((int)logN_);
         const fe hp = fe_mul(h_, fe_pow_u64(wN, rank_));      // offset of that coset: h w_N^c0
-        fe* inv = d_scratch_;                                  // [3][n]
-        fe* inv_scratch = d_scratch_ + 3 * n_;                 // [3 n]
-        fe* p0n = d_scratch_ + 6 * n_;                         // [n]
-        SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, 3, ShardMap{0, 0, 0}));
-        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * n_, c_->d_flag));
+        fe* inv = d_scratch_;                                  // [npts][n]
+        fe* inv_scratch = d_scratch_ + (uint64_t)npts * n_;    // [npts n]
+        fe* p0n = d_scratch_ + 2ull * npts * n_;               // [n]
+        if ((2ull * npts + 1) * n_ > std::max<uint64_t>(Nl_ * 7, 4 * n_)) { sp_set_error("deep: scratch too small for this frame"); return SP_E_ALLOC; }
+        SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
+        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         fe* post = d_scratch_;                                 // [n], the inverses are dead now
@@ -483,10 +492,11 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
     } else {
         // deg H >= 2n (constraint-violating trace, single GPU only): the quotient form on the whole domain
+        if (npts > 3) { sp_set_error("deep: whole-domain fallback supports at most two frame rows"); return SP_E_UNSUPPORTED; }
         fe* inv = d_scratch_;
         fe* inv_scratch = d_scratch_ + 3 * Nl_;
-        SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, 3, shard_map()));
-        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, 3 * Nl_, c_->d_flag));
+        SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));
+        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * Nl_, c_->d_flag));
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0]));
     }
     // FRI layer 0 (reference fri/mod.rs:27-33)

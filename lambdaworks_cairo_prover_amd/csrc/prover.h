@@ -42,6 +42,9 @@ class StarkProver : public sp_deletable {
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
     int open(const std::vector<uint64_t>& iotas, Openings& out);
 
+    // AIRs other than Cairo: frame rows of the transition constraints (reset to {0, 1} by setup)
+    void set_frame_offsets(const std::vector<uint32_t>& ofs) { offsets_ = ofs; }
+    uint32_t frame_rows() const { return (uint32_t)offsets_.size(); }
     uint64_t n() const { return n_; }
     uint64_t N() const { return N_; }
     uint32_t cols() const { return C_; }
@@ -86,6 +89,7 @@ class StarkProver : public sp_deletable {
     fe* d_hfull_ = nullptr; bool h_full_ = false;  // general (degree >= 2n) composition polynomial: N/2 coefficients per half
     fe z_; fe h1_z2_, h2_z2_;
     std::vector<fe> trace_ood_;
+    std::vector<uint32_t> offsets_{0, 1};   // transition offsets of the AIR (frame rows); Cairo: {0, 1}
     int stage_ = 0;  // 0 new, 1 setup, 2 main committed, 3 aux committed, 4 composition, 5 ood, 6 fri running, 7 fri done
 };
 

@@ -52,6 +52,24 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t co
 // constraint vanishes on every row it is enforced on and every boundary value matches.  trace: [C][n] natural order.
 int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev);
 
+// ---- AIRs given as a constraint program (include/stark252_hip.h sp_air_desc; reference trait src/starks/traits.rs:15-119)
+constexpr int AIR_MAX_OPS = 192, AIR_MAX_CONSTS = 48, AIR_MAX_OFFSETS = 4, AIR_MAX_EXEMPT_KINDS = 4, AIR_MAX_TRANSITIONS = 16;
+struct AirOpDev { uint8_t op, pad; uint16_t a, b, pad2; };   // 0 LOAD(row, col) 1 CONST(idx) 2 ADD 3 SUB 4 MUL 5 OUT(constraint, value)
+struct AirProgram {
+    uint32_t n_ops, n_offsets, offsets[AIR_MAX_OFFSETS];
+    uint32_t ex_kind[AIR_MAX_TRANSITIONS];    // per constraint: 0 = enforced on every row, else 1 + index into ex_count
+    uint32_t ex_count[AIR_MAX_EXEMPT_KINDS];  // rows exempted for that kind (the last ex_count rows of the trace)
+    uint32_t ex_rows[AIR_MAX_TRANSITIONS];    // per constraint: its own exemption count (trace check)
+    AirOpDev ops[AIR_MAX_OPS];
+    fe consts[AIR_MAX_CONSTS];                // constants followed by the RAP challenges
+};
+// ConstraintEvaluator::evaluate (evaluator.rs:38-260) for a program AIR; K carries the per-coset coefficients, zerofier and
+// boundary data exactly as for Cairo (its Cairo-only fields are ignored); ex_roots[j] = g^(n-1-j).
+int air_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
+                    const fe* roots_N, const CompositionConsts* consts_dev, const AirProgram* prog_dev, const fe* ex_roots,
+                    const fe* binv, fe* out, uint32_t shard_log = 0, uint32_t shard_rank = 0);
+int air_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, const AirProgram* prog_dev, int* flag_dev);
+
 // Split of the composition polynomial (reference src/starks/prover.rs:250-252, evaluation_table.rs:27-33):
 // X = unscaled bit-reversed size-N inverse transform of the N evaluations; writes the h-scaled bit-reversed coefficient
 // arrays (n each) of H1 (even) and H2 (odd): H1s[q] = X[q*b/2] * t2[q], H2s[q] = X[N/2 + q*b/2] * t2[q] * hinv,
@@ -72,14 +90,14 @@ int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32
 struct DeepConsts {
     fe gamma_h1, gamma_h2;       // gamma, gamma'
     fe c_h;                      // gamma*H1(z^2) + gamma'*H2(z^2)
-    fe c_t[2];                   // sum_j gamma_{j,k} t_j(z g^k)
-    fe gammas[2][64];            // gamma_{j,k}, k = frame row, j = column (<= 61 columns)
-    uint32_t cols;
+    fe c_t[AIR_MAX_OFFSETS];     // sum_j gamma_{j,k} t_j(z g^ofs_k)
+    fe gammas[AIR_MAX_OFFSETS][64];  // gamma_{j,k}, k = frame row, j = column (<= 61 columns)
+    uint32_t cols, rows;         // rows = number of frame rows (transition offsets): 2 for Cairo
 };
 // compute_deep_composition_poly (reference src/starks/prover.rs:410-482) in evaluation form:
-// p0(x) = (sum_j g_j0 t_j(x) - c_t0) / (x - z) + (sum_j g_j1 t_j(x) - c_t1) / (x - z g) + (g H1 + g' H2 - c_h) / (x - z^2);
-// inv: [3][N] = 1/(x - z), 1/(x - z g), 1/(x - z^2).
-// `count` points, point q = element (q << shift) of every column (columns at col_stride); inv = [3][count].
+// p0(x) = sum_k (sum_j g_jk t_j(x) - c_tk) / (x - z g^ofs_k) + (g H1 + g' H2 - c_h) / (x - z^2);
+// inv: [rows + 1][count] = 1/(x - z g^ofs_k) for each frame row, then 1/(x - z^2).
+// `count` points, point q = element (q << shift) of every column (columns at col_stride).
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
                      const DeepConsts* consts_dev, const fe* inv, fe* out);
 

@@ -50,7 +50,7 @@ int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bit
 }
 
 // ---------------------------------------------------------------------------------------------- x_i - point
-struct PointsArgs { fe h; fe pt[4]; };
+struct PointsArgs { fe h; fe pt[AIR_MAX_OFFSETS + 1]; };
 __device__ __forceinline__ uint32_t shard_global_index(uint32_t i_loc, ShardMap m) {
     const uint32_t lb_loc = m.logb - m.shard_log;
     const uint32_t c_loc = i_loc & ((1u << lb_loc) - 1u), q = i_loc >> lb_loc;
@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) coset_minus_points_kernel(fe* den, uint64
     for (uint32_t d = 0; d < ndist; ++d) sk_st(den + (uint64_t)d * N + i, fe_sub(x, a.pt[d]));
 }
 int coset_minus_points(hipStream_t st, fe* den, uint64_t N, uint32_t logN, const fe* roots_N, const fe& h, const fe* points_host, uint32_t ndist, ShardMap sm) {
-    if (ndist > 4) return SP_E_INVALID_ARG;
+    if (ndist > AIR_MAX_OFFSETS + 1) return SP_E_INVALID_ARG;
     PointsArgs a;
     a.h = h;
     for (uint32_t d = 0; d < ndist; ++d) a.pt[d] = points_host[d];
@@ -383,15 +383,21 @@ __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, c
     uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= count) return;
     const uint64_t i = q << shift;
-    fe a0 = fe_zero(), a1 = fe_zero();
-    const uint32_t C = K->cols;
+    const uint32_t C = K->cols, R = K->rows;
+    fe a[AIR_MAX_OFFSETS];
+#pragma unroll
+    for (int k = 0; k < AIR_MAX_OFFSETS; ++k) a[k] = fe_zero();
     for (uint32_t j = 0; j < C; ++j) {
         fe t = sk_ld(lde + (uint64_t)j * col_stride + i);
-        a0 = a0 + K->gammas[0][j] * t;
-        a1 = a1 + K->gammas[1][j] * t;
+#pragma unroll
+        for (int k = 0; k < AIR_MAX_OFFSETS; ++k)
+            if ((uint32_t)k < R) a[k] = a[k] + K->gammas[k][j] * t;
     }
     fe hh = K->gamma_h1 * sk_ld(h1 + i) + K->gamma_h2 * sk_ld(h2 + i) - K->c_h;
-    fe r = (a0 - K->c_t[0]) * sk_ld(inv + q) + (a1 - K->c_t[1]) * sk_ld(inv + count + q) + hh * sk_ld(inv + 2 * count + q);
+    fe r = hh * sk_ld(inv + (uint64_t)R * count + q);
+#pragma unroll
+    for (int k = 0; k < AIR_MAX_OFFSETS; ++k)
+        if ((uint32_t)k < R) r = r + (a[k] - K->c_t[k]) * sk_ld(inv + (uint64_t)k * count + q);
     sk_st(out + q, r);
 }
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
@@ -477,6 +483,91 @@ __global__ void __launch_bounds__(256) interleave_shards_kernel(const uint4* gat
 int interleave_shards(hipStream_t st, const void* gathered, void* out, uint64_t n, ShardMap m) {
     uint64_t N = n << m.logb;
     hipLaunchKernelGGL(interleave_shards_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st, (const uint4*)gathered, (uint4*)out, n, m);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- program AIRs
+// The constraint program runs once per point with its values in a per-thread array (scratch): these AIRs are the small
+// examples of the reference (a handful of ops), throughput is not the point here, identical field elements are.
+template <bool CHECK>
+__global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t col_len, uint32_t stride_log,
+                                                              uint32_t logN, uint32_t logb, const fe* __restrict__ roots,
+                                                              const CompositionConsts* __restrict__ K, const AirProgram* __restrict__ Pg,
+                                                              const fe* __restrict__ ex_roots, const fe* __restrict__ binv,
+                                                              fe* __restrict__ out, int* __restrict__ flag, uint32_t shard_log, uint32_t shard_rank) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t b = 1u << logb, b_loc = b >> shard_log;
+    const ShardMap sm{logb, shard_log, shard_rank};
+    const uint64_t e = CHECK ? i : (i << stride_log);
+    const uint32_t iglob = CHECK ? 0u : shard_global_index((uint32_t)e, sm);
+    const uint32_t c = iglob & (b - 1);
+    const uint32_t T = K->n_transitions, B = K->n_boundary;
+    fe v[AIR_MAX_OPS];
+    fe cons[AIR_MAX_TRANSITIONS];
+    for (uint32_t k = 0; k < T; ++k) cons[k] = fe_zero();
+    const uint32_t n_ops = Pg->n_ops;
+    for (uint32_t t = 0; t < n_ops; ++t) {
+        const AirOpDev o = Pg->ops[t];
+        fe r = fe_zero();
+        switch (o.op) {
+            case 0: {   // frame row = trace row + offset: LDE index + offset * blowup (frame.rs:40-59), same coset
+                const uint64_t row = (e + (uint64_t)Pg->offsets[o.a] * (CHECK ? 1u : b_loc)) & (col_len - 1);
+                r = sk_ld(cols + (uint64_t)o.b * col_len + row);
+                break;
+            }
+            case 1: r = Pg->consts[o.a]; break;
+            case 2: r = v[o.a] + v[o.b]; break;
+            case 3: r = v[o.a] - v[o.b]; break;
+            case 4: r = v[o.a] * v[o.b]; break;
+            default: cons[o.a] = v[o.b]; break;
+        }
+        v[t] = r;
+    }
+    if (CHECK) {
+        bool bad = false;
+        for (uint32_t k = 0; k < T; ++k)
+            if (i + Pg->ex_rows[k] < count && !fe_is_zero(cons[k])) bad = true;   // enforced on rows 0 .. n - 1 - exemptions
+        for (uint32_t j = 0; j < B; ++j)
+            if (i == K->bstep[j] && !fe_eq(sk_ld(cols + (uint64_t)K->bcol[j] * col_len + i), K->bvalue[j])) bad = true;
+        if (bad) atomicOr(flag, 1);
+        return;
+    }
+    const fe x = root_pow(roots, iglob, logN) * K->h;
+    fe exv[AIR_MAX_EXEMPT_KINDS];
+    for (int q = 0; q < AIR_MAX_EXEMPT_KINDS; ++q) {
+        fe p = fe_one();
+        for (uint32_t j = 0; j < Pg->ex_count[q]; ++j) p = p * (x - sk_ld(ex_roots + j));
+        exv[q] = p;
+    }
+    fe acc = fe_zero();
+    for (uint32_t k = 0; k < T; ++k) {
+        fe term = K->coef[c][k] * cons[k];
+        const uint32_t ek = Pg->ex_kind[k];
+        if (ek) term = term * exv[ek - 1];
+        acc = acc + term;
+    }
+    fe total = K->zerofier[c] * acc;
+    for (uint32_t j = 0; j < B; ++j) {
+        fe num = sk_ld(cols + (uint64_t)K->bcol[j] * col_len + e) - K->bvalue[j];
+        total = total + K->coef[c][T + j] * num * sk_ld(binv + (uint64_t)K->bden[j] * count + i);
+    }
+    sk_st(out + i, total);
+}
+
+int air_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
+                    const fe* roots_N, const CompositionConsts* consts_dev, const AirProgram* prog_dev, const fe* ex_roots,
+                    const fe* binv, fe* out, uint32_t shard_log, uint32_t shard_rank) {
+    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(air_composition_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, count, col_len, stride_log,
+                       logN, logb, roots_N, consts_dev, prog_dev, ex_roots, binv, out, (int*)nullptr, shard_log, shard_rank);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int air_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, const AirProgram* prog_dev, int* flag_dev) {
+    hipLaunchKernelGGL(air_composition_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, trace, n, n, 0u, 0u, 0u,
+                       (const fe*)nullptr, consts_dev, prog_dev, (const fe*)nullptr, (const fe*)nullptr, (fe*)nullptr, flag_dev, 0u, 0u);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
