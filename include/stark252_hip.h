@@ -203,6 +203,36 @@ void sp_free(void* p);
 /* Device time (ms, HIP events on the context stream) of rounds 0..4 of the last sp_cairo_prove. */
 int sp_last_round_ms(sp_ctx* ctx, float out[5]);
 
+/* ---- AIRs other than Cairo ------------------------------------------------------------------ */
+
+/* What an implementor of the reference's `AIR` trait provides (src/starks/traits.rs:15-119, context.rs:4-18), with
+ * `compute_transition` as a straight-line program over frame cells:
+ *   op 0 LOAD  a = frame row (index into `offsets`), b = column of main||aux      -> value
+ *   op 1 CONST a = index into consts; indices >= n_consts are the RAP challenges   -> value
+ *   op 2 ADD, 3 SUB, 4 MUL   a, b = indices of earlier ops                          -> value
+ *   op 5 OUT   a = constraint index, b = index of the op holding its value
+ * The reference's examples (src/starks/example/{simple_fibonacci,fibonacci_2_columns,quadratic_air,fibonacci_rap,
+ * dummy_air}.rs) are given in this form by lambdaworks_cairo_prover_amd/air.py. */
+typedef struct { uint8_t op; uint8_t pad; uint16_t a; uint16_t b; uint16_t pad2; } sp_air_op;
+typedef struct { uint32_t col; uint32_t pad; uint64_t step; uint8_t value[32]; /* canonical BE */ } sp_air_boundary;
+typedef struct {
+    uint32_t main_cols, aux_cols;            /* AirContext::trace_columns = main_cols + aux_cols */
+    uint32_t n_offsets; uint32_t offsets[4]; /* transition_offsets */
+    uint32_t n_transitions; uint32_t degrees[16]; uint32_t exemptions[16]; /* transition_degrees / transition_exemptions */
+    uint32_t num_transition_exemptions;      /* AirContext::num_transition_exemptions */
+    uint32_t degree_bound_factor;            /* composition_poly_degree_bound() / trace_length (1 or 2) */
+    uint32_t n_ops; const sp_air_op* ops;
+    uint32_t n_consts; const uint8_t* consts; /* canonical BE */
+    uint32_t n_rap;                          /* build_rap_challenges: this many transcript_to_field samples */
+    uint32_t aux_kind;                       /* build_auxiliary_trace: 0 none, 1 fibonacci_rap permutation column */
+    uint32_t n_boundary; const sp_air_boundary* boundary;
+} sp_air_desc;
+
+/* prove::<Stark252PrimeField, A> (reference src/starks/prover.rs:532-766) + Serializable::serialize for the AIR `air`.
+ * main_trace: row-major n x air->main_cols, context encoding, host memory.  *proof_out is malloc'd (sp_free). */
+int sp_air_prove(sp_ctx* ctx, const sp_air_desc* air, const uint8_t* main_trace, uint64_t n, const sp_proof_options* opt,
+                 uint8_t** proof_out, uint64_t* proof_len);
+
 /* ---- Cairo front-end on the host --------------------------------------------------- */
 
 typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public inputs + main trace */

@@ -134,6 +134,19 @@ class Context:
         self._lib.sp_free(out)
         return proof
 
+    def air_prove(self, desc, main_trace, options):
+        """sp_air_prove: desc = lambdaworks_cairo_prover_amd.air.AirDescC (AirBuilder.build()[0]); main_trace (n, cols, 32)."""
+        a = np.ascontiguousarray(main_trace, dtype=np.uint8)
+        n, cols = a.shape[0], a.shape[1]
+        assert cols == desc.main_cols
+        opt = options.to_c()
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_uint64()
+        check(self._lib.sp_air_prove(self._h, ctypes.byref(desc), _u8p(a), ctypes.c_uint64(n), ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln)))
+        proof = ctypes.string_at(out, ln.value)
+        self._lib.sp_free(out)
+        return proof
+
     def last_round_ms(self):
         ms = (ctypes.c_float * 5)()
         check(self._lib.sp_last_round_ms(self._h, ms))

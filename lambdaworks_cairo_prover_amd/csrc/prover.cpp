@@ -1,6 +1,7 @@
 // Round-by-round STARK prover on the device (see prover.h). Host code only: it sequences kernels on the context
 // stream, keeps every polynomial / evaluation / tree resident in HBM and moves only roots, challenges and openings.
 #include "prover.h"
+#include <array>
 #include "keccak.h"
 #include <algorithm>
 #include <cstring>
@@ -57,6 +58,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     }
     free_all();
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; h_full_ = false;
+    d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
     world_ = (uint32_t)c_->world; rank_ = (uint32_t)c_->rank; logG_ = (uint32_t)sp_log2_exact(world_); Nl_ = N_ >> logG_;
@@ -71,7 +73,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
     SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
     SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * Nl_ * 2));
-    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * std::max<uint64_t>(Nl_ * 7, 4 * n_)));
+    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * scratch_elems()));
     d_local_ = nullptr; d_gather_ = nullptr;
     if (world_ > 1) {
         SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
@@ -231,9 +233,6 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     if (steps.size() > 3) { sp_set_error("composition: more than 3 distinct boundary steps"); return SP_E_UNSUPPORTED; }
     std::vector<fe> points;
     for (uint64_t s : steps) points.push_back(fe_pow_u64(g_, s));
-    fe* comp = d_fri_evals_[0];              // [N] full composition evaluations (the FRI layer-0 buffer is free until round 4)
-    fe* comp_local = world_ == 1 ? comp : d_local_;
-    const uint32_t nd = (uint32_t)points.size();
     // --- per-coset constants: x^n takes b values h^n w_b^c (reference evaluator.rs:156-171)
     K.h = h_;
     K.rap[0] = rap[0]; K.rap[1] = rap[1]; K.rap[2] = rap[2];
@@ -273,6 +272,132 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
             return SP_E_UNSUPPORTED;
         }
     }
+    return composition_core(K, points, nullptr, nullptr, true, root_out);
+}
+
+int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& rap, const std::vector<fe>& b_alpha, const std::vector<fe>& b_beta,
+                                 const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta, uint8_t root_out[32]) {
+    if (stage_ != 3 && !(stage_ == 2 && Ca_ == 0)) { sp_set_error("composition: trace segments not committed"); return SP_E_STATE; }
+    const uint32_t T = (uint32_t)air.degrees.size(), B = (uint32_t)air.boundary.size(), R = (uint32_t)air.offsets.size();
+    if (T == 0 || T > AIR_MAX_TRANSITIONS || B > CAIRO_MAX_BOUNDARY || R == 0 || R > AIR_MAX_OFFSETS || air.exemptions.size() != T ||
+        t_alpha.size() != T || t_beta.size() != T || b_alpha.size() != B || b_beta.size() != B || air.ops.size() > AIR_MAX_OPS ||
+        air.consts.size() + rap.size() > AIR_MAX_CONSTS || rap.size() != air.n_rap || air.main_cols != Cm_ || air.aux_cols != Ca_ ||
+        air.degree_bound_factor < 1) {
+        sp_set_error("composition_air: descriptor out of range or inconsistent with the committed trace");
+        return SP_E_INVALID_ARG;
+    }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const uint32_t b = 1u << logb_, f = air.degree_bound_factor;
+    // --- validate the program (every operand refers to an earlier value, cells exist) and build the device copy
+    AirProgram prog;
+    std::memset(&prog, 0, sizeof(prog));
+    prog.n_ops = (uint32_t)air.ops.size();
+    prog.n_offsets = R;
+    for (uint32_t k = 0; k < R; ++k) prog.offsets[k] = air.offsets[k];
+    std::vector<bool> produced(T, false);
+    for (uint32_t t = 0; t < prog.n_ops; ++t) {
+        const AirOpDev& o = air.ops[t];
+        bool ok = true;
+        switch (o.op) {
+            case 0: ok = o.a < R && o.b < C_; break;
+            case 1: ok = o.a < air.consts.size() + rap.size(); break;
+            case 2: case 3: case 4: ok = o.a < t && o.b < t && air.ops[o.a].op != 5 && air.ops[o.b].op != 5; break;
+            case 5: ok = o.a < T && o.b < t && air.ops[o.b].op != 5; if (ok) produced[o.a] = true; break;
+            default: ok = false;
+        }
+        if (!ok) { sp_set_error("composition_air: malformed constraint program"); return SP_E_INVALID_ARG; }
+        prog.ops[t] = o;
+    }
+    for (uint32_t k = 0; k < T; ++k) if (!produced[k]) { sp_set_error("composition_air: a constraint has no OUT op"); return SP_E_INVALID_ARG; }
+    for (size_t i = 0; i < air.consts.size(); ++i) prog.consts[i] = air.consts[i];
+    for (size_t i = 0; i < rap.size(); ++i) prog.consts[air.consts.size() + i] = rap[i];
+    // --- transition exemptions (traits.rs:49-79, evaluator.rs:299-323): distinct non-zero counts; with
+    //     num_transition_exemptions == 1 every exempted constraint uses the first of them
+    std::vector<uint32_t> uniq;
+    for (uint32_t e : air.exemptions) if (e > 0 && std::find(uniq.begin(), uniq.end(), e) == uniq.end()) uniq.push_back(e);
+    if (uniq.size() > AIR_MAX_EXEMPT_KINDS) { sp_set_error("composition_air: too many distinct exemption counts"); return SP_E_UNSUPPORTED; }
+    uint32_t max_ex = 0;
+    for (size_t q = 0; q < uniq.size(); ++q) { prog.ex_count[q] = uniq[q]; max_ex = std::max(max_ex, uniq[q]); }
+    if (max_ex >= n_) { sp_set_error("composition_air: exemptions exceed the trace length"); return SP_E_INVALID_ARG; }
+    uint64_t deg_bound = 0;   // of H for a constraint-satisfying trace
+    for (uint32_t k = 0; k < T; ++k) {
+        const uint32_t e = air.exemptions[k], d = air.degrees[k];
+        if (d < 1 || d > f + 1) { sp_set_error("composition_air: transition degree above the composition degree bound"); return SP_E_INVALID_ARG; }
+        if (e) {
+            size_t idx = air.num_transition_exemptions == 1 ? 0 : (size_t)(std::find(uniq.begin(), uniq.end(), e) - uniq.begin());
+            prog.ex_kind[k] = 1 + (uint32_t)idx;
+        }
+        // deg C_k <= d (n - 1); times x^(n (f - d + 1)); times the exemption product; over x^n - 1
+        const uint32_t ex_used = prog.ex_kind[k] ? prog.ex_count[prog.ex_kind[k] - 1] : 0;
+        prog.ex_rows[k] = ex_used;   // rows the composition really exempts for this constraint (what the trace check must mirror)
+        deg_bound = std::max<uint64_t>(deg_bound, (uint64_t)d * (n_ - 1) + n_ * (f - d + 1) + ex_used - n_ + 1);
+    }
+    deg_bound = std::max<uint64_t>(deg_bound, (n_ - 1) + n_ * (f - 1));   // boundary terms
+    const bool allow_sub = deg_bound <= 2 * n_;                            // deg H < 2n: 2n evaluations fix it
+    if (max_ex > ex_roots_cap_) {
+        SP_TRY(alloc((void**)&d_ex_roots_, sizeof(fe) * std::max<uint32_t>(max_ex, 64)));
+        ex_roots_cap_ = std::max<uint32_t>(max_ex, 64);
+    }
+    if (!d_air_prog_) SP_TRY(alloc((void**)&d_air_prog_, sizeof(AirProgram)));
+    if (max_ex) {
+        std::vector<fe> er(max_ex);
+        for (uint32_t j = 0; j < max_ex; ++j) er[j] = fe_pow_u64(g_, n_ - 1 - j);
+        SP_HIP_CHECK(hipMemcpyAsync(d_ex_roots_, er.data(), sizeof(fe) * max_ex, hipMemcpyHostToDevice, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    }
+    SP_HIP_CHECK(hipMemcpyAsync(d_air_prog_, &prog, sizeof(prog), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // prog is a stack object
+    // --- boundary data and per-coset constants
+    std::vector<uint64_t> steps;
+    CompositionConsts K;
+    std::memset(&K, 0, sizeof(K));
+    for (uint32_t j = 0; j < B; ++j) {
+        const BoundaryConstraint& bc = air.boundary[j];
+        if (bc.col >= C_ || bc.step >= n_) return SP_E_INVALID_ARG;
+        auto it = std::find(steps.begin(), steps.end(), bc.step);
+        if (it == steps.end()) { steps.push_back(bc.step); it = steps.end() - 1; }
+        K.bden[j] = (uint32_t)(it - steps.begin());
+        K.bcol[j] = bc.col; K.bvalue[j] = bc.value; K.bstep[j] = bc.step;
+    }
+    if (steps.size() > 3) { sp_set_error("composition: more than 3 distinct boundary steps"); return SP_E_UNSUPPORTED; }
+    std::vector<fe> points;
+    for (uint64_t st : steps) points.push_back(fe_pow_u64(g_, st));
+    K.h = h_;
+    K.n_boundary = B; K.n_transitions = T; K.main_cols = Cm_;
+    {
+        fe hn = fe_pow_u64(h_, n_);
+        fe wb = host_primitive_root((int)logb_);
+        std::vector<fe> zf(b);
+        fe xn = hn;
+        for (uint32_t c = 0; c < b; ++c) {
+            // degree adjustments x^(D - n (deg - 1)) and x^(D - n) with D = f n are powers of x^n (evaluator.rs:142-154, :78-82)
+            for (uint32_t k = 0; k < T; ++k) K.coef[c][k] = fe_add(fe_mul(t_alpha[k], fe_pow_u64(xn, f - air.degrees[k] + 1)), t_beta[k]);
+            for (uint32_t j = 0; j < B; ++j) K.coef[c][T + j] = fe_add(fe_mul(b_alpha[j], fe_pow_u64(xn, f - 1)), b_beta[j]);
+            zf[c] = fe_sub(xn, fe_one());
+            xn = fe_mul(xn, wb);
+        }
+        host_batch_inverse(zf);
+        for (uint32_t c = 0; c < b; ++c) K.zerofier[c] = zf[c];
+    }
+    offsets_ = air.offsets;
+    return composition_core(K, points, d_air_prog_, d_ex_roots_, allow_sub, root_out);
+}
+
+// Shared second half of round 2: K (per-coset coefficients, zerofier, boundary data) is complete; `points` are the distinct
+// boundary points g^step.  prog_dev == nullptr: the Cairo kernels; otherwise the constraint program of a generic AIR.
+// allow_sub_coset: the caller knows deg H < 2n for a constraint-satisfying trace.
+int StarkProver::composition_core(const CompositionConsts& K, const std::vector<fe>& points, const AirProgram* prog_dev,
+                                  const fe* ex_roots_dev, bool allow_sub_coset, uint8_t root_out[32]) {
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    fe* comp = d_fri_evals_[0];              // [N] full composition evaluations (the FRI layer-0 buffer is free until round 4)
+    fe* comp_local = world_ == 1 ? comp : d_local_;
+    const uint32_t nd = (uint32_t)points.size();
+    auto evaluate = [&](uint64_t count, uint32_t stride_log, const fe* binv, fe* out) -> int {
+        if (prog_dev) return air_composition(c_->stream, d_lde_, count, Nl_, stride_log, logN_, logb_, roots, d_comp_consts_, prog_dev, ex_roots_dev, binv, out, logG_, rank_);
+        return cairo_composition(c_->stream, d_lde_, count, Nl_, stride_log, logN_, logb_, roots, d_comp_consts_, binv, out, logG_, rank_);
+    };
+    SP_HIP_CHECK(hipSetDevice(c_->device));
     SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     // A trace that satisfies its constraints gives deg H < 2n, and then 2n evaluations fix H.  Decide that EXACTLY by
@@ -280,9 +405,10 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     // points of the cosets 0 and b/2 only; otherwise (the reference still proves such traces, with longer H1/H2) fall
     // back to the whole domain and the general split, so the bytes are identical for every input.
     int flag = 0;
-    bool sub_coset = logb_ >= logG_ + 1;  // this rank holds both cosets c0 = rank and c0 + b/2 (always on one GPU)
+    bool sub_coset = allow_sub_coset && logb_ >= logG_ + 1;  // this rank holds both cosets c0 = rank and c0 + b/2 (always on one GPU)
     if (sub_coset) {
-        SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
+        if (prog_dev) SP_TRY(air_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, prog_dev, c_->d_flag));
+        else SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // (also: K is a stack object)
         sub_coset = flag == 0;
@@ -306,7 +432,7 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * M, c_->d_flag));
         }
         fe* comp2 = d_h12s_;                      // [2n] evaluations H(h w_2n^i), then [H1s | H2s]
-        SP_TRY(cairo_composition(c_->stream, d_lde_, M, Nl_, logb_ - logG_ - 1, logN_, logb_, roots, d_comp_consts_, binv, comp2, logG_, rank_));
+        SP_TRY(evaluate(M, logb_ - logG_ - 1, binv, comp2));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         // interpolate_offset_fft + even/odd split in one inverse transform: position q < n of the bit-reversed output is
         // 2n c_j hp^j for j = 2k, position n + q for j = 2k + 1 (k = rev_n(q)); the post factors leave a_k h^k = c_2k h^k
@@ -328,7 +454,7 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
             SP_TRY(coset_minus_points(c_->stream, binv, Nl_, logN_, roots, h_, points.data(), nd, shard_map()));
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
         }
-        SP_TRY(cairo_composition(c_->stream, d_lde_, Nl_, Nl_, 0, logN_, logb_, roots, d_comp_consts_, binv, comp_local, logG_, rank_));
+        SP_TRY(evaluate(Nl_, 0, binv, comp_local));
         if (world_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
             SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
             SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
@@ -427,14 +553,14 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     std::vector<fe> ys;
     for (uint32_t k = 0; k < R; ++k) ys.push_back(fe_mul(fe_mul(z, fe_pow_u64(g_, offsets_[k])), hinv_));
     std::vector<fe> tr;
-    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), tr));
+    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, scratch_elems(), tr));
     trace_ood.resize((size_t)R * C_);
     for (uint32_t j = 0; j < C_; ++j)
         for (uint32_t k = 0; k < R; ++k) trace_ood[(size_t)k * C_ + j] = tr[(size_t)j * R + k];
     std::vector<fe> yh = {fe_mul(fe_sqr(z), hinv_)};
     std::vector<fe> hv;
-    if (!h_full_) SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
-    else SP_TRY(eval_bitrev(c_, d_hfull_, N_ >> 1, 2, logN_ - 1, yh, d_scratch_, std::max<uint64_t>(7 * Nl_, 4 * n_), hv));
+    if (!h_full_) SP_TRY(eval_bitrev(c_, d_h12s_, n_, 2, logn_, yh, d_scratch_, scratch_elems(), hv));
+    else SP_TRY(eval_bitrev(c_, d_hfull_, N_ >> 1, 2, logN_ - 1, yh, d_scratch_, scratch_elems(), hv));
     h1_z2_ = hv[0]; h2_z2_ = hv[1];
     *h1_z2 = hv[0]; *h2_z2 = hv[1];
     trace_ood_ = trace_ood;
@@ -481,7 +607,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         fe* inv = d_scratch_;                                  // [npts][n]
         fe* inv_scratch = d_scratch_ + (uint64_t)npts * n_;    // [npts n]
         fe* p0n = d_scratch_ + 2ull * npts * n_;               // [n]
-        if ((2ull * npts + 1) * n_ > std::max<uint64_t>(Nl_ * 7, 4 * n_)) { sp_set_error("deep: scratch too small for this frame"); return SP_E_ALLOC; }
+        if ((2ull * npts + 1) * n_ > scratch_elems()) { sp_set_error("deep: scratch too small for this frame"); return SP_E_ALLOC; }
         SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n));
@@ -492,9 +618,13 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
     } else {
         // deg H >= 2n (constraint-violating trace, single GPU only): the quotient form on the whole domain
-        if (npts > 3) { sp_set_error("deep: whole-domain fallback supports at most two frame rows"); return SP_E_UNSUPPORTED; }
         fe* inv = d_scratch_;
-        fe* inv_scratch = d_scratch_ + 3 * Nl_;
+        if (2ull * npts * Nl_ > scratch_elems()) {   // more than two frame rows: the inverses outgrow the shared scratch
+            void* big = nullptr;
+            SP_TRY(alloc(&big, sizeof(fe) * 2ull * npts * Nl_));   // stays until the next reshaping setup()
+            inv = static_cast<fe*>(big);
+        }
+        fe* inv_scratch = inv + (uint64_t)npts * Nl_;
         SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * Nl_, c_->d_flag));
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0]));
@@ -712,6 +842,64 @@ bool z_in_domains(const fe& z, const fe& hinv, uint32_t logn, uint32_t logN) {  
 
 }  // namespace
 
+// StarkProof serialization (reference proof/stark.rs:161-218, fri/fri_decommit.rs:24-45, frame.rs:86-106).
+// roots: the trace-segment roots (one or two); ood: frame rows x C evaluations.
+static void serialize_proof(uint64_t n, const std::vector<std::array<uint8_t, 32>>& roots, uint32_t C, const std::vector<fe>& ood,
+                            const uint8_t comp_root[32], const fe& h1z, const fe& h2z, const std::vector<std::vector<uint8_t>>& fri_roots,
+                            const fe& last_value, const std::vector<uint64_t>& iotas, const Openings& o, uint64_t nonce,
+                            std::vector<uint8_t>& proof_out) {
+    const uint32_t L = o.n_layers, d0 = o.depth0;
+    ProofWriter w;
+    w.u64(n);
+    w.u64(roots.size());
+    for (auto& r : roots) w.raw(r.data(), 32);
+    {
+        ProofWriter f;
+        f.u64(ood.size()); f.u64(32);
+        for (auto& e : ood) f.felt(e);
+        f.u64(C);
+        w.u64(f.b.size()); w.bytes(f.b);
+    }
+    w.raw(comp_root, 32);
+    w.u64(32); w.felt(h1z); w.felt(h2z);
+    w.u64(fri_roots.size());
+    for (auto& r : fri_roots) w.raw(r.data(), 32);
+    w.felt(last_value);
+    size_t path_total = 0;
+    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
+    w.u64(iotas.size());
+    for (size_t s = 0; s < iotas.size(); ++s) {
+        ProofWriter qw;
+        qw.u64(L);
+        size_t po = 0;
+        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
+        qw.u64(32);
+        qw.u64(L);
+        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals_sym[s * L + k]);
+        qw.u64(L);
+        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals[s * L + k]);
+        qw.u64(L);
+        po = 0;
+        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
+        w.u64(qw.b.size()); w.bytes(qw.b);
+    }
+    w.u64(iotas.size());
+    for (size_t s = 0; s < iotas.size(); ++s) {
+        ProofWriter ow;
+        ow.path(&o.comp_paths[s * d0], d0);
+        ow.u64(32);
+        ow.felt(o.comp_evals[s * 2]); ow.felt(o.comp_evals[s * 2 + 1]);
+        ow.u64(roots.size());
+        ow.path(&o.main_paths[s * d0], d0);
+        if (roots.size() > 1) ow.path(&o.aux_paths[s * d0], d0);
+        ow.u64(C);
+        for (uint32_t j = 0; j < C; ++j) ow.felt(o.trace_evals[s * C + j]);
+        w.u64(ow.b.size()); w.bytes(ow.b);
+    }
+    w.u64(nonce);
+    proof_out.swap(w.b);
+}
+
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
                 const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device) {
     try {
@@ -808,59 +996,122 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             for (int r = 0; r < 4; ++r) SP_HIP_CHECK(hipEventElapsedTime(&round_ms[r + 1], ev[r], ev[r + 1]));
         }
         for (auto& e : ev) (void)hipEventDestroy(e);
-        // ---- serialization (reference proof/stark.rs:161-218, fri/fri_decommit.rs:24-45, frame.rs:86-106)
-        const uint32_t C = P->cols(), L = o.n_layers, d0 = o.depth0;
-        ProofWriter w;
-        w.u64(n);
-        w.u64(2); w.raw(main_root, 32); w.raw(aux_root, 32);
-        {
-            ProofWriter f;
-            f.u64(ood.size()); f.u64(32);
-            for (auto& e : ood) f.felt(e);
-            f.u64(C);
-            w.u64(f.b.size()); w.bytes(f.b);
-        }
-        w.raw(comp_root, 32);
-        w.u64(32); w.felt(h1z); w.felt(h2z);
-        w.u64(fri_roots.size());
-        for (auto& r : fri_roots) w.raw(r.data(), 32);
-        w.felt(last_value);
-        size_t path_total = 0;
-        for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
-        w.u64(iotas.size());
-        for (size_t s = 0; s < iotas.size(); ++s) {
-            ProofWriter qw;
-            qw.u64(L);
-            size_t po = 0;
-            for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
-            qw.u64(32);
-            qw.u64(L);
-            for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals_sym[s * L + k]);
-            qw.u64(L);
-            for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals[s * L + k]);
-            qw.u64(L);
-            po = 0;
-            for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
-            w.u64(qw.b.size()); w.bytes(qw.b);
-        }
-        w.u64(iotas.size());
-        for (size_t s = 0; s < iotas.size(); ++s) {
-            ProofWriter ow;
-            ow.path(&o.comp_paths[s * d0], d0);
-            ow.u64(32);
-            ow.felt(o.comp_evals[s * 2]); ow.felt(o.comp_evals[s * 2 + 1]);
-            ow.u64(2);
-            ow.path(&o.main_paths[s * d0], d0);
-            ow.path(&o.aux_paths[s * d0], d0);
-            ow.u64(C);
-            for (uint32_t j = 0; j < C; ++j) ow.felt(o.trace_evals[s * C + j]);
-            w.u64(ow.b.size()); w.bytes(ow.b);
-        }
-        w.u64(nonce);
-        proof_out.swap(w.b);
+        std::vector<std::array<uint8_t, 32>> roots(2);
+        std::memcpy(roots[0].data(), main_root, 32); std::memcpy(roots[1].data(), aux_root, 32);
+        serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
         return SP_OK;
     } catch (const std::exception& e) {
         sp_set_error(std::string("cairo_prove: ") + e.what());
+        return SP_E_INVALID_ARG;
+    }
+}
+
+// prove::<F, A> for a program AIR (reference src/starks/prover.rs:532-766): same rounds, the AIR-specific parts come from
+// the descriptor - RAP challenges (n_rap field samples), auxiliary trace (by kind, built on the host: the example AIRs are
+// tiny), boundary constraints, transition program.
+int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, uint64_t n, const ProofOptionsHost& opt,
+              std::vector<uint8_t>& proof_out) {
+    try {
+        if (air.main_cols == 0 || air.main_cols + air.aux_cols > 64) { sp_set_error("air_prove: column count out of range"); return SP_E_INVALID_ARG; }
+        StarkProver* P = dynamic_cast<StarkProver*>(ctx->prover_state_deleter_holder);
+        if (!P) {
+            P = new StarkProver(ctx);
+            delete ctx->prover_state_deleter_holder;
+            ctx->prover_state_deleter_holder = P;
+        }
+        SP_TRY(P->setup(n, air.main_cols, air.aux_cols, false, opt));
+        HostTranscript tr;
+        uint8_t root[32];
+        std::vector<std::array<uint8_t, 32>> roots;
+        // ---- round 1 (reference prover.rs:187-224)
+        SP_TRY(P->commit_trace(0, main_trace, air.main_cols, root, false));
+        roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
+        tr.append(root, 32);
+        std::vector<fe> rap(air.n_rap);
+        for (auto& x : rap) x = tr.to_field();
+        if (air.aux_cols) {
+            if (air.aux_kind != 1 || air.aux_cols != 1 || air.main_cols < 2 || air.n_rap < 1) {
+                sp_set_error("air_prove: unknown auxiliary-trace kind (1 = fibonacci_rap permutation column)");
+                return SP_E_UNSUPPORTED;
+            }
+            // fibonacci_rap.rs:69-93: z_0 = 1, z_i = z_(i-1) (a_(i-1) + gamma) / (b_(i-1) + gamma)
+            std::vector<fe> den(n), num(n);
+            for (uint64_t i = 0; i < n; ++i) {
+                fe a, b;
+                const uint8_t* row = main_trace + (size_t)i * air.main_cols * 32;
+                if (ctx->enc == SP_FE_CANON_BE) { a = fe_from_bytes_be(row); b = fe_from_bytes_be(row + 32); }
+                else { uint64_t l[4]; std::memcpy(l, row, 32); a = fe_from_lw_limbs(l); std::memcpy(l, row + 32, 32); b = fe_from_lw_limbs(l); }
+                num[i] = fe_add(a, rap[0]); den[i] = fe_add(b, rap[0]);
+            }
+            for (auto& d : den) if (fe_is_zero(d)) { sp_set_error("air_prove: zero denominator in the permutation column"); return SP_E_ZERO_INVERSE; }
+            host_batch_inverse(den);
+            std::vector<uint8_t> aux_rows((size_t)n * 32);
+            fe zacc = fe_one();
+            for (uint64_t i = 0; i < n; ++i) {
+                if (i > 0) zacc = fe_mul(zacc, fe_mul(num[i - 1], den[i - 1]));
+                if (ctx->enc == SP_FE_CANON_BE) fe_to_bytes_be(zacc, &aux_rows[(size_t)i * 32]);
+                else { uint64_t l[4]; fe_to_lw_limbs(zacc, l); std::memcpy(&aux_rows[(size_t)i * 32], l, 32); }
+            }
+            SP_TRY(P->commit_trace(1, aux_rows.data(), 1, root, false));
+            roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
+            tr.append(root, 32);
+        }
+        // ---- round 2 (reference prover.rs:597-635)
+        const size_t B = air.boundary.size(), T = air.degrees.size();
+        std::vector<fe> b_alpha(B), b_beta(B), t_alpha(T), t_beta(T);
+        for (auto& x : b_alpha) x = tr.to_field();
+        for (auto& x : b_beta) x = tr.to_field();
+        for (auto& x : t_alpha) x = tr.to_field();
+        for (auto& x : t_beta) x = tr.to_field();
+        SP_TRY(P->composition_air(air, rap, b_alpha, b_beta, t_alpha, t_beta, root));
+        uint8_t comp_root[32]; std::memcpy(comp_root, root, 32);
+        tr.append(root, 32);
+        // ---- round 3 (reference prover.rs:652-684)
+        const uint32_t logn = (uint32_t)sp_log2_exact(n), logN = logn + (uint32_t)sp_log2_exact(opt.blowup_factor);
+        fe hinv = fe_inv(fe_from_u64(opt.coset_offset));
+        fe z;
+        do { z = tr.to_field(); } while (z_in_domains(z, hinv, logn, logN));
+        fe h1z, h2z;
+        std::vector<fe> ood;
+        SP_TRY(P->ood(z, &h1z, &h2z, ood));
+        tr.append_felt(h1z); tr.append_felt(h2z);
+        for (auto& e : ood) tr.append_felt(e);
+        // ---- round 4 (reference prover.rs:327-404)
+        fe gamma = tr.to_field(), gamma_p = tr.to_field();
+        std::vector<fe> tg((size_t)P->frame_rows() * P->cols());
+        for (auto& x : tg) x = tr.to_field();
+        SP_TRY(P->deep_fri_begin(gamma, gamma_p, tg, root));
+        std::vector<std::vector<uint8_t>> fri_roots;
+        fri_roots.emplace_back(root, root + 32);
+        tr.append(root, 32);
+        fe last_value;
+        for (;;) {
+            fe zeta = tr.to_field();
+            int is_last = 0;
+            SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
+            if (is_last) break;
+            fri_roots.emplace_back(root, root + 32);
+            tr.append(root, 32);
+        }
+        tr.append_felt(last_value);
+        uint8_t gch[32];
+        tr.challenge(gch);
+        uint64_t nonce = 0;
+        SP_TRY(P->grind(gch, opt.grinding_factor, &nonce));
+        {
+            uint8_t nb[8];
+            for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
+            tr.append(nb, 8);
+        }
+        std::vector<uint64_t> iotas(opt.fri_number_of_queries);
+        for (auto& x : iotas) x = tr.to_usize() % P->N();
+        Openings o;
+        SP_TRY(P->open(iotas, o));
+        SP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
+        return SP_OK;
+    } catch (const std::exception& e) {
+        sp_set_error(std::string("air_prove: ") + e.what());
         return SP_E_INVALID_ARG;
     }
 }

@@ -6,10 +6,22 @@
 #include "cairo_air_host.h"
 #include "aux_kernels.h"
 #include <vector>
+#include <algorithm>
 
 namespace sp {
 
 struct ProofOptionsHost { uint8_t blowup_factor; uint64_t fri_number_of_queries; uint64_t coset_offset; uint8_t grinding_factor; };
+
+// Host form of sp_air_desc (include/stark252_hip.h).
+struct AirDescHost {
+    uint32_t main_cols = 0, aux_cols = 0;
+    std::vector<uint32_t> offsets, degrees, exemptions;
+    uint32_t num_transition_exemptions = 1, degree_bound_factor = 1;
+    std::vector<AirOpDev> ops;
+    std::vector<fe> consts;
+    uint32_t n_rap = 0, aux_kind = 0;
+    std::vector<BoundaryConstraint> boundary;
+};
 
 struct Openings {
     uint32_t n_queries = 0, n_layers = 0, n_cols = 0, depth0 = 0;
@@ -34,7 +46,11 @@ class StarkProver : public sp_deletable {
     int composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
                     const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
                     const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint8_t root_out[32]);
-    // round 3: H1(z^2), H2(z^2), t_j(z g^k) for k = 0,1 (row-major [k][j])
+    // round 2 for an AIR given as a constraint program (reference traits.rs:15-119 + evaluator.rs:38-260); rap = its RAP
+    // challenges (appended to the program's constants); also sets the frame offsets used by rounds 3 and 4.
+    int composition_air(const AirDescHost& air, const std::vector<fe>& rap, const std::vector<fe>& b_alpha, const std::vector<fe>& b_beta,
+                        const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta, uint8_t root_out[32]);
+    // round 3: H1(z^2), H2(z^2), t_j(z g^ofs_k) for every frame row k (row-major [k][j])
     int ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_ood);
     // round 4
     int deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::vector<fe>& trace_gammas /*[j*2+k]*/, uint8_t root0_out[32]);
@@ -57,6 +73,11 @@ class StarkProver : public sp_deletable {
     int alloc(void** p, size_t bytes);
     int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]);
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
+    // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
+    // per-level power tables of up to five points, which dominate for tiny traces)
+    uint64_t scratch_elems() const { return std::max<uint64_t>(std::max<uint64_t>(Nl_ * 7, 4 * n_), 8192); }
+    int composition_core(const CompositionConsts& K, const std::vector<fe>& points, const AirProgram* prog_dev, const fe* ex_roots_dev,
+                         bool allow_sub_coset, uint8_t root_out[32]);
 
     sp_ctx* c_;
     ProofOptionsHost opt_{};
@@ -80,6 +101,7 @@ class StarkProver : public sp_deletable {
     uint32_t fri_layer_ = 0;                // number of committed layers so far
     fe fri_offset_;                         // h^(2^layer)
     CompositionConsts* d_comp_consts_ = nullptr;
+    AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
     uint64_t* d_positions_ = nullptr;
@@ -97,5 +119,9 @@ class StarkProver : public sp_deletable {
 // (src/starks/proof/stark.rs:161-218). main_trace: row-major n x cols in the context encoding.
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
                 const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device = false);
+// Whole proof for an AIR given as a constraint program: `prove::<F, A>` (reference src/starks/prover.rs:532-766) + serialize.
+// main_trace: row-major n x air.main_cols in the context encoding (host memory).
+int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, uint64_t n, const ProofOptionsHost& opt,
+              std::vector<uint8_t>& proof_out);
 
 }  // namespace sp
