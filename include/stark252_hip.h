@@ -233,6 +233,10 @@ typedef struct {
 int sp_air_prove(sp_ctx* ctx, const sp_air_desc* air, const uint8_t* main_trace, uint64_t n, const sp_proof_options* opt,
                  uint8_t** proof_out, uint64_t* proof_len);
 
+/* verify::<Stark252PrimeField, A> (reference src/starks/verifier.rs:559-657) on the host CPU: 1 accept, 0 reject (also for
+ * malformed proofs or descriptors). */
+int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* air, const sp_proof_options* opt);
+
 /* ---- Cairo front-end on the host --------------------------------------------------- */
 
 typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public inputs + main trace */

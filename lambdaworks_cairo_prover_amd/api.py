@@ -258,6 +258,13 @@ def cairo_verify(proof, public_inputs_c, options):
     return lib.sp_cairo_verify(proof, ctypes.c_uint64(len(proof)), ctypes.byref(public_inputs_c), ctypes.byref(opt)) == 1
 
 
+def air_verify(proof, desc, options):
+    """sp_air_verify: the library's CPU verifier for an AIR given as a constraint program."""
+    lib = _lib.load()
+    opt = options.to_c()
+    return lib.sp_air_verify(proof, ctypes.c_uint64(len(proof)), ctypes.byref(desc), ctypes.byref(opt)) == 1
+
+
 def proof_file_bytes(proof, run):
     """u64_be(len) || proof || PublicInputs, the file format of the reference CLI (src/main.rs:98-102)."""
     lib = _lib.load()

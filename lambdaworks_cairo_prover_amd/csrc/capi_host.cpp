@@ -1,6 +1,8 @@
 // C ABI: host-only entry points (Cairo front-end, encoding helpers). See include/stark252_hip.h.
 #include "../../include/stark252_hip.h"
 #include "cairo_host.h"
+#include "cairo_air_host.h"
+#include <array>
 #include "common.h"
 #include <cstring>
 #include <cstdlib>
@@ -21,6 +23,12 @@ struct sp_cairo_run {
 
 static thread_local std::string g_last_error;
 void sp_set_error(const std::string& s) { g_last_error = s; }
+namespace sp {
+int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, uint32_t aux_cols, const std::vector<uint32_t>& offsets,
+                    const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint32_t bound_factor,
+                    const std::vector<std::array<uint16_t, 3>>& ops, const std::vector<fe>& consts, uint32_t n_rap,
+                    const std::vector<BoundaryConstraint>& boundary, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding);
+}
 namespace sp { int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding); }
 
 extern "C" {
@@ -146,6 +154,26 @@ int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_pub
         }
         r.num_steps = p->num_steps;
         return sp::cairo_verify_host(proof, proof_len, r, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
+}
+
+// verify::<Stark252PrimeField, A> (reference src/starks/verifier.rs:559-657) for a program AIR: 1 = accept, 0 = reject
+// (also for malformed proofs or descriptors).
+int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d, const sp_proof_options* opt) {
+    if (!proof || !d || !opt) return SP_E_INVALID_ARG;
+    try {
+        if (d->n_offsets == 0 || d->n_offsets > 4 || d->n_transitions == 0 || d->n_transitions > 16 || (d->n_ops && !d->ops) ||
+            (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) return 0;
+        std::vector<uint32_t> offsets(d->offsets, d->offsets + d->n_offsets), degrees(d->degrees, d->degrees + d->n_transitions),
+            exemptions(d->exemptions, d->exemptions + d->n_transitions);
+        std::vector<std::array<uint16_t, 3>> ops;
+        for (uint32_t i = 0; i < d->n_ops; ++i) ops.push_back({d->ops[i].op, d->ops[i].a, d->ops[i].b});
+        std::vector<fe> consts;
+        for (uint32_t i = 0; i < d->n_consts; ++i) consts.push_back(fe_from_bytes_be(d->consts + 32 * (size_t)i));
+        std::vector<sp::BoundaryConstraint> bcs;
+        for (uint32_t i = 0; i < d->n_boundary; ++i) bcs.push_back(sp::BoundaryConstraint{d->boundary[i].col, d->boundary[i].step, fe_from_bytes_be(d->boundary[i].value)});
+        return sp::air_verify_host(proof, proof_len, d->main_cols, d->aux_cols, offsets, degrees, exemptions, d->degree_bound_factor, ops, consts,
+                                   d->n_rap, bcs, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }
 

@@ -5,8 +5,10 @@
 #include "cairo_air_host.h"
 #include "common.h"
 #include "keccak.h"
+#include <algorithm>
 #include <array>
 #include <cstring>
+#include <functional>
 #include <stdexcept>
 
 namespace sp {
@@ -164,26 +166,39 @@ bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, co
 }
 }  // namespace
 
+// What `verify` needs from an AIR (reference src/starks/traits.rs:15-119).
+struct VerifySpec {
+    uint32_t main_cols = 0, aux_cols = 0;
+    std::vector<uint32_t> offsets, degrees, exemptions;
+    uint32_t bound_factor = 2;   // composition_poly_degree_bound / trace_length
+    uint32_t n_rap = 0;
+    std::function<std::vector<BoundaryConstraint>(const std::vector<fe>& rap)> boundary;
+    std::function<void(const fe* frame /*[rows][C]*/, const std::vector<fe>& rap, fe* out)> transition;
+};
+
 // returns 1 accept, 0 reject; throws on malformed input
-int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
+static int verify_host(const uint8_t* proof_bytes, size_t len, const VerifySpec& air, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
     Proof pr = parse(proof_bytes, len);
     if (pr.queries.size() < queries) return 0;
     const uint64_t n = pr.trace_length;
     int k = sp_log2_exact(n), lb = sp_log2_exact(blowup);
     if (k < 1 || lb < 1 || k + lb > 40) return 0;
-    CairoAirInfo air = cairo_air_info(pub);
-    const uint32_t C = air.trace_columns, T = air.num_transition_constraints;
+    const uint32_t C = air.main_cols + air.aux_cols, T = (uint32_t)air.degrees.size(), R = (uint32_t)air.offsets.size();
+    const uint32_t f = air.bound_factor;
+    const size_t n_roots = air.aux_cols ? 2 : 1;
     const uint64_t N = n << lb;
-    if (pr.ood.size() != 2 * (size_t)C || pr.trace_roots.size() != 2 || pr.fri_roots.size() != (size_t)k) return 0;
+    if (pr.ood.size() != (size_t)R * C || pr.trace_roots.size() != n_roots || pr.fri_roots.size() != (size_t)k) return 0;
+    for (uint32_t c = 0; c < T; ++c) if (air.degrees[c] < 1 || air.degrees[c] > f + 1 || air.exemptions[c] >= n) return 0;
     const fe h = fe_from_u64(coset_offset), hinv = fe_inv(h);
     auto root_of = [&](int order) { fe w = fe_from_bytes_be((const uint8_t*)"\x00\x52\x82\xdb\x87\x52\x9c\xfa\x3f\x04\x64\x51\x9c\x8b\x0f\xa5\xad\x18\x71\x48\xe1\x1a\x61\x61\x60\x70\x02\x4f\x42\xf8\xef\x94"); for (int i = order; i < 192; ++i) w = fe_sqr(w); return w; };
     const fe g = root_of(k), w = root_of(k + lb);
     // ---- step 1: replay the transcript (verifier.rs:59-206)
     Tr t;
     t.append(pr.trace_roots[0].data(), 32);
-    fe rap[3] = {t.field(), t.field(), t.field()};
-    t.append(pr.trace_roots[1].data(), 32);
-    std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
+    std::vector<fe> rap(air.n_rap);
+    for (auto& x : rap) x = t.field();
+    if (n_roots > 1) t.append(pr.trace_roots[1].data(), 32);
+    std::vector<BoundaryConstraint> bcs = air.boundary(rap);
     std::vector<fe> ba(bcs.size()), bb(bcs.size()), ta(T), tb(T);
     for (auto& x : ba) x = t.field();
     for (auto& x : bb) x = t.field();
@@ -201,7 +216,7 @@ int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs
     t.felt(pr.h1z); t.felt(pr.h2z);
     for (auto& e : pr.ood) t.felt(e);
     fe gamma = t.field(), gamma_p = t.field();
-    std::vector<fe> tg(2 * (size_t)C);
+    std::vector<fe> tg((size_t)R * C);
     for (auto& x : tg) x = t.field();
     std::vector<fe> zetas;
     for (auto& r : pr.fri_roots) { t.append(r.data(), 32); zetas.push_back(t.field()); }
@@ -226,24 +241,30 @@ int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs
     // ---- step 2: composition polynomial at z (verifier.rs:208-317)
     {
         fe zn = fe_pow_u64(z, n);
+        fe bdz = fe_pow_u64(zn, f - 1);                       // z^(D - n)
         fe bq = fe_zero();
         for (size_t j = 0; j < bcs.size(); ++j) {
+            if (bcs[j].col >= C) return 0;
             fe den = fe_sub(z, fe_pow_u64(g, bcs[j].step));
             if (fe_is_zero(den)) return 0;
             fe num = fe_sub(pr.ood[bcs[j].col], bcs[j].value);
-            bq = fe_add(bq, fe_mul(fe_mul(num, fe_inv(den)), fe_add(fe_mul(ba[j], zn), bb[j])));
+            bq = fe_add(bq, fe_mul(fe_mul(num, fe_inv(den)), fe_add(fe_mul(ba[j], bdz), bb[j])));
         }
         std::vector<fe> cons(T);
-        cairo_transition_host(pr.ood.data(), C, air.has_rc_builtin, rap, cons.data());
+        air.transition(pr.ood.data(), rap, cons.data());
         fe zden = fe_sub(zn, fe_one());
         if (fe_is_zero(zden)) return 0;
         fe zf = fe_inv(zden);
-        fe ex = fe_sub(z, fe_pow_u64(g, n - 1));
-        fe pw[4] = {fe_one(), zn, fe_sqr(zn), fe_mul(fe_sqr(zn), zn)};
+        // transition_exemptions_verifier (traits.rs:97-118): ex_e(z) = prod_{i=1..e} (z - g^(n-i))
+        uint32_t max_ex = 0;
+        for (uint32_t e : air.exemptions) max_ex = std::max(max_ex, e);
+        std::vector<fe> ex(max_ex + 1, fe_one());
+        for (uint32_t e = 1; e <= max_ex; ++e) ex[e] = fe_mul(ex[e - 1], fe_sub(z, fe_pow_u64(g, n - e)));
         fe sum = fe_zero();
         for (uint32_t c = 0; c < T; ++c) {
-            fe term = fe_mul(fe_mul(zf, cons[c]), fe_add(fe_mul(ta[c], pw[3 - air.transition_degrees[c]]), tb[c]));
-            if (air.transition_exemptions[c]) term = fe_mul(term, ex);
+            fe adj = fe_pow_u64(zn, f - air.degrees[c] + 1);   // z^(D - n (deg - 1))
+            fe term = fe_mul(fe_mul(zf, cons[c]), fe_add(fe_mul(ta[c], adj), tb[c]));
+            term = fe_mul(term, ex[air.exemptions[c]]);
             sum = fe_add(sum, term);
         }
         if (!fe_eq(fe_add(pr.h1z, fe_mul(z, pr.h2z)), fe_add(bq, sum))) return 0;
@@ -271,27 +292,91 @@ int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs
     // ---- step 4: DEEP consistency and openings (verifier.rs:358-441, :525-557)
     if (pr.openings.size() < queries) return 0;
     const fe z2 = fe_sqr(z);
+    std::vector<fe> zk(R);
+    for (uint32_t r = 0; r < R; ++r) zk[r] = fe_mul(z, fe_pow_u64(g, air.offsets[r]));
     for (size_t s = 0; s < queries; ++s) {
         const Opening& o = pr.openings[s];
-        if (o.trace_evals.size() != C || o.trace_paths.size() != 2) return 0;
+        if (o.trace_evals.size() != C || o.trace_paths.size() != n_roots) return 0;
         fe hh[2] = {o.h1, o.h2};
         ok &= merkle_ok(o.comp_path, pr.comp_root, iotas[s], hh, 2);
-        ok &= merkle_ok(o.trace_paths[0], pr.trace_roots[0], iotas[s], o.trace_evals.data(), air.main_columns);
-        ok &= merkle_ok(o.trace_paths[1], pr.trace_roots[1], iotas[s], o.trace_evals.data() + air.main_columns, air.aux_columns);
+        ok &= merkle_ok(o.trace_paths[0], pr.trace_roots[0], iotas[s], o.trace_evals.data(), air.main_cols);
+        if (n_roots > 1) ok &= merkle_ok(o.trace_paths[1], pr.trace_roots[1], iotas[s], o.trace_evals.data() + air.main_cols, air.aux_cols);
         fe x = fe_mul(h, fe_pow_u64(w, iotas[s]));
-        fe d2 = fe_sub(x, z2), d0 = fe_sub(x, z), d1 = fe_sub(x, fe_mul(z, g));
-        if (fe_is_zero(d0) || fe_is_zero(d1) || fe_is_zero(d2)) return 0;
-        fe i0 = fe_inv(d0), i1 = fe_inv(d1), i2 = fe_inv(d2);
+        fe d2 = fe_sub(x, z2);
+        if (fe_is_zero(d2)) return 0;
+        fe i2 = fe_inv(d2);
         fe acc = fe_zero();
-        for (uint32_t j = 0; j < C; ++j) {
-            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[j]), i0), tg[2 * j]));
-            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[C + j]), i1), tg[2 * j + 1]));
+        for (uint32_t r = 0; r < R; ++r) {
+            fe d = fe_sub(x, zk[r]);
+            if (fe_is_zero(d)) return 0;
+            fe ir = fe_inv(d);
+            for (uint32_t j = 0; j < C; ++j)
+                acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[(size_t)r * C + j]), ir), tg[(size_t)R * j + r]));
         }
         acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h1, pr.h1z), i2), gamma));
         acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h2, pr.h2z), i2), gamma_p));
         ok &= fe_eq(acc, pr.queries[s].evals[0]);
     }
     return ok ? 1 : 0;
+}
+
+int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
+    CairoAirInfo info = cairo_air_info(pub);
+    VerifySpec spec;
+    spec.main_cols = info.main_columns; spec.aux_cols = info.aux_columns;
+    spec.offsets = {0, 1};
+    spec.degrees = info.transition_degrees; spec.exemptions = info.transition_exemptions;
+    spec.bound_factor = 2; spec.n_rap = 3;
+    // the trace length is only known from the proof: read it first (boundary steps depend on it)
+    if (len < 8) throw std::runtime_error("InvalidAmountOfBytes");
+    uint64_t n = 0;
+    for (int i = 0; i < 8; ++i) n = (n << 8) | proof_bytes[i];
+    const bool has_rc = info.has_rc_builtin;
+    const uint32_t C = info.trace_columns;
+    spec.boundary = [&pub, n, has_rc](const std::vector<fe>& rap) { fe r[3] = {rap[0], rap[1], rap[2]}; return boundary_constraints(pub, r, n, has_rc); };
+    spec.transition = [C, has_rc](const fe* frame, const std::vector<fe>& rap, fe* out) { fe r[3] = {rap[0], rap[1], rap[2]}; cairo_transition_host(frame, C, has_rc, r, out); };
+    return verify_host(proof_bytes, len, spec, blowup, queries, coset_offset, grinding);
+}
+
+// `verify::<F, A>` for a program AIR (include/stark252_hip.h sp_air_desc); ops as in AirOpDev of stark_kernels.h.
+int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, uint32_t aux_cols, const std::vector<uint32_t>& offsets,
+                    const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint32_t bound_factor,
+                    const std::vector<std::array<uint16_t, 3>>& ops /*op, a, b*/, const std::vector<fe>& consts, uint32_t n_rap,
+                    const std::vector<BoundaryConstraint>& boundary, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
+    const uint32_t C = main_cols + aux_cols, T = (uint32_t)degrees.size(), R = (uint32_t)offsets.size();
+    if (T == 0 || R == 0 || exemptions.size() != T || bound_factor < 1) return 0;
+    for (size_t t = 0; t < ops.size(); ++t) {   // same well-formedness rules as the prover
+        const uint16_t op = ops[t][0], a = ops[t][1], b = ops[t][2];
+        bool ok = true;
+        switch (op) {
+            case 0: ok = a < R && b < C; break;
+            case 1: ok = a < consts.size() + n_rap; break;
+            case 2: case 3: case 4: ok = a < t && b < t && ops[a][0] != 5 && ops[b][0] != 5; break;
+            case 5: ok = a < T && b < t && ops[b][0] != 5; break;
+            default: ok = false;
+        }
+        if (!ok) throw std::runtime_error("malformed constraint program");
+    }
+    VerifySpec spec;
+    spec.main_cols = main_cols; spec.aux_cols = aux_cols; spec.offsets = offsets; spec.degrees = degrees; spec.exemptions = exemptions;
+    spec.bound_factor = bound_factor; spec.n_rap = n_rap;
+    spec.boundary = [&boundary](const std::vector<fe>&) { return boundary; };
+    spec.transition = [&ops, &consts, C, T](const fe* frame, const std::vector<fe>& rap, fe* out) {
+        std::vector<fe> v(ops.size(), fe_zero());
+        for (uint32_t k = 0; k < T; ++k) out[k] = fe_zero();
+        for (size_t t = 0; t < ops.size(); ++t) {
+            const uint16_t op = ops[t][0], a = ops[t][1], b = ops[t][2];
+            switch (op) {
+                case 0: v[t] = frame[(size_t)a * C + b]; break;
+                case 1: v[t] = a < consts.size() ? consts[a] : rap[a - consts.size()]; break;
+                case 2: v[t] = fe_add(v[a], v[b]); break;
+                case 3: v[t] = fe_sub(v[a], v[b]); break;
+                case 4: v[t] = fe_mul(v[a], v[b]); break;
+                default: out[a] = v[b]; break;
+            }
+        }
+    };
+    return verify_host(proof_bytes, len, spec, blowup, queries, coset_offset, grinding);
 }
 
 }  // namespace sp

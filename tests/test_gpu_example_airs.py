@@ -36,6 +36,7 @@ def test_device_proof_bytes_equal_oracle(hip_ctx, oracle, kind, length, params, 
     assert len(got) == len(want)
     assert got == want
     assert O.example_verify(kind, got, options, params, steps)
+    assert api.air_verify(got, desc, api.ProofOptions(*options))
 
 
 @pytest.mark.parametrize("kind,length,builder", [("simple_fibonacci", 32, lambda n, L: air.simple_fibonacci(1, 1)),

@@ -51,3 +51,26 @@ def test_larger_traces(oracle, kind, length):
     steps = length if kind == "fibonacci_rap" else 0
     proof = O.example_prove(kind, trace, DEFAULT, (1, 1), steps)
     assert O.example_verify(kind, proof, DEFAULT, (1, 1), steps)
+
+
+@pytest.mark.parametrize("kind,length,params,builder", CASES)
+def test_product_verifier_on_program_airs(oracle, hip_lib, kind, length, params, builder):
+    """sp_air_verify (the library's CPU verifier, no GPU needed) accepts the oracle's proofs of the example AIRs, agrees
+    with the oracle's verifier on tampered proofs, and rejects a proof under another AIR's descriptor."""
+    import random
+    from lambdaworks_cairo_prover_amd import api
+    trace = O.example_trace(kind, length, params)
+    n = trace.shape[0]
+    steps = length if kind == "fibonacci_rap" else 0
+    proof = O.example_prove(kind, trace, DEFAULT, params, steps)
+    desc, keep = builder(n).build()
+    opts = api.ProofOptions(*DEFAULT)
+    assert api.air_verify(proof, desc, opts)
+    rng = random.Random(5)
+    for _ in range(40):
+        bad = bytearray(proof)
+        bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+        assert api.air_verify(bytes(bad), desc, opts) == O.example_verify(kind, bytes(bad), DEFAULT, params, steps)
+    assert not api.air_verify(proof[:-1], desc, opts)
+    other, keep2 = (air.quadratic(3) if kind != "quadratic" else air.simple_fibonacci(1, 1)).build()
+    assert not api.air_verify(proof, other, opts)
