@@ -191,6 +191,26 @@ int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
     return SP_OK;
 }
 
+// Coset-sharded commitments: every rank holds all leaf digests but reduces only its contiguous 1/G of each level
+// (the subtree over leaves [rank N/G, (rank+1) N/G)), down to the level with G nodes.  The caller all-gathers that level
+// (one digest per rank) and finishes with merkle_reduce(nodes, G).  Nodes outside the rank's subtree are left unwritten.
+int merkle_reduce_subtree(hipStream_t st, digest32* nodes, uint64_t n_leaves, uint32_t logG, uint32_t rank) {
+    const uint64_t G = 1ull << logG;
+    if (n_leaves < 2 * G) { sp_set_error("merkle: fewer than two leaves per rank"); return SP_E_INVALID_ARG; }
+    for (uint64_t count = n_leaves >> 1; count >= G; count >>= 1) {
+        const uint64_t mine = count >> logG;
+        const uint64_t first = (count - 1) + (uint64_t)rank * mine;
+        if (mine > MK_LANES_MAX_NODES) {
+            unsigned blocks = (unsigned)((mine + MK_THREADS - 1) / MK_THREADS);
+            hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, first, mine);
+        } else {
+            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((mine + 7) / 8)), dim3(256), 0, st, nodes, first, (uint32_t)mine, 0);
+        }
+        SP_HIP_CHECK(hipGetLastError());
+    }
+    return SP_OK;
+}
+
 int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out) {
     int depth = sp_log2_exact(n_leaves);
     if (depth < 0) return SP_E_INVALID_ARG;

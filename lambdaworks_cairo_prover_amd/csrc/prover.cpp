@@ -124,6 +124,18 @@ int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t nc
         SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, Nl_, reinterpret_cast<digest32*>(d_local_)));
         SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(digest32)));
         SP_TRY(interleave_shards(c_->stream, d_gather_, tree + (N_ - 1), n_, shard_map()));
+        // Merkle combine: every rank reduces the subtree over its contiguous 1/G of the leaves,
+        // the G subtree roots are all-gathered and the top log2 G levels finished everywhere.  Authentication paths are
+        // served by the rank that owns the leaf's subtree (open()).
+        const uint64_t G = world_;
+        SP_TRY(merkle_reduce_subtree(c_->stream, tree, N_, logG_, rank_));
+        SP_HIP_CHECK(hipMemcpyAsync(d_local_, tree + (G - 1) + rank_, sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
+        SP_TRY(all_gather(d_local_, d_gather_, sizeof(digest32)));
+        SP_HIP_CHECK(hipMemcpyAsync(tree + (G - 1), d_gather_, G * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
+        SP_TRY(merkle_reduce(c_->stream, tree, G));
+        SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        return SP_OK;
     }
     SP_TRY(merkle_reduce(c_->stream, tree, N_));
     SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
@@ -751,6 +763,31 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     SP_TRY(merkle_gather_paths(st, d_tree_main_, N_, d_positions_, q, p_main));
     if (Ca_) SP_TRY(merkle_gather_paths(st, d_tree_aux_, N_, d_positions_, q, p_aux));
     SP_TRY(merkle_gather_paths(st, d_tree_comp_, N_, d_positions_, q, p_comp));
+    if (world_ > 1) {
+        // the trees are reduced in contiguous shares (commit_columns): below the replicated top only the rank that owns the
+        // leaf's subtree has the siblings.  All-gather every rank's view of the paths and keep the owner's.
+        const size_t per = (size_t)q * d0;                 // digests per tree
+        const size_t blk = 3 * per;
+        if (blk * world_ > N_ || blk > Nl_) { sp_set_error("open: too many queries for the staging buffers"); return SP_E_UNSUPPORTED; }
+        digest32* send = reinterpret_cast<digest32*>(d_local_);
+        SP_HIP_CHECK(hipMemcpyAsync(send, p_main, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
+        if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(send + per, p_aux, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
+        SP_HIP_CHECK(hipMemcpyAsync(send + 2 * per, p_comp, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
+        SP_TRY(all_gather(send, d_gather_, blk * sizeof(digest32)));
+        std::vector<digest32> all(blk * world_), sel(blk);
+        SP_HIP_CHECK(hipMemcpy(all.data(), d_gather_, all.size() * sizeof(digest32), hipMemcpyDeviceToHost));
+        const uint64_t leaves_per_rank = N_ >> logG_;
+        for (uint32_t s = 0; s < q; ++s) {
+            const size_t owner = (size_t)(pos[s] / leaves_per_rank);
+            for (int t3 = 0; t3 < 3; ++t3)
+                std::copy(all.begin() + owner * blk + t3 * per + (size_t)s * d0, all.begin() + owner * blk + t3 * per + (size_t)(s + 1) * d0,
+                          sel.begin() + t3 * per + (size_t)s * d0);
+        }
+        SP_HIP_CHECK(hipMemcpyAsync(p_main, sel.data(), per * sizeof(digest32), hipMemcpyHostToDevice, st));
+        if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(p_aux, sel.data() + per, per * sizeof(digest32), hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(hipMemcpyAsync(p_comp, sel.data() + 2 * per, per * sizeof(digest32), hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(hipStreamSynchronize(st));  // sel is a local
+    }
     o.trace_evals.resize((size_t)q * C_); o.comp_evals.resize((size_t)q * 2);
     o.main_paths.resize((size_t)q * d0); o.aux_paths.resize((size_t)q * d0); o.comp_paths.resize((size_t)q * d0);
     SP_HIP_CHECK(hipMemcpyAsync(o.trace_evals.data(), g_trace, sizeof(fe) * q * C_, hipMemcpyDeviceToHost, st));
