@@ -184,6 +184,44 @@ SP_HD fe fe_sub_add_2p(const fe& a, const fe& b) {
 // [0, 4p) -> canonical [0, p)
 SP_HD fe fe_canonical_4p(const fe& a) { return fe_reduce_once(fe_reduce_2p(a)); }
 
+// ---- deferred reduction for the DIT passes: p > 2^251, so ANY 256-bit value is < 32p and a DIT butterfly
+// (u, t) -> (u + t, u - t + 2p) with t = v w in [0, 2p) needs no correction at all while the bound (2 + 2 stages) p stays
+// below 32p, i.e. for up to 14 stages.  One quotient estimate from the top five bits brings a value back:
+// x = q 2^251 + r0 (q < 32, r0 < 2^251) and p = 2^251 + d, d = 17 2^192 + 1 < 2^197, so q d < 2^202.
+// x - k p with k = q - (q != 0):  in [2^251 - 30 d, 2^252) for q >= 1, x itself (< 2^251) for q = 0  ->  [0, 2p).
+SP_HD fe fe_reduce_lazy_2p(const fe& a) {
+    const uint32_t q = a.v[7] >> 27;
+    const uint32_t k = q - (q != 0u);
+    fe r;
+    unsigned br = 0, bo;
+    r.v[0] = SP_SUBC(a.v[0], k, br, bo); br = bo;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { r.v[i] = SP_SUBC(a.v[i], 0u, br, bo); br = bo; }
+    r.v[6] = SP_SUBC(a.v[6], 17u * k, br, bo); br = bo;
+    r.v[7] = SP_SUBC(a.v[7], k << 27, br, bo);
+    return r;
+}
+// any 256-bit value -> canonical [0, p):  y = x - q p lies in (-q d, 2^251); a borrow means y + p in (p - 31 d, p).
+SP_HD fe fe_canonical_lazy(const fe& a) {
+    const uint32_t q = a.v[7] >> 27;
+    fe d;
+    unsigned br = 0, bo;
+    d.v[0] = SP_SUBC(a.v[0], q, br, bo); br = bo;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { d.v[i] = SP_SUBC(a.v[i], 0u, br, bo); br = bo; }
+    d.v[6] = SP_SUBC(a.v[6], 17u * q, br, bo); br = bo;
+    d.v[7] = SP_SUBC(a.v[7], q << 27, br, bo); br = bo;
+    const uint32_t m = 0u - (uint32_t)br;
+    fe r;
+    unsigned c = 0, co;
+    r.v[0] = SP_ADDC(d.v[0], m & SP_P0, c, co); c = co;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { r.v[i] = SP_ADDC(d.v[i], 0u, c, co); c = co; }
+    r.v[6] = SP_ADDC(d.v[6], m & SP_P6, c, co); c = co;
+    r.v[7] = SP_ADDC(d.v[7], m & SP_P7, c, co);
+    return r;
+}
+
 SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 
 // canonical integer (little-endian limbs, < p) -> Montgomery

@@ -2,6 +2,7 @@
 // inter-pass twiddle exponent E(pos).
 #include "ntt.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace sp {
 
@@ -40,10 +41,15 @@ __device__ __forceinline__ fe big_root(const fe* tw, uint32_t e, uint32_t logM) 
     return (e & half) ? fe_neg(w) : w;
 }
 
-// One four-step pass. Template flags are compile-time so each instantiation keeps only its own address math.
-// Lazy reduction (Harvey butterflies, fp.h): inside a transform the data lives in [0, 4p) for DIT passes and in
-// [0, 2p) for DIF passes, also in HBM between the passes of one transform (a.weak_out = 1); only the last pass of a
-// transform stores canonical values.  Twiddles are always canonical, so every product is fe_mul_lazy(data, twiddle).
+// One pass.  Template flags are compile-time so each instantiation keeps only its own address math.
+//  * DIT passes are plain Cooley-Tukey stages a.s+1 .. a.s+r of the size-2^logM transform on a tile of R rows at stride
+//    2^s: the s = 0 pass uses the pass-local table w_R^e, a strided pass stages the global twiddles of its own
+//    butterflies (one table entry per element) in LDS, so there is no inter-pass twiddle product.  Reduction is deferred
+//    (fp.h): pass input < 2p, no correction inside the pass, fe_reduce_lazy_2p on the store of every pass but the last,
+//    fe_canonical_lazy on the last.
+//  * DIF passes are four-step: radix-2 DIF stages with w_R^-e, then the inter-pass twiddle w_M^-E(pos); data in [0, 2p)
+//    between stages and passes (a.weak_out = 1), canonical after the last pass.
+// Twiddles are always canonical, so every product is fe_mul_lazy(data, twiddle).
 template <bool DIF, int LOADM, int STOREM, bool CONTIG>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
@@ -52,8 +58,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
     uint4* Llo = smem;
     uint4* Lhi = smem + TILE;
-    uint4* Twl = smem + 2 * TILE;            // small twiddles, R/2 entries (two planes)
-    uint4* Twh = Twl + (R >> 1);
+    // twiddles (two planes): R/2 entries w_R^e of the pass-local table (contiguous and DIF passes), or, for the strided
+    // DIT passes, the global twiddles of this tile's butterflies of the stages j < r: stage j, butterfly row i, column gl
+    // at (2^(j-1) - 1 + i) * G + gl (TILE/2 - G entries).  The twiddles of stage r serve one butterfly each and go
+    // straight to registers.
+    constexpr bool GLOBAL_TW = !DIF && !CONTIG;
+    uint4* Twl = smem + 2 * TILE;
+    uint4* Twh = Twl + (GLOBAL_TW ? (TILE >> 1) : (R >> 1));
     const uint32_t tid = threadIdx.x;
     // vector index fastest: consecutive work-groups run the same tile of different vectors, so the inter-pass twiddles
     // they gather (the same table entries for every vector) are L2 hits for all but the first of them
@@ -73,14 +84,51 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     fe* dst = a.dst + (uint64_t)vec * a.dst_vec_stride;
     const uint32_t logM = a.logM;
 
-    for (uint32_t i = tid; i < (R >> 1); i += NTT_THREADS) lds_st(Twl, Twh, i, ld_fe(a.small_tw + i));
-
     // tile coordinates
     uint32_t lo0 = 0, hi = 0;
     if (!CONTIG) {
         uint32_t lo_tiles = 1u << (s - g);
         lo0 = (tile & (lo_tiles - 1)) << g;
         hi = tile >> (s - g);
+    }
+    // plain Cooley-Tukey twiddles (strided DIT passes): the butterfly of global stage J = a.s + j whose upper element sits at
+    // global position P uses w_(2^J)^(P mod 2^(J-1)) = w_M^(((i << a.s) + column) << (logM - a.s - j)), i = row mod 2^(j-1);
+    // the global column of local column c is (c << shard_log) | shard_rank.  No separate inter-pass twiddle product.
+    auto global_tw = [&](uint32_t jm1, uint32_t i, uint32_t gl) -> const fe* {
+        const uint32_t col = ((lo0 + gl) << a.shard_log) | a.shard_rank;
+        return a.big_tw + (((i << a.s) + col) << (logM - a.s - jm1 - 1u));
+    };
+    constexpr int TW_REGS = GLOBAL_TW ? (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS : 1;   // butterflies per thread and stage
+    fe tw_last[TW_REGS];
+    if (GLOBAL_TW) {
+        if (r >= 1) {
+#pragma unroll
+            for (int q = 0; q < TW_REGS; ++q) {
+                const uint32_t b = tid + q * NTT_THREADS;
+                if (b < (TILE >> 1)) tw_last[q] = ld_fe(global_tw(r - 1, b >> g, b & (G - 1)));
+            }
+        }
+        constexpr int U = (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS;
+        const uint32_t cnt = (TILE >> 1) - G;   // (meaningful for r >= 1 only)
+        if (r >= 1) {
+            fe tmp[U];
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t x = tid + q * NTT_THREADS;
+                if (x < cnt) {
+                    const uint32_t y = (x >> g) + 1u;
+                    const uint32_t jm1 = 31u - __clz(y);                 // j - 1
+                    tmp[q] = ld_fe(global_tw(jm1, y - (1u << jm1), x & (G - 1)));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < U; ++q) {
+                const uint32_t x = tid + q * NTT_THREADS;
+                if (x < cnt) lds_st(Twl, Twh, x, tmp[q]);
+            }
+        }
+    } else {
+        for (uint32_t i = tid; i < (R >> 1); i += NTT_THREADS) lds_st(Twl, Twh, i, ld_fe(a.small_tw + i));
     }
     // position (in the 2^logM working array) of tile element (t, gl)
     auto position = [&](uint32_t t, uint32_t gl) -> uint32_t {
@@ -102,27 +150,33 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     };
 
     // ------------------------------------------------------------------ load
-    for (uint32_t e = tid; e < TILE; e += NTT_THREADS) {
-        uint32_t t, gl;
-        fe x;
-        if (CONTIG && LOADM == NTT_LOAD_INPLACE) {
-            t = e & (R - 1); gl = e >> r;
-            x = ld_fe(src + position(t, gl));
-        } else if (CONTIG) {  // gather from the natural-order source: x[rev(pos)]
-            gl = e & (G - 1); t = e >> g;
-            uint32_t sidx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
-            x = ld_fe(src + sidx);
-        } else {
-            gl = e & (G - 1); t = e >> g;
-            uint32_t pos = position(t, gl);
-            if (LOADM == NTT_LOAD_EXPAND) x = ld_fe(src + (pos >> s));  // s = local log2(cosets held)
-            else x = ld_fe(src + pos);
-            if (!DIF) {
-                uint32_t ex = twiddle_exp(pos);
-                if (ex != 0) x = fe_mul_lazy(x, big_root(a.big_tw, ex, logM));
+    constexpr int LU = 4;   // loads in flight per thread
+    for (uint32_t e0 = tid; e0 < TILE; e0 += NTT_THREADS * LU) {
+        fe xs[LU];
+        uint32_t li[LU];
+#pragma unroll
+        for (int q = 0; q < LU; ++q) {
+            const uint32_t e = e0 + q * NTT_THREADS;
+            if (e >= TILE) continue;
+            uint32_t t, gl;
+            if (CONTIG && LOADM == NTT_LOAD_INPLACE) {
+                t = e & (R - 1); gl = e >> r;
+                xs[q] = ld_fe(src + position(t, gl));
+            } else if (CONTIG) {  // gather from the natural-order source: x[rev(pos)]
+                gl = e & (G - 1); t = e >> g;
+                uint32_t sidx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
+                xs[q] = ld_fe(src + sidx);
+            } else {
+                gl = e & (G - 1); t = e >> g;
+                uint32_t pos = position(t, gl);
+                if (LOADM == NTT_LOAD_EXPAND) xs[q] = ld_fe(src + (pos >> s));  // s = local log2(cosets held)
+                else xs[q] = ld_fe(src + pos);
             }
+            li[q] = lidx(t, gl);
         }
-        lds_st(Llo, Lhi, lidx(t, gl), x);
+#pragma unroll
+        for (int q = 0; q < LU; ++q)
+            if (e0 + q * NTT_THREADS < TILE) lds_st(Llo, Lhi, li[q], xs[q]);
     }
     __syncthreads();
 
@@ -131,17 +185,31 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     if (!DIF) {
         for (uint32_t j = 1; j <= r; ++j) {
             const uint32_t half = 1u << (j - 1);
+            if (GLOBAL_TW && j == r) {
+#pragma unroll
+                for (int q = 0; q < TW_REGS; ++q) {
+                    const uint32_t b = tid + q * NTT_THREADS;
+                    if (b >= NB) continue;
+                    const uint32_t gl = b & (G - 1), bf = b >> g;   // half = R/2: i = bf, t0 = bf
+                    const uint32_t i0 = lidx(bf, gl), i1 = lidx(bf + half, gl);
+                    fe u = lds_ld(Llo, Lhi, i0), v = fe_mul_lazy(lds_ld(Llo, Lhi, i1), tw_last[q]);
+                    lds_st(Llo, Lhi, i0, fe_add_raw(u, v));
+                    lds_st(Llo, Lhi, i1, fe_sub_add_2p(u, v));
+                }
+                __syncthreads();
+                continue;
+            }
             for (uint32_t b = tid; b < NB; b += NTT_THREADS) {
                 uint32_t bf, gl;
                 if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
                 uint32_t i = bf & (half - 1);
                 uint32_t t0 = ((bf >> (j - 1)) << j) | i;
                 uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
-                // u, v in [0, 4p)  ->  t = v w in [0, 2p), u' = u mod 2p;  outputs u' + t and u' - t + 2p in [0, 4p)
-                fe u = fe_reduce_2p(lds_ld(Llo, Lhi, i0)), v = lds_ld(Llo, Lhi, i1);
-                uint32_t twi = i << (r - j);
-                if (twi != 0) v = fe_mul_lazy(v, lds_ld(Twl, Twh, twi));
-                else v = fe_reduce_2p(v);
+                // deferred reduction (fp.h): the pass input is < 2p, t = v w is in [0, 2p) whatever v is, and the outputs
+                // u + t and u - t + 2p stay below (2 + 2j) p < 2^256 for the <= 10 stages of a pass
+                fe u = lds_ld(Llo, Lhi, i0), v = lds_ld(Llo, Lhi, i1);
+                if (GLOBAL_TW) v = fe_mul_lazy(v, lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl));
+                else if (j > 1) v = fe_mul_lazy(v, lds_ld(Twl, Twh, i << (r - j)));   // stage 1: w = 1 and v < 2p already
                 lds_st(Llo, Lhi, i0, fe_add_raw(u, v));
                 lds_st(Llo, Lhi, i1, fe_sub_add_2p(u, v));
             }
@@ -187,7 +255,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         }
         if (DIF && a.post_table) x = fe_mul_lazy(x, ld_fe(a.post_table + didx));
         if (has_scalar) x = fe_mul_lazy(x, scal);
-        if (!a.weak_out) x = DIF ? fe_reduce_once(x) : fe_canonical_4p(x);  // last pass of the transform: canonical
+        if (DIF) { if (!a.weak_out) x = fe_reduce_once(x); }                  // last pass of the transform: canonical
+        else x = a.weak_out ? fe_reduce_lazy_2p(x) : fe_canonical_lazy(x);   // DIT: back below 2p for the next pass
         st_fe(dst + didx, x);
     }
 }
@@ -294,6 +363,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
     uint32_t tiles = 1u << (a.logM - a.shard_log - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
+    if (!DIF && !CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r
     NttPassArgs b = a;
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
@@ -327,7 +397,9 @@ struct PassGeom { int s, r, g, s_prev; };
 // (more work-groups in flight).  Measured: single 2^22 NTT 3 % faster with 512-element tiles, the proof's large batches
 // indifferent to slightly better with 1024.
 static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max, uint64_t footprint) {
-    const int min_tile_log = footprint > (256ull << 20) ? 10 : 9;
+    static const int tile_big = std::getenv("SP_NTT_TILE_BIG") ? std::atoi(std::getenv("SP_NTT_TILE_BIG")) : 10;
+    static const int tile_small = std::getenv("SP_NTT_TILE_SMALL") ? std::atoi(std::getenv("SP_NTT_TILE_SMALL")) : 9;
+    const int min_tile_log = footprint > (256ull << 20) ? tile_big : tile_small;
     std::vector<PassGeom> out;
     int s = first_stride_log, s_prev = 0;
     int rem = k - first_stride_log;
