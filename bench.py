@@ -4,6 +4,11 @@ CPU-baseline objects.  One "step" = one forward natural-order NTT of 2^22 elemen
 
 python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU; the path
 shards by column with no data-path collective -> weak scaling, value = butterflies of all ranks / max time).
+
+The "proof" object of the same JSON line is BASELINE.json's second figure: whole-proof generation of the 2^20-row Cairo
+fibonacci trace (configs[2]) on the N GPUs - in process for N = 1, for N > 1 coset-sharded over the library's RCCL
+communicator in one child process per rank under a time limit (proof_isolated), so that the headline line survives
+whatever happens there.
 """
 import argparse
 import json
@@ -39,14 +44,17 @@ def cpu_baseline(log_n=22, reps=3):
             "sample": f"{reps} x forward NTT 2^{log_n} through oracle_ntt (includes 32-byte BE codec), single thread"}
 
 
-def proof_benchmark(api, ctx, args, world, dist):
+def proof_benchmark(api, ctx, args, world, dist, force_rccl=False):
     """Whole-proof generation (BASELINE configs[2] shape by default: fib trace 2^20 rows, blowup 8, 80 queries, grinding 20)
     on the coset-sharded device prover; with N > 1 ranks the shards exchange through the library's RCCL communicator."""
     run = api.CairoRun.fibonacci(args.proof_fib)
     trace = run.main_trace()
     opt = api.ProofOptions(args.proof_blowup, 80, 3, 20)
-    if world > 1:
-        ctx.init_rccl()
+    if world > 1 or force_rccl:
+        if dist.get_backend() == "nccl":
+            ctx.init_rccl()                                   # the library's own RCCL communicator (xGMI)
+        else:                                                 # development aid: ranks sharing one GPU, host-staged exchange
+            ctx.set_collective(world, dist.get_rank(), api.StagedAllGather())
     import torch
     dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))  # input resident in HBM
     torch.cuda.synchronize()
@@ -58,7 +66,12 @@ def proof_benchmark(api, ctx, args, world, dist):
             dist.barrier()
         t0 = time.perf_counter()
         proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
-        times.append((time.perf_counter() - t0) * 1e3)
+        dt = (time.perf_counter() - t0) * 1e3
+        if dist is not None and world > 1:   # max over ranks
+            t = torch.tensor([dt], dtype=torch.float64, device=dev_trace.device if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        times.append(dt)
     t0 = time.perf_counter()
     proof_h = ctx.cairo_prove(trace, run.public_inputs_c, opt)
     pcie_ms = (time.perf_counter() - t0) * 1e3
@@ -71,6 +84,95 @@ def proof_benchmark(api, ctx, args, world, dist):
             "note": "wall time of sp_cairo_prove_dev (main trace resident in HBM); the *_from_host_buffer figure adds the PCIe copy"}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _device_index(local_rank):
+    # SP_BENCH_FORCE_DEVICE: development aid (several ranks on the one GPU of the test box)
+    return int(os.environ.get("SP_BENCH_FORCE_DEVICE", local_rank))
+
+
+def _backend():
+    return os.environ.get("SP_BENCH_BACKEND", "nccl")
+
+
+def proof_child(args):
+    """Runs in a child process of every rank (see proof_isolated): its own process group on its own port and its own RCCL
+    communicator inside the library; rank 0 writes the result as JSON to args.proof_child."""
+    import torch
+    from lambdaworks_cairo_prover_amd import api
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    import torch.distributed as dist
+    dev_index = _device_index(local_rank)
+    torch.cuda.set_device(dev_index)
+    if _backend() == "nccl":
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+    else:
+        dist.init_process_group(_backend())
+    result = None
+    try:
+        ctx = api.Context(device=dev_index)
+        result = proof_benchmark(api, ctx, args, world, dist, force_rccl=True)
+        ctx.close()
+    except Exception as e:
+        result = {"error": repr(e)}
+    if rank == 0:
+        with open(args.proof_child, "w") as f:
+            json.dump(result, f)
+    dist.destroy_process_group()
+
+
+def proof_isolated(args, rank, local_rank, world, dist):
+    """Whole-proof timing for N > 1 GPUs.  The sharded prover exchanges leaf digests through the library's RCCL communicator;
+    every rank runs it in a CHILD process under a time limit, so that a failure or a hang of that path cannot take the
+    headline measurement with it.  Returns the child's result (rank 0) or an error object."""
+    import subprocess
+    import tempfile
+    box = [None, None]
+    if rank == 0:
+        fd, path = tempfile.mkstemp(prefix="sp_proof_", suffix=".json")
+        os.close(fd)
+        os.unlink(path)
+        box = [_free_port(), path]
+    if dist is not None:
+        dist.broadcast_object_list(box, src=0)
+    port, path = box
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    cmd = [sys.executable, os.path.abspath(__file__), "--proof-child", path, "--proof-fib", str(args.proof_fib),
+           "--proof-blowup", str(args.proof_blowup)]
+    err = tempfile.TemporaryFile()
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=err)
+    status = "ok"
+    try:
+        rc = child.wait(timeout=args.proof_timeout)
+        if rc != 0:
+            status = f"child exit code {rc}"
+    except subprocess.TimeoutExpired:
+        child.kill()          # exactly the process started above
+        child.wait()
+        status = f"timeout after {args.proof_timeout} s"
+    if rank != 0:
+        return None
+    try:
+        with open(path) as f:
+            res = json.load(f)
+        os.unlink(path)
+        if status != "ok" and isinstance(res, dict):
+            res["child_status"] = status
+        return res
+    except Exception:
+        err.seek(0)
+        tail = err.read().decode(errors="replace")[-600:]
+        return {"error": f"sharded proof child: {status}", "stderr_tail": tail}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,10 +180,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--proof", type=int, default=-1, help="also time whole-proof generation (default: on for 1 GPU, off otherwise)")
+    ap.add_argument("--proof", type=int, default=-1, help="also time whole-proof generation (default: on; N > 1 in child processes)")
+    ap.add_argument("--proof-isolated", action="store_true", help="run the proof timing in a child process also for 1 GPU")
+    ap.add_argument("--proof-timeout", type=int, default=420, help="seconds the child processes of the N > 1 proof timing may take")
+    ap.add_argument("--proof-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--proof-fib", type=int, default=149000, help="fibonacci index of the proved Cairo program (149000 -> 2^20 rows)")
     ap.add_argument("--proof-blowup", type=int, default=8)
     args = ap.parse_args()
+    if args.proof_child:
+        return proof_child(args)
 
     import numpy as np
     import torch
@@ -91,12 +198,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    dev_index = _device_index(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+        if _backend() == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group(_backend())
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
 
     n = 1 << args.log_n
     # synthetic input: uniformly random residues < 2^251 (< p), written directly in the device layout
@@ -107,7 +218,7 @@ def main():
     host = host | (host2 << 31)
     host[:, 7] &= 0x07FFFFFF
     data = host.to(dev).contiguous()
-    ctx = api.Context(device=local_rank)
+    ctx = api.Context(device=dev_index)
 
     def barrier():
         torch.cuda.synchronize()
@@ -126,7 +237,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if _backend() == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -159,10 +270,12 @@ def main():
                      # (sustained fe_mul rate 1.86e11/s): time the arithmetic alone needs / time measured
                      "valu_frac_incl_twiddles": (butterflies / VALU_BUTTERFLY_CEILING + 2 * n / VALU_MUL_CEILING) / (avg_ms * 1e-3)},
     }
-    want_proof = args.proof == 1 or (args.proof == -1 and world == 1)
-    if want_proof:
+    if args.proof != 0:
         try:
-            out["proof"] = proof_benchmark(api, ctx, args, world, dist)
+            if world == 1 and not args.proof_isolated:
+                out["proof"] = proof_benchmark(api, ctx, args, world, dist)
+            else:
+                out["proof"] = proof_isolated(args, rank, local_rank, world, dist)
         except Exception as e:  # the headline metric must survive a failure of the secondary one
             out["proof"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
