@@ -5,6 +5,7 @@
 #include "keccak.h"
 #include <algorithm>
 #include <cstring>
+#include <cmath>
 #include <stdexcept>
 #include <chrono>
 #include <cstdio>
@@ -509,8 +510,25 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
     uint64_t in_stride = vec_stride;
     uint32_t in_points = 1;
     uint64_t M = 1ULL << k;
-    const uint64_t level1 = (uint64_t)vectors * points * (M >> std::min<uint32_t>(8, k));
-    if (2 * level1 + (uint64_t)points * 256 > scratch_elems) { sp_set_error("eval_bitrev: scratch too small"); return SP_E_ALLOC; }
+    // level sizes: 2^8 terms per output while that leaves >= 2^16 outputs in flight, then 2^4 (a level with few outputs and
+    // long serial sums runs one wave per SIMD for hundreds of microseconds)
+    std::vector<uint32_t> ls;
+    {
+        uint32_t kk = k;
+        const double lt0 = std::log2((double)vectors * points);
+        while (kk > 0) {
+            const int room = (int)(lt0 + kk) - 16;
+            uint32_t l = room >= 8 ? 8u : (uint32_t)std::max(4, room);
+            l = std::min(l, kk);
+            // the two ping-pong buffers hold the first level's outputs: longer sums if the scratch area demands it
+            while (ls.empty() && l < std::min<uint32_t>(8, kk) && 2ull * vectors * points * (M >> l) + 8ull * points * 256 > scratch_elems) ++l;
+            ls.push_back(l);
+            kk -= l;
+        }
+    }
+    const uint64_t level1 = k == 0 ? 0 : (uint64_t)vectors * points * (M >> ls[0]);
+    const uint64_t tab_elems = (uint64_t)ls.size() * points * 256;
+    if (2 * level1 + tab_elems > scratch_elems) { sp_set_error("eval_bitrev: scratch too small"); return SP_E_ALLOC; }
     fe* bufs[2] = {scratch, scratch + level1};
     fe* yp_dev = scratch + 2 * level1;
     int which = 0;
@@ -523,11 +541,11 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
         }
         return SP_OK;
     }
-    while (M > 1) {
-        const uint32_t kk = (uint32_t)sp_log2_exact(M);
-        const uint32_t l = std::min<uint32_t>(8, kk);
-        const uint32_t Tn = 1u << l;
-        std::vector<fe> yp((size_t)points * Tn);
+    // all power tables first (yp[level][p][t] = y_level^rev_l(t), y_(level+1) = y_level^(2^l)), one upload, no host
+    // synchronisation between the levels
+    std::vector<fe> yp(tab_elems, fe_zero());
+    for (size_t lev = 0; lev < ls.size(); ++lev) {
+        const uint32_t l = ls[lev], Tn = 1u << l;
         for (uint32_t p = 0; p < points; ++p) {
             std::vector<fe> pw(Tn);
             pw[0] = fe_one();
@@ -535,21 +553,28 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
             for (uint32_t t = 0; t < Tn; ++t) {  // yp[t] = y^rev_l(t)
                 uint32_t r = 0;
                 for (uint32_t bit = 0; bit < l; ++bit) if ((t >> bit) & 1) r |= 1u << (l - 1 - bit);
-                yp[(size_t)p * Tn + t] = pw[r];
+                yp[(lev * points + p) * 256 + t] = pw[r];
             }
             fe y2 = ycur[p];
             for (uint32_t s = 0; s < l; ++s) y2 = fe_sqr(y2);
             ycur[p] = y2;
         }
-        SP_HIP_CHECK(hipMemcpyAsync(yp_dev, yp.data(), yp.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp is a local vector
+    }
+    SP_HIP_CHECK(hipMemcpyAsync(yp_dev, yp.data(), yp.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+    // one compacted table per level: the kernel indexes yp[p * T + t]
+    for (size_t lev = 0; lev < ls.size(); ++lev) {
+        const uint32_t l = ls[lev], Tn = 1u << l;
+        if (Tn != 256)
+            for (uint32_t p = 1; p < points; ++p)
+                SP_HIP_CHECK(hipMemcpyAsync(yp_dev + lev * points * 256 + (size_t)p * Tn, yp_dev + (lev * points + p) * 256, sizeof(fe) * Tn,
+                                            hipMemcpyDeviceToDevice, c->stream));
         fe* outb = bufs[which];
-        SP_TRY(fold_eval_level(c->stream, in, in_stride, in_points, M, l, yp_dev, points, vectors, outb));
-        SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp_dev is rewritten by the next level
+        SP_TRY(fold_eval_level(c->stream, in, in_stride, in_points, M, l, yp_dev + lev * points * 256, points, vectors, outb));
         M >>= l;
         in = outb; in_stride = (uint64_t)points * M; in_points = points;
         which ^= 1;
     }
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp is a local vector
     out.resize((size_t)vectors * points);
     SP_HIP_CHECK(hipMemcpyAsync(out.data(), in, out.size() * sizeof(fe), hipMemcpyDeviceToHost, c->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c->stream));

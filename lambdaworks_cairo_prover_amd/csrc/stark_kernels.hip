@@ -357,18 +357,16 @@ __global__ void __launch_bounds__(256) fold_eval_kernel(const fe* in, uint64_t i
                                                         const fe* yp, uint32_t points, fe* out) {
     uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= Mq) return;
-    uint32_t v = blockIdx.y;
-    for (uint32_t p = 0; p < points; ++p) {
-        const fe* src = in + (uint64_t)v * in_vec_stride + (in_points > 1 ? (uint64_t)p * Mq * T : 0);
-        fe acc = fe_zero();
-        for (uint32_t t = 0; t < T; ++t) acc = fe_add(acc, fe_mul(sk_ld(src + (uint64_t)t * Mq + q), yp[p * T + t]));
-        sk_st(out + ((uint64_t)v * points + p) * Mq + q, acc);
-    }
+    const uint32_t v = blockIdx.y, p = blockIdx.z;
+    const fe* src = in + (uint64_t)v * in_vec_stride + (in_points > 1 ? (uint64_t)p * Mq * T : 0);
+    fe acc = fe_zero();
+    for (uint32_t t = 0; t < T; ++t) acc = fe_add(acc, fe_mul(sk_ld(src + (uint64_t)t * Mq + q), yp[p * T + t]));
+    sk_st(out + ((uint64_t)v * points + p) * Mq + q, acc);
 }
 int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32_t in_points, uint64_t M, uint32_t l,
                     const fe* yp, uint32_t points, uint32_t vectors, fe* out) {
     uint64_t Mq = M >> l;
-    dim3 grid((unsigned)((Mq + 255) / 256), vectors);
+    dim3 grid((unsigned)((Mq + 255) / 256), vectors, points);
     hipLaunchKernelGGL(fold_eval_kernel, grid, dim3(256), 0, st, in, in_vec_stride, in_points, Mq, 1u << l, yp, points, out);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""HBM traffic per NTT from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
+/opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/<name>.json, the file bench.py reads for roofline.traffic.
+usage: pmc_traffic.py <fetch_results.db> <write_results.db> <log_n> <out.json>"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    q = "select kernel_name, count(*), sum(value) from counters_collection where counter_name = ? group by kernel_name"
+    return {name: (cnt, tot) for name, cnt, tot in db.execute(q, (counter,))}
+
+
+def main():
+    fpath, wpath, log_n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    f, w = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
+    passes = {k: v for k, v in f.items() if "ntt_pass_kernel" in k}
+    # every NTT of the run launches each of its pass kernels the same number of times: launches of the first pass = NTTs
+    ntts = min(c for c, _ in passes.values())
+    launches = sum(c for c, _ in passes.values()) / ntts
+    fetch_kb = sum(t for _, t in passes.values()) / ntts
+    write_kb = sum(t for k, (_, t) in w.items() if "ntt_pass_kernel" in k) / ntts
+    res = {
+        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --proof 0 --steps 20 --warmup 3`",
+        "log_n": log_n,
+        "launches_per_ntt": launches,
+        "fetch_size_kb_per_ntt": fetch_kb,
+        "write_size_kb_per_ntt": write_kb,
+        "correction": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE as reported",
+        "traffic_bytes_per_ntt": (2 * fetch_kb + write_kb) * 1024,
+        "per_kernel_fetch_kb_avg": {k: t / c for k, (c, t) in passes.items()},
+    }
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
