@@ -222,6 +222,28 @@ SP_HD fe fe_canonical_lazy(const fe& a) {
     return r;
 }
 
+// a - b + k p  for k in {2, 4, 8}  (b < k p, a < k p  ->  result in (0, 2 k p); exact modulo 2^256)
+SP_HD fe fe_sub_add_kp(const fe& a, const fe& b, uint32_t k) {
+    fe d;
+    unsigned br = 0, bo;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { d.v[i] = SP_SUBC(a.v[i], b.v[i], br, bo); br = bo; }
+    fe r;
+    unsigned c = 0, co;
+    r.v[0] = SP_ADDC(d.v[0], k, c, co); c = co;
+#pragma unroll
+    for (int i = 1; i < 6; ++i) { r.v[i] = SP_ADDC(d.v[i], 0u, c, co); c = co; }
+    r.v[6] = SP_ADDC(d.v[6], 17u * k, c, co); c = co;
+    r.v[7] = SP_ADDC(d.v[7], k << 27, c, co);
+    return r;
+}
+// -1 in Montgomery form: p - (R mod p)
+SP_HD fe fe_neg_one() {
+    fe r = fe_zero();
+    r.v[0] = 0x20u; r.v[6] = 0x220u;
+    return r;
+}
+
 SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 
 // canonical integer (little-endian limbs, < p) -> Montgomery

@@ -1,14 +1,13 @@
-// Stark252 NTT engine for gfx950: four-step passes through LDS, radix-2 stages inside a pass.
+// Stark252 NTT engine for gfx950: multi-stage passes through LDS, radix-2 stages inside a pass.
 //
 // Replaces the lambdaworks FFTPoly calls of the reference: Polynomial::interpolate_fft (src/starks/trace.rs:107),
 // interpolate_offset_fft (src/starks/constraints/evaluation_table.rs:32), evaluate_offset_fft
 // (src/starks/prover.rs:117, src/starks/fri/fri_commitment.rs:36).
 //
-// Two pass structures (DESIGN.md "NTT"):
-//   DIT pass  : [x w_M^E(pos)] -> radix-2 DIT stages over R = 2^r elements at stride 2^s   (bit-reversed in -> natural out)
-//   DIF pass  : radix-2 DIF stages -> [x w_M^-E(pos)]                                        (natural in -> bit-reversed out)
-// A size-2^k transform is a chain of passes with s = 0, r1, r1+r2, ... ; the s = 0 pass works on contiguous tiles,
-// the others on tiles of R strided rows x G adjacent elements (G*32 B contiguous per row -> coalesced).
+// A size-2^k transform is a chain of passes; each pass runs r consecutive radix-2 stages of the plain in-place algorithm
+// (Cooley-Tukey DIT: bit-reversed in -> natural out; Gentleman-Sande DIF: natural in -> bit-reversed out) on tiles staged
+// in LDS.  The s = 0 pass works on contiguous tiles, the others on tiles of R = 2^r rows at stride 2^s x G adjacent
+// elements (G*32 B contiguous per row -> coalesced) together with the twiddles of exactly those butterflies.
 // All memory orders are chosen so the prover never needs a bit-reversal pass: iNTT leaves coefficients
 // bit-reversed, the LDE consumes them bit-reversed and emits natural order.
 #pragma once
@@ -28,20 +27,17 @@ struct NttPassArgs {
     const fe* src;
     fe* dst;
     uint64_t src_vec_stride, dst_vec_stride;  // elements between consecutive vectors of the batch
-    const fe* small_tw;   // w_R^(+-e), e in [0, R/2)   (direction chosen by the host)
-    const fe* big_tw;     // w_M^e, e in [0, M/2)       (forward roots; inverse obtained by index negation)
+    const fe* small_tw;   // s = 0 pass: w_R^(+-e), e in [0, R/2)   (direction chosen by the host)
+    const fe* big_tw;     // strided passes: w_M^e, e in [0, M/2)  (forward roots; the inverse butterfly uses w^-e = -w^(M/2-e))
     const fe* post_table; // DIF only, nullable: multiply the element stored at position pos by post_table[pos]
     const fe* scalar;     // nullable: multiply every stored element by *scalar (device pointer)
     uint32_t logM;        // transform size (dst vector length 2^logM)
     uint32_t s, r, g;     // this pass: stride 2^s, R = 2^r rows, G = 2^g adjacent elements per row
-    uint32_t s_prev;      // stride (log2) of the neighbouring lower pass (inter-pass twiddle), used when s > 0
-    uint32_t big_neg;     // 1: use w_M^(-E) (inverse transform)
     uint32_t log_expand;  // EXPAND load: src index = pos >> log_expand (zero-padded/replicated LDE input)
     // Coset sharding across GPUs (LDE only): this rank holds the cosets c = c_loc * 2^shard_log + shard_rank of the
     // 2^(log_expand + shard_log) cosets; arrays are local (2^(logM - shard_log) elements), twiddles use global indices.
     uint32_t shard_log, shard_rank;
-    // 1 on every pass but the last one of a transform: the stored data stays lazily reduced ([0, 4p) after a DIT pass,
-    // [0, 2p) after a DIF pass); 0: the pass stores canonical values.
+    // 1 on every pass but the last one of a transform: the stored data is only brought below 2p; 0: canonical values.
     uint32_t weak_out;
     uint32_t batch;       // vectors per launch (filled in by the launcher)
     uint32_t xcd_map;     // 1: XCD-aware block -> (tile, vector) mapping (needs tiles % 8 == 0)

@@ -34,40 +34,37 @@ __device__ __forceinline__ void lds_st(uint4* lo, uint4* hi, uint32_t i, const f
 }
 __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
-// w_M^e from the half table (e in [0, M))
-__device__ __forceinline__ fe big_root(const fe* tw, uint32_t e, uint32_t logM) {
-    uint32_t half = 1u << (logM - 1);
-    fe w = ld_fe(tw + (e & (half - 1)));
-    return (e & half) ? fe_neg(w) : w;
-}
-
-// One pass.  Template flags are compile-time so each instantiation keeps only its own address math.
-//  * DIT passes are plain Cooley-Tukey stages a.s+1 .. a.s+r of the size-2^logM transform on a tile of R rows at stride
-//    2^s: the s = 0 pass uses the pass-local table w_R^e, a strided pass stages the global twiddles of its own
-//    butterflies (one table entry per element) in LDS, so there is no inter-pass twiddle product.  Reduction is deferred
-//    (fp.h): pass input < 2p, no correction inside the pass, fe_reduce_lazy_2p on the store of every pass but the last,
-//    fe_canonical_lazy on the last.
-//  * DIF passes are four-step: radix-2 DIF stages with w_R^-e, then the inter-pass twiddle w_M^-E(pos); data in [0, 2p)
-//    between stages and passes (a.weak_out = 1), canonical after the last pass.
+// One pass = r consecutive radix-2 stages of the plain in-place transform of size 2^logM on a tile of R = 2^r rows at
+// stride 2^s (G adjacent elements per row).  Template flags are compile-time so each instantiation keeps only its own
+// address math.
+//  * DIT (Cooley-Tukey, bit-reversed in -> natural out): stage J = a.s + j pairs positions P and P + 2^(J-1) and computes
+//    (u, v) -> (u + v w, u - v w) with w = w_(2^J)^(P mod 2^(J-1)).
+//  * DIF (Gentleman-Sande, natural in -> bit-reversed out, inverse roots, unscaled): the same pairs in the opposite stage
+//    order, (x, y) -> (x + y, (x - y) w^-1).  w^-1 = -w_(2^J)^(2^(J-1) - e), so the butterfly computes (y - x) times a
+//    forward-table entry (and times -1 for e = 0): one table serves both directions.
+//  * Twiddles: the s = 0 pass uses the pass-local table w_R^(+-e) (R/2 entries in LDS).  A strided pass stages the twiddles
+//    of its own butterflies: w_M^(((i << a.s) + column) << (logM - a.s - j)), i = row mod 2^(j-1); the global column of
+//    local column c is (c << shard_log) | shard_rank.  Stages j < r go to LDS (entry (2^(j-1) - 1 + i) * G + gl), the
+//    twiddles of stage r serve one butterfly each and go straight to registers.  There is no inter-pass twiddle product.
+//  * Deferred reduction (fp.h): p > 2^251, so every 256-bit value is < 32p.  Pass input < 2p.  DIT: t = v w < 2p and the
+//    outputs u + t, u - t + 2p grow by 2p per stage - no correction for the <= 10 stages of a pass.  DIF: x + y doubles
+//    the bound, (y - x + kb p) w is < 2p again; the sum is brought back below 2p every third stage (kb = 2, 4, 8).
+//    Stores: fe_reduce_lazy_2p on every pass but the last of a transform (a.weak_out), fe_canonical_lazy on the last.
 // Twiddles are always canonical, so every product is fe_mul_lazy(data, twiddle).
 template <bool DIF, int LOADM, int STOREM, bool CONTIG>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t r = a.r, g = a.g;
-    const uint32_t s = a.s - a.shard_log;  // local (address) stride; a.s / a.s_prev / a.logM stay global for the twiddles
+    const uint32_t s = a.s - a.shard_log;  // local (address) stride; a.s / a.logM stay global for the twiddles
     const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
+    constexpr bool GLOBAL_TW = !CONTIG;
     uint4* Llo = smem;
     uint4* Lhi = smem + TILE;
-    // twiddles (two planes): R/2 entries w_R^e of the pass-local table (contiguous and DIF passes), or, for the strided
-    // DIT passes, the global twiddles of this tile's butterflies of the stages j < r: stage j, butterfly row i, column gl
-    // at (2^(j-1) - 1 + i) * G + gl (TILE/2 - G entries).  The twiddles of stage r serve one butterfly each and go
-    // straight to registers.
-    constexpr bool GLOBAL_TW = !DIF && !CONTIG;
     uint4* Twl = smem + 2 * TILE;
     uint4* Twh = Twl + (GLOBAL_TW ? (TILE >> 1) : (R >> 1));
     const uint32_t tid = threadIdx.x;
-    // vector index fastest: consecutive work-groups run the same tile of different vectors, so the inter-pass twiddles
-    // they gather (the same table entries for every vector) are L2 hits for all but the first of them
+    // vector index fastest: consecutive work-groups run the same tile of different vectors, so the twiddles they gather
+    // (the same table entries for every vector) are L2 hits for all but the first of them.
     // Work-groups are dealt round-robin to the 8 XCDs (each with its own L2): pin tile t to XCD t mod 8 and let that XCD
     // run the tile for all vectors back to back  (id = slot * 8 + t % 8, slot = (t / 8) * batch + vec).
     uint32_t tile, vec;
@@ -91,38 +88,35 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         lo0 = (tile & (lo_tiles - 1)) << g;
         hi = tile >> (s - g);
     }
-    // plain Cooley-Tukey twiddles (strided DIT passes): the butterfly of global stage J = a.s + j whose upper element sits at
-    // global position P uses w_(2^J)^(P mod 2^(J-1)) = w_M^(((i << a.s) + column) << (logM - a.s - j)), i = row mod 2^(j-1);
-    // the global column of local column c is (c << shard_log) | shard_rank.  No separate inter-pass twiddle product.
-    auto global_tw = [&](uint32_t jm1, uint32_t i, uint32_t gl) -> const fe* {
+    auto global_tw = [&](uint32_t jm1, uint32_t i, uint32_t gl) -> fe {
         const uint32_t col = ((lo0 + gl) << a.shard_log) | a.shard_rank;
-        return a.big_tw + (((i << a.s) + col) << (logM - a.s - jm1 - 1u));
+        const uint32_t e = ((i << a.s) + col) << (logM - a.s - jm1 - 1u);
+        if (!DIF) return ld_fe(a.big_tw + e);
+        if (e == 0) return fe_neg_one();
+        return ld_fe(a.big_tw + ((1u << (logM - 1)) - e));
     };
-    constexpr int TW_REGS = GLOBAL_TW ? (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS : 1;   // butterflies per thread and stage
-    fe tw_last[TW_REGS];
+    constexpr int BPT = (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS;   // butterflies per thread and stage (at most)
+    fe tw_last[GLOBAL_TW ? BPT : 1];
     if (GLOBAL_TW) {
         if (r >= 1) {
 #pragma unroll
-            for (int q = 0; q < TW_REGS; ++q) {
+            for (int q = 0; q < BPT; ++q) {
                 const uint32_t b = tid + q * NTT_THREADS;
-                if (b < (TILE >> 1)) tw_last[q] = ld_fe(global_tw(r - 1, b >> g, b & (G - 1)));
+                if (b < (TILE >> 1)) tw_last[q] = global_tw(r - 1, b >> g, b & (G - 1));
             }
-        }
-        constexpr int U = (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS;
-        const uint32_t cnt = (TILE >> 1) - G;   // (meaningful for r >= 1 only)
-        if (r >= 1) {
-            fe tmp[U];
+            const uint32_t cnt = (TILE >> 1) - G;
+            fe tmp[BPT];
 #pragma unroll
-            for (int q = 0; q < U; ++q) {
+            for (int q = 0; q < BPT; ++q) {
                 const uint32_t x = tid + q * NTT_THREADS;
                 if (x < cnt) {
                     const uint32_t y = (x >> g) + 1u;
                     const uint32_t jm1 = 31u - __clz(y);                 // j - 1
-                    tmp[q] = ld_fe(global_tw(jm1, y - (1u << jm1), x & (G - 1)));
+                    tmp[q] = global_tw(jm1, y - (1u << jm1), x & (G - 1));
                 }
             }
 #pragma unroll
-            for (int q = 0; q < U; ++q) {
+            for (int q = 0; q < BPT; ++q) {
                 const uint32_t x = tid + q * NTT_THREADS;
                 if (x < cnt) lds_st(Twl, Twh, x, tmp[q]);
             }
@@ -140,14 +134,6 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         return (hi << (s + r)) + (t << s) + lo0 + gl;
     };
     auto lidx = [&](uint32_t t, uint32_t gl) -> uint32_t { return CONTIG ? (gl << r) + t : (t << g) + gl; };
-    auto twiddle_exp = [&](uint32_t pos) -> uint32_t {
-        // pos is the LOCAL position; bits above the stride are identical in the global index
-        uint32_t u;
-        if (LOADM == NTT_LOAD_EXPAND) u = ((pos & ((1u << s) - 1u)) << a.shard_log) + a.shard_rank;  // global coset index
-        else u = (pos >> (a.s_prev - a.shard_log)) & ((1u << (a.s - a.s_prev)) - 1u);
-        uint32_t e = (bitrev(pos >> s, logM - a.s) * u) << a.s_prev;
-        return a.big_neg ? ((0u - e) & ((1u << logM) - 1u)) : e;
-    };
 
     // ------------------------------------------------------------------ load
     constexpr int LU = 4;   // loads in flight per thread
@@ -182,59 +168,41 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
 
     // ------------------------------------------------------------------ radix-2 stages
     const uint32_t NB = TILE >> 1;
-    if (!DIF) {
-        for (uint32_t j = 1; j <= r; ++j) {
-            const uint32_t half = 1u << (j - 1);
-            if (GLOBAL_TW && j == r) {
+    uint32_t kb = 2;   // DIF: every element is < kb * p
+    for (uint32_t jj = 1; jj <= r; ++jj) {
+        const uint32_t j = DIF ? r + 1 - jj : jj;
+        const uint32_t half = 1u << (j - 1);
+        const bool fold = DIF && kb == 8;   // the sums of this stage would reach 16p: bring them back below 2p
 #pragma unroll
-                for (int q = 0; q < TW_REGS; ++q) {
-                    const uint32_t b = tid + q * NTT_THREADS;
-                    if (b >= NB) continue;
-                    const uint32_t gl = b & (G - 1), bf = b >> g;   // half = R/2: i = bf, t0 = bf
-                    const uint32_t i0 = lidx(bf, gl), i1 = lidx(bf + half, gl);
-                    fe u = lds_ld(Llo, Lhi, i0), v = fe_mul_lazy(lds_ld(Llo, Lhi, i1), tw_last[q]);
-                    lds_st(Llo, Lhi, i0, fe_add_raw(u, v));
-                    lds_st(Llo, Lhi, i1, fe_sub_add_2p(u, v));
-                }
-                __syncthreads();
-                continue;
-            }
-            for (uint32_t b = tid; b < NB; b += NTT_THREADS) {
-                uint32_t bf, gl;
-                if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
-                uint32_t i = bf & (half - 1);
-                uint32_t t0 = ((bf >> (j - 1)) << j) | i;
-                uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
-                // deferred reduction (fp.h): the pass input is < 2p, t = v w is in [0, 2p) whatever v is, and the outputs
-                // u + t and u - t + 2p stay below (2 + 2j) p < 2^256 for the <= 10 stages of a pass
-                fe u = lds_ld(Llo, Lhi, i0), v = lds_ld(Llo, Lhi, i1);
-                if (GLOBAL_TW) v = fe_mul_lazy(v, lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl));
-                else if (j > 1) v = fe_mul_lazy(v, lds_ld(Twl, Twh, i << (r - j)));   // stage 1: w = 1 and v < 2p already
-                lds_st(Llo, Lhi, i0, fe_add_raw(u, v));
-                lds_st(Llo, Lhi, i1, fe_sub_add_2p(u, v));
-            }
-            __syncthreads();
-        }
-    } else {
-        for (uint32_t j = r; j >= 1; --j) {
-            const uint32_t half = 1u << (j - 1);
-            for (uint32_t b = tid; b < NB; b += NTT_THREADS) {
-                uint32_t bf, gl;
-                if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
-                uint32_t i = bf & (half - 1);
-                uint32_t t0 = ((bf >> (j - 1)) << j) | i;
-                uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
-                // x, y in [0, 2p)  ->  x + y mod 2p and (x - y + 2p) w, both in [0, 2p)
-                fe x = lds_ld(Llo, Lhi, i0), y = lds_ld(Llo, Lhi, i1);
-                fe d = fe_sub_add_2p(x, y);
-                uint32_t twi = i << (r - j);
-                if (twi != 0) d = fe_mul_lazy(d, lds_ld(Twl, Twh, twi));
-                else d = fe_reduce_2p(d);
-                lds_st(Llo, Lhi, i0, fe_reduce_2p(fe_add_raw(x, y)));
+        for (int q = 0; q < BPT; ++q) {
+            const uint32_t b = tid + q * NTT_THREADS;
+            if (b >= NB) continue;
+            uint32_t bf, gl;
+            if (CONTIG) { bf = b & ((R >> 1) - 1); gl = b >> (r - 1); } else { gl = b & (G - 1); bf = b >> g; }
+            const uint32_t i = bf & (half - 1);
+            const uint32_t t0 = 2u * bf - i;                    // ((bf >> (j-1)) << j) | i
+            const uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
+            fe w;
+            bool has_w = true;
+            if (GLOBAL_TW) { if (j == r) w = tw_last[q]; else w = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl); }
+            else if (j > 1) w = lds_ld(Twl, Twh, i << (r - j));
+            else has_w = false;                                 // w_2^0 = 1
+            fe x = lds_ld(Llo, Lhi, i0), y = lds_ld(Llo, Lhi, i1);
+            if (!DIF) {
+                if (has_w) y = fe_mul_lazy(y, w);               // stage 1 of the s = 0 pass: y < 2p already
+                lds_st(Llo, Lhi, i0, fe_add_raw(x, y));
+                lds_st(Llo, Lhi, i1, fe_sub_add_2p(x, y));
+            } else {
+                fe sum = fe_add_raw(x, y);
+                if (fold) sum = fe_reduce_lazy_2p(sum);
+                fe d = GLOBAL_TW ? fe_sub_add_kp(y, x, kb) : fe_sub_add_kp(x, y, kb);
+                if (has_w) d = fe_mul_lazy(d, w);
+                lds_st(Llo, Lhi, i0, sum);
                 lds_st(Llo, Lhi, i1, d);
             }
-            __syncthreads();
         }
+        kb = fold ? 2u : 2u * kb;
+        __syncthreads();
     }
 
     // ------------------------------------------------------------------ store
@@ -249,14 +217,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         uint32_t pos = position(t, gl);
         uint32_t didx = pos;
         if (CONTIG && STOREM == NTT_STORE_SCATTER_BITREV) didx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
-        if (DIF && !CONTIG) {
-            uint32_t ex = twiddle_exp(pos);
-            if (ex != 0) x = fe_mul_lazy(x, big_root(a.big_tw, ex, logM));
-        }
         if (DIF && a.post_table) x = fe_mul_lazy(x, ld_fe(a.post_table + didx));
         if (has_scalar) x = fe_mul_lazy(x, scal);
-        if (DIF) { if (!a.weak_out) x = fe_reduce_once(x); }                  // last pass of the transform: canonical
-        else x = a.weak_out ? fe_reduce_lazy_2p(x) : fe_canonical_lazy(x);   // DIT: back below 2p for the next pass
+        x = a.weak_out ? fe_reduce_lazy_2p(x) : fe_canonical_lazy(x);
         st_fe(dst + didx, x);
     }
 }
@@ -363,7 +326,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
     uint32_t tiles = 1u << (a.logM - a.shard_log - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
-    if (!DIF && !CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r
+    if (!CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r
     NttPassArgs b = a;
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
@@ -391,7 +354,7 @@ int NttEngine::launch_pass(bool dif, int lm, int sm, const NttPassArgs& a, uint3
 
 // Builds the pass list for a size-2^k transform. first_contig_max limits the s = 0 pass (gather/scatter passes
 // want G >= 4 rows per tile so that their strided side is coalesced).
-struct PassGeom { int s, r, g, s_prev; };
+struct PassGeom { int s, r, g; };
 // footprint = bytes the whole batched transform touches: beyond the 256 MB infinity cache the strided passes read HBM, where
 // 256-byte rows (8 elements, 1024-element tiles) beat 128-byte rows; cache-resident transforms prefer the smaller tiles
 // (more work-groups in flight).  Measured: single 2^22 NTT 3 % faster with 512-element tiles, the proof's large batches
@@ -401,14 +364,14 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
     static const int tile_small = std::getenv("SP_NTT_TILE_SMALL") ? std::atoi(std::getenv("SP_NTT_TILE_SMALL")) : 9;
     const int min_tile_log = footprint > (256ull << 20) ? tile_big : tile_small;
     std::vector<PassGeom> out;
-    int s = first_stride_log, s_prev = 0;
+    int s = first_stride_log;
     int rem = k - first_stride_log;
     if (rem <= 0) return out;
     if (s == 0) {
         int r1 = std::min(rem, first_contig_max);
         int g = std::min(NTT_TILE_LOG - r1, k - r1);
-        out.push_back({0, r1, g, 0});
-        s_prev = 0; s = r1; rem -= r1;
+        out.push_back({0, r1, g});
+        s = r1; rem -= r1;
     }
     if (rem > 0) {
         int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
@@ -417,8 +380,8 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
             // adjacent elements per row: at least 4 (128 B), more for short passes so that a tile never has fewer
             // than 2^min_tile_log elements (a 2^5-row pass with 4 columns would leave half the work-group idle)
             int g = std::min(std::max(NTT_STRIDED_G_LOG, min_tile_log - take), s);
-            out.push_back({s, take, g, s_prev});
-            s_prev = s; s += take; rem -= take;
+            out.push_back({s, take, g});
+            s += take; rem -= take;
         }
     }
     return out;
@@ -434,7 +397,7 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
         NttPassArgs a{};
         a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i + 1 < geo.size();
         SP_TRY(launch_pass(false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
     }
@@ -447,14 +410,14 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
     // beyond one tile the contiguous pass is kept short (2^7 rows x 8 contiguous runs): a 2^10-row pass stages a 16 KB
     // twiddle table per 32 KB tile and fits only three work-groups per CU (measured 55 % of the strided passes' rate)
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : 7, ((uint64_t)batch << k) * sizeof(fe));
-    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    if (geo.empty()) geo.push_back({0, 0, 0});
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];
         NttPassArgs a{};
         a.src = (src && i + 1 == geo.size()) ? src : data;  // the first pass executed may read another array (same stride)
         a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
-        a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i != 0;
         if (i == 0) a.post_table = post_table;
         SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
@@ -466,7 +429,7 @@ int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, ui
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch << k) * sizeof(fe));
-    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    if (geo.empty()) geo.push_back({0, 0, 0});
     bool first = true;
     // ping-pong: pass 1 src -> dst (gather, must be out of place); if final_dst is given (same stride as src), pass 2
     // writes dst -> final_dst and later passes run in place there, so the result lands in final_dst without a copy.
@@ -480,7 +443,7 @@ int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, ui
         a.src_vec_stride = cur_stride; a.dst_vec_stride = out_stride;
         cur = out; cur_stride = out_stride; ++pi;
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = pi < geo.size();
         SP_TRY(launch_pass(false, first ? NTT_LOAD_GATHER_BITREV : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
         first = false;
@@ -497,7 +460,7 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
     const fe* big = nullptr;
     SP_TRY(roots(k, &big));
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch << k) * sizeof(fe));
-    if (geo.empty()) geo.push_back({0, 0, 0, 0});
+    if (geo.empty()) geo.push_back({0, 0, 0});
     if (!d_scalar_) SP_HIP_CHECK(hipMalloc(&d_scalar_, sizeof(fe)));
     fe ninv = fe_inv(fe_from_u64(1ULL << k));
     SP_HIP_CHECK(hipMemcpyAsync(d_scalar_, &ninv, sizeof(fe), hipMemcpyHostToDevice, stream_));
@@ -513,7 +476,7 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
         a.dst = (i == 0) ? data : tmp;
         a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
-        a.big_tw = big; a.big_neg = 1; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g; a.s_prev = p.s_prev;
+        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i != 0;
         int sm = NTT_STORE_INPLACE;
         if (i == 0) { sm = NTT_STORE_SCATTER_BITREV; a.scalar = d_scalar_; }
@@ -535,7 +498,7 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
     SP_TRY(roots(K, &big));
     std::vector<PassGeom> geo = geometry(K, logb, NTT_MAX_CONTIG_LOG, ((uint64_t)batch << (K - shard_log)) * sizeof(fe));
     if (geo.empty()) {  // k == 0: constant polynomial replicated
-        geo.push_back({logb, 0, std::min(logb, NTT_STRIDED_G_LOG), 0});
+        geo.push_back({logb, 0, std::min(logb, NTT_STRIDED_G_LOG)});
     }
     bool first = true;
     size_t pi = 0;
@@ -545,7 +508,7 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
         a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
         a.weak_out = ++pi < geo.size();
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.s_prev = p.s_prev; a.log_expand = logb;
+        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.log_expand = logb;
         a.shard_log = (uint32_t)shard_log; a.shard_rank = (uint32_t)shard_rank;
         a.g = (uint32_t)std::min<int>(p.g, p.s - shard_log);  // adjacent elements per row cannot exceed the local stride
         SP_TRY(launch_pass(false, first ? NTT_LOAD_EXPAND : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
