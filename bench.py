@@ -44,6 +44,62 @@ def cpu_baseline(log_n=22, reps=3):
             "sample": f"{reps} x forward NTT 2^{log_n} through oracle_ntt (includes 32-byte BE codec), single thread"}
 
 
+VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
+
+
+def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
+    """The hash passes (BASELINE north_star: 'achieved HBM GB/s against the chip's peak for the NTT and hash passes'):
+    one batched Keccak-256 Merkle commitment of the configs[2] main-trace shape - 2^23 leaves of 34 field elements read
+    from the column-major LDE in HBM, all 2^24 - 1 nodes written - timed with HIP events on the context stream."""
+    n = 1 << log_leaves
+    data = torch.randint(0, 2**31 - 1, (cols, n, 8), dtype=torch.int32, device=dev)   # any residues: hashed after Montgomery -> canonical
+    data[..., 7] &= 0x07FFFFFF
+    nodes = torch.empty((2 * n - 1, 32), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.merkle_build_dev(data.data_ptr(), n, cols, n, nodes.data_ptr())
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(reps):
+        ctx.merkle_build_dev(data.data_ptr(), n, cols, n, nodes.data_ptr())
+    ms = ctx.timer_stop() / reps
+    ctx.sync()
+    algo_bytes = n * (32 * cols + 64)                         # SURVEY.md section 8(d): leaf bytes read + 32 B per node written (+ re-read)
+    perms = n * ((32 * cols + 1 + 135) // 136) + (n - 1)
+    achieved = algo_bytes / (ms * 1e-3) / 1e9
+    del data, nodes
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "kernel": "leaf_hash_kernel + node_hash levels of one batched Merkle build", "avg_launch_ms": ms,
+            "workload": f"2^{log_leaves} leaves x {cols} field elements (configs[2] main-trace commitment)",
+            "keccak_f_per_s": perms / (ms * 1e-3), "valu_ceiling_keccak_f_per_s": VALU_KECCAK_CEILING,
+            "valu_frac": perms / (ms * 1e-3) / VALU_KECCAK_CEILING}
+
+
+def cpu_proof_baseline(api, ctx):
+    """The CPU oracle's whole prover (OpenMP over columns / LDE points, the reference's rayon decomposition) on a bounded
+    sample of the proof workload - the same Cairo fibonacci program at 2^14 trace rows, same options as configs[2] - next to
+    the device prover on that very input; the two proofs must be the same bytes."""
+    import ctypes
+    import oracle_lib as oracle
+    cores = os.cpu_count() or 1
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        cores = 1
+    run = api.CairoRun.fibonacci(2330)
+    trace = run.main_trace()
+    opts = (8, 80, 3, 20)
+    t0 = time.perf_counter()
+    want = oracle.cairo_prove(trace, run.public_inputs_c, opts)
+    cpu_ms = (time.perf_counter() - t0) * 1e3
+    gpu_ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = ctx.cairo_prove(trace, run.public_inputs_c, api.ProofOptions(*opts))
+        gpu_ms.append((time.perf_counter() - t0) * 1e3)
+    return {"sample": f"whole proof, Cairo fibonacci trace {run.n_rows} rows x 52 columns, blowup 8, 80 queries, grinding 20",
+            "cpu_ms": cpu_ms, "cores": cores, "kind": "port", "gpu_ms_same_input": min(gpu_ms), "identical_bytes": got == want}
+
+
 def proof_benchmark(api, ctx, args, world, dist, force_rccl=False):
     """Whole-proof generation (BASELINE configs[2] shape by default: fib trace 2^20 rows, blowup 8, 80 queries, grinding 20)
     on the coset-sharded device prover; with N > 1 ranks the shards exchange through the library's RCCL communicator."""
@@ -265,11 +321,13 @@ def main():
                      # the pass kernels are VALU-issue bound: the honest ceiling is the sustained rate
                      # of a registers-only butterfly (mul + add + sub) chain, profiles/r01_mul9_ubench.txt
                      "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING,
-                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING,
-                     # the same, also counting the one product per element at each of the two pass boundaries
-                     # (sustained fe_mul rate 1.86e11/s): time the arithmetic alone needs / time measured
-                     "valu_frac_incl_twiddles": (butterflies / VALU_BUTTERFLY_CEILING + 2 * n / VALU_MUL_CEILING) / (avg_ms * 1e-3)},
+                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING},
     }
+    if rank == 0:
+        try:
+            out["roofline_merkle"] = merkle_roofline(torch, ctx, dev)
+        except Exception as e:
+            out["roofline_merkle"] = {"error": repr(e)}
     if args.proof != 0:
         try:
             if world == 1 and not args.proof_isolated:
@@ -280,6 +338,10 @@ def main():
             out["proof"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
+        try:
+            out["cpu_baseline"]["proof"] = cpu_proof_baseline(api, ctx)
+        except Exception as e:
+            out["cpu_baseline"]["proof"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()

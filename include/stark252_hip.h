@@ -103,6 +103,13 @@ int sp_lde(sp_ctx* ctx, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32
 int sp_merkle_build(sp_ctx* ctx, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf,
                     uint8_t root_out[32], uint8_t* nodes_out);
 
+/* MerkleTree::build (prover.rs:96-104 batch_commit, fri_commitment.rs:39) on device memory, for bench.py and callers that
+ * already hold the evaluations in HBM: `fe_per_leaf` columns in the DEVICE layout, column j at cols_dev + j*col_stride*32,
+ * leaf i = Keccak-256 of the canonical big-endian encodings of column 0..fe_per_leaf-1 at row i.  nodes_dev receives the
+ * 2*n_leaves - 1 digests in lambdaworks order (root first).  Asynchronous on the context stream; sp_sync() to wait. */
+int sp_merkle_build_dev(sp_ctx* ctx, const void* cols_dev, uint64_t n_leaves, uint32_t fe_per_leaf, uint64_t col_stride,
+                        void* nodes_dev);
+
 /* FieldElement::inplace_batch_inverse (constraints/evaluator.rs:69,171; cairo/air.rs:540,561). */
 int sp_batch_inverse(sp_ctx* ctx, uint8_t* data, uint64_t n);
 

@@ -103,6 +103,11 @@ class Context:
                                         _u8p(nodes) if want_nodes else None))
         return (root.tobytes(), nodes) if want_nodes else root.tobytes()
 
+    def merkle_build_dev(self, cols_ptr, n_leaves, fe_per_leaf, col_stride, nodes_ptr):
+        """sp_merkle_build_dev: column-major device-layout columns -> (2n-1) x 32-byte nodes on the device (asynchronous)."""
+        check(self._lib.sp_merkle_build_dev(self._h, ctypes.c_void_p(cols_ptr), ctypes.c_uint64(n_leaves), ctypes.c_uint32(fe_per_leaf),
+                                            ctypes.c_uint64(col_stride), ctypes.c_void_p(nodes_ptr)))
+
     def batch_inverse(self, data):
         a = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32).copy()
         check(self._lib.sp_batch_inverse(self._h, _u8p(a), ctypes.c_uint64(a.shape[0])))

@@ -266,6 +266,19 @@ int sp_merkle_build(sp_ctx* c, const uint8_t* leaves, uint64_t n_leaves, uint32_
     return SP_OK;
 }
 
+int sp_merkle_build_dev(sp_ctx* c, const void* cols_dev, uint64_t n_leaves, uint32_t fe_per_leaf, uint64_t col_stride, void* nodes_dev) {
+    if (!c || !cols_dev || !nodes_dev || fe_per_leaf == 0 || col_stride < n_leaves) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    if (sp_log2_exact(n_leaves) < 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
+    SP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+    int rc = merkle_hash_leaves(c->stream, reinterpret_cast<const fe*>(cols_dev), col_stride, fe_per_leaf, n_leaves, reinterpret_cast<digest32*>(nodes_dev));
+    if (rc == SP_OK) rc = merkle_reduce(c->stream, reinterpret_cast<digest32*>(nodes_dev), n_leaves);
+    SP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+    if (rc != SP_OK) return rc;
+    c->last_pending = true;
+    return SP_OK;
+}
+
 int sp_batch_inverse(sp_ctx* c, uint8_t* data, uint64_t n) {
     if (!c || !data) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c->device));

@@ -139,6 +139,30 @@ def test_ntt_dev_batched_device_entry_point(hip_ctx, oracle, k, batch):
         d.free()
 
 
+@pytest.mark.parametrize("k,width", [(6, 1), (11, 2), (13, 34)])
+def test_merkle_build_dev_device_entry_point(hip_ctx, oracle, k, width):
+    """sp_merkle_build_dev (the entry point bench.py times for the hash passes): column-major device-layout columns in,
+    every node of the tree out - the same nodes as the oracle's MerkleTree::build over the same rows."""
+    n = 1 << k
+    rng = np.random.default_rng(7 * k + width)
+    cols = [api.felts_to_bytes([int(x) for x in rng.integers(0, 2**62, size=n)] if j % 3 else
+                               [random.Random(j * 1000 + i).randrange(api.P) for i in range(n)]) for j in range(width)]
+    dev_layout = np.ascontiguousarray(np.concatenate([api.fe_to_device(c) for c in cols]))
+    d = _HipBuffer(dev_layout)
+    nodes = _HipBuffer(np.zeros((2 * n - 1) * 32, dtype=np.uint8))
+    try:
+        hip_ctx.merkle_build_dev(d.ptr.value, n, width, n, nodes.ptr.value)
+        hip_ctx.sync()
+        got = nodes.to_host().reshape(2 * n - 1, 32)
+        rows = np.stack(cols, axis=1)                      # (n, width, 32)
+        want_root, want_nodes = oracle.merkle_build(rows, want_nodes=True)
+        assert got[0].tobytes() == want_root
+        assert np.array_equal(got, want_nodes)
+    finally:
+        d.free()
+        nodes.free()
+
+
 @pytest.mark.parametrize("k", [13, 18])
 def test_ntt_extreme_values_across_passes(hip_ctx, oracle, k):
     """The passes keep their data lazily reduced ([0, 4p) / [0, 2p)) between stages and passes: inputs at the top of the
