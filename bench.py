@@ -128,12 +128,13 @@ def proof_benchmark(api, ctx, args, world, dist, force_rccl=False):
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
+    rounds_dev = ctx.last_round_ms()
     t0 = time.perf_counter()
     proof_h = ctx.cairo_prove(trace, run.public_inputs_c, opt)
     pcie_ms = (time.perf_counter() - t0) * 1e3
     assert proof_h == proof
     import hashlib
-    return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": ctx.last_round_ms(), "trace_rows": run.n_rows,
+    return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": rounds_dev, "trace_rows": run.n_rows,
             "trace_cols": 52, "blowup": args.proof_blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
             "proof_gen_ms_from_host_buffer": pcie_ms,

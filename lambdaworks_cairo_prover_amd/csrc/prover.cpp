@@ -821,34 +821,53 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(o.aux_paths.data(), p_aux, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(hipMemcpyAsync(o.comp_paths.data(), p_comp, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
     SP_HIP_CHECK(hipStreamSynchronize(st));
-    // FRI layers (reference fri/mod.rs:74-127): index iota mod |D_k| and its symmetric index
+    // FRI layers (reference fri/mod.rs:74-127): index iota mod |D_k| and its symmetric index.  All layers in one go: one
+    // upload of the 2qL indices, the gathers queued back to back into one staging area, one download.
     size_t path_total = 0;
     for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
     o.fri_evals.assign((size_t)q * L, fe_zero()); o.fri_evals_sym.assign((size_t)q * L, fe_zero());
     o.fri_paths.assign((size_t)q * path_total, digest32{}); o.fri_paths_sym.assign((size_t)q * path_total, digest32{});
-    std::vector<fe> ev(q), evs(q);
-    size_t path_off = 0;
+    std::vector<uint64_t> idx((size_t)2 * q * L);
     for (uint32_t k = 0; k < L; ++k) {
         const uint64_t M = N_ >> k;
+        for (uint32_t s = 0; s < q; ++s) { idx[(size_t)2 * q * k + s] = iotas[s] % M; idx[(size_t)2 * q * k + q + s] = (iotas[s] + M / 2) % M; }
+    }
+    off = 0;
+    const size_t need = 3 * 256 + sizeof(uint64_t) * idx.size() + sizeof(fe) * 2 * q * L + sizeof(digest32) * 2 * q * path_total;
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp;   // many queries on a tiny domain: own staging buffer
+    if (need > scratch_elems() * sizeof(fe)) {
+        if (hipMalloc(&tmp.p, need) != hipSuccess) { sp_set_error("open: staging allocation failed"); return SP_E_ALLOC; }
+        base = static_cast<uint8_t*>(tmp.p);
+    }
+    uint64_t* d_idx = (uint64_t*)carve(sizeof(uint64_t) * idx.size());
+    fe* gv = (fe*)carve(sizeof(fe) * 2 * q * L);
+    digest32* gp = (digest32*)carve(sizeof(digest32) * 2 * q * path_total);
+    SP_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    {
+        size_t po = 0;
+        for (uint32_t k = 0; k < L; ++k) {
+            const uint64_t M = N_ >> k;
+            const uint32_t depth = d0 - k;
+            SP_TRY(gather_rows(st, d_fri_evals_[k], M, 1, d_idx + (size_t)2 * q * k, 2 * q, gv + (size_t)2 * q * k));
+            SP_TRY(merkle_gather_paths(st, d_fri_trees_[k], M, d_idx + (size_t)2 * q * k, 2 * q, gp + 2 * q * po));
+            po += depth;
+        }
+    }
+    std::vector<fe> hv((size_t)2 * q * L);
+    std::vector<digest32> hp((size_t)2 * q * path_total);
+    SP_HIP_CHECK(hipMemcpyAsync(hv.data(), gv, sizeof(fe) * hv.size(), hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipMemcpyAsync(hp.data(), gp, sizeof(digest32) * hp.size(), hipMemcpyDeviceToHost, st));
+    SP_HIP_CHECK(hipStreamSynchronize(st));
+    size_t path_off = 0;
+    for (uint32_t k = 0; k < L; ++k) {
         const uint32_t depth = d0 - k;
-        std::vector<uint64_t> idx(2 * q);
-        for (uint32_t s = 0; s < q; ++s) { idx[s] = iotas[s] % M; idx[q + s] = (iotas[s] + M / 2) % M; }
-        off = 0;
-        fe* gv = (fe*)carve(sizeof(fe) * 2 * q);
-        digest32* gp = (digest32*)carve(sizeof(digest32) * 2 * q * depth);
-        SP_HIP_CHECK(hipMemcpyAsync(d_positions_, idx.data(), 2 * q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        SP_TRY(gather_rows(st, d_fri_evals_[k], M, 1, d_positions_, 2 * q, gv));
-        SP_TRY(merkle_gather_paths(st, d_fri_trees_[k], M, d_positions_, 2 * q, gp));
-        std::vector<fe> hv(2 * q);
-        std::vector<digest32> hp((size_t)2 * q * depth);
-        SP_HIP_CHECK(hipMemcpyAsync(hv.data(), gv, sizeof(fe) * 2 * q, hipMemcpyDeviceToHost, st));
-        SP_HIP_CHECK(hipMemcpyAsync(hp.data(), gp, sizeof(digest32) * 2 * q * depth, hipMemcpyDeviceToHost, st));
-        SP_HIP_CHECK(hipStreamSynchronize(st));
+        const fe* v = hv.data() + (size_t)2 * q * k;
+        const digest32* pp = hp.data() + (size_t)2 * q * path_off;
         for (uint32_t s = 0; s < q; ++s) {
-            o.fri_evals[(size_t)s * L + k] = hv[s];
-            o.fri_evals_sym[(size_t)s * L + k] = hv[q + s];
-            std::copy(hp.begin() + (size_t)s * depth, hp.begin() + (size_t)(s + 1) * depth, o.fri_paths.begin() + (size_t)s * path_total + path_off);
-            std::copy(hp.begin() + (size_t)(q + s) * depth, hp.begin() + (size_t)(q + s + 1) * depth, o.fri_paths_sym.begin() + (size_t)s * path_total + path_off);
+            o.fri_evals[(size_t)s * L + k] = v[s];
+            o.fri_evals_sym[(size_t)s * L + k] = v[q + s];
+            std::copy(pp + (size_t)s * depth, pp + (size_t)(s + 1) * depth, o.fri_paths.begin() + (size_t)s * path_total + path_off);
+            std::copy(pp + (size_t)(q + s) * depth, pp + (size_t)(q + s + 1) * depth, o.fri_paths_sym.begin() + (size_t)s * path_total + path_off);
         }
         path_off += depth;
     }
