@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--proof", type=int, default=-1, help="also time whole-proof generation (default: on; N > 1 in child processes)")
     ap.add_argument("--proof-isolated", action="store_true", help="run the proof timing in a child process also for 1 GPU")
-    ap.add_argument("--proof-timeout", type=int, default=420, help="seconds the child processes of the N > 1 proof timing may take")
+    ap.add_argument("--proof-timeout", type=int, default=240, help="seconds the child processes of the N > 1 proof timing may take")
     ap.add_argument("--proof-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--proof-fib", type=int, default=149000, help="fibonacci index of the proved Cairo program (149000 -> 2^20 rows)")
     ap.add_argument("--proof-blowup", type=int, default=8)

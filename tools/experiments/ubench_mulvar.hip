@@ -84,6 +84,37 @@ __device__ __forceinline__ fe mul_pairs(const fe& a, const fe& b) {
     for (int j = 0; j < 8; ++j) r.v[j] = (uint32_t)T[j];
     return r;
 }
+
+// (e) 17 m from shifts and adds instead of a ninth multiply-add per row
+__device__ __forceinline__ fe mul_shift17(const fe& a, const fe& b) {
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t D[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) D[j] = (uint64_t)a.v[i] * b.v[j] + t[j];
+        const uint32_t u0 = (uint32_t)D[0];
+        const uint32_t m = 0u - u0;
+        unsigned c = (u0 != 0), c1, c2, c3;
+#pragma unroll
+        for (int j = 1; j <= 5; ++j) { t[j - 1] = SP_ADDC(D[j], D[j - 1] >> 32, c, c1); c = c1; }
+        const uint32_t m17lo = SP_ADDC(m, m << 4, 0u, c3);
+        const uint32_t m17hi = (m >> 28) + c3;
+        const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
+        t[5] = SP_ADDC(x6, m17lo, 0u, c2);
+        const uint32_t x7 = SP_ADDC(D[7], D[6] >> 32, c1, c1);
+        const uint32_t k7 = m17hi + (m << 27);
+        t[6] = SP_ADDC(x7, k7, c2, c2);
+        const uint32_t x8 = SP_ADDC(D[7] >> 32, m >> 5, c1, c1);
+        t[7] = SP_ADDC(x8, 0u, c2, c2);
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = t[j];
+    return r;
+}
 template <int OP>
 __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
     fe x = in[threadIdx.x & 63], y = in[(threadIdx.x + 7) & 63];
@@ -95,6 +126,7 @@ __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
         else if (OP == 4) x = fe_mul_lazy(x, y);
         else if (OP == 5) x = mul_pairs<1>(x, y);
         else if (OP == 6) x = mul_pairs<0>(x, y);
+        else if (OP == 7) x = mul_shift17(x, y);
     }
     out[blockIdx.x * 256 + threadIdx.x] = x;
 }
@@ -120,5 +152,6 @@ int main() {
     run<0>("fe_mul (canonical result)", d_out, d_in); run<1>("fe_mul lazy (no final subtraction)", d_out, d_in);
     run<2>("64 v_mad_u64_u32 + 128 xor", d_out, d_in); run<3>("fe_add + extra reduce", d_out, d_in);
     run<4>("fp.h fe_mul_lazy", d_out, d_in); run<5>("pairs, volatile zero init", d_out, d_in); run<6>("pairs, hoistable zero init", d_out, d_in);
+    run<7>("17 m by shift and add (64 multiply-adds)", d_out, d_in);
     return 0;
 }
