@@ -28,3 +28,13 @@ static inline int sp_log2_exact(uint64_t n) {
     while ((1ULL << k) < n) ++k;
     return k;
 }
+
+// Order of the LDE evaluations inside a column.  Natural: element i = p(h w_N^i).  Coset-major
+// (the prover's trace and composition columns): the 2^log_bloc cosets this rank holds one after the other, 2^logn rows
+// each; the evaluation with local natural index e = m * b_loc + c_loc sits at c_loc * n + m.
+struct LdeOrder {
+    uint32_t coset_major, log_bloc, logn;
+    SP_HD uint64_t at(uint64_t e) const {
+        return coset_major ? (((e & ((1ULL << log_bloc) - 1ULL)) << logn) | (e >> log_bloc)) : e;
+    }
+};

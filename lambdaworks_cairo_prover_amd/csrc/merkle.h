@@ -13,9 +13,12 @@ struct digest32 { uint64_t w[4]; };
 // Hash `n_leaves` leaves into nodes[n_leaves-1 ..]; leaf i = Keccak256(col_0[i] || col_1[i] || ...) with every
 // element as canonical 32-byte big-endian.  Columns are device arrays in the device fe layout:
 // column j starts at cols + j*col_stride, element i of a column at index i (natural LDE order).
-int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes);
+// `order`: where leaf i's elements sit inside a column (leaves are always in natural order).
+int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes,
+                       LdeOrder order = LdeOrder{0, 0, 0});
 // Same, but the n_leaves digests go to a plain array (coset-sharded commitment: leaves are exchanged before the tree is built).
-int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out);
+int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out,
+                            LdeOrder order = LdeOrder{0, 0, 0});
 // Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves);
 // Sharded reduction (several ranks): this rank's contiguous 1/2^logG of every level down to the level with 2^logG nodes;

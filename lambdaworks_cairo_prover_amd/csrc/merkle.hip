@@ -26,7 +26,7 @@ __device__ __forceinline__ void absorb_block(uint64_t s[25], const uint64_t* blk
 }
 
 __global__ void __launch_bounds__(MK_THREADS) leaf_hash_kernel(const fe* cols, uint64_t col_stride, uint32_t ncols,
-                                                               uint64_t n_leaves, digest32* leaves_out) {
+                                                               uint64_t n_leaves, digest32* leaves_out, LdeOrder order) {
     __shared__ uint64_t blkbuf[MK_THREADS * 17];
     uint64_t i = (uint64_t)blockIdx.x * MK_THREADS + threadIdx.x;
     if (i >= n_leaves) return;
@@ -35,8 +35,9 @@ __global__ void __launch_bounds__(MK_THREADS) leaf_hash_kernel(const fe* cols, u
 #pragma unroll
     for (int k = 0; k < 25; ++k) s[k] = 0;
     uint32_t pos = 0;
+    const uint64_t at = order.at(i);   // coset-major columns: 8 lanes x 8 consecutive rows = 256-byte runs per coset
     for (uint32_t j = 0; j < ncols; ++j) {
-        fe raw = fe_from_mont(mk_ld_fe(cols + (uint64_t)j * col_stride + i));
+        fe raw = fe_from_mont(mk_ld_fe(cols + (uint64_t)j * col_stride + at));
 #pragma unroll
         for (int l = 0; l < 4; ++l) {
             // big-endian bytes of the element, 8 at a time, as a little-endian Keccak lane
@@ -157,18 +158,18 @@ __global__ void gather_paths_kernel(const digest32* nodes, uint64_t n_leaves, ui
     out[(uint64_t)qi * depth + lvl] = nodes[sib];
 }
 
-int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes) {
+int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes, LdeOrder order) {
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || ncols == 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
-    hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1));
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
 
-int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out) {
+int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out, LdeOrder order) {
     if (n_leaves == 0 || ncols == 0) return SP_E_INVALID_ARG;
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
-    hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, leaves_out);
+    hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, leaves_out, order);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }

@@ -31,12 +31,18 @@ struct NttPassArgs {
     const fe* big_tw;     // strided passes: w_M^e, e in [0, M/2)  (forward roots; the inverse butterfly uses w^-e = -w^(M/2-e))
     const fe* post_table; // DIF only, nullable: multiply the element stored at position pos by post_table[pos]
     const fe* scalar;     // nullable: multiply every stored element by *scalar (device pointer)
-    uint32_t logM;        // transform size (dst vector length 2^logM)
-    uint32_t s, r, g;     // this pass: stride 2^s, R = 2^r rows, G = 2^g adjacent elements per row
-    uint32_t log_expand;  // EXPAND load: src index = pos >> log_expand (zero-padded/replicated LDE input)
-    // Coset sharding across GPUs (LDE only): this rank holds the cosets c = c_loc * 2^shard_log + shard_rank of the
-    // 2^(log_expand + shard_log) cosets; arrays are local (2^(logM - shard_log) elements), twiddles use global indices.
-    uint32_t shard_log, shard_rank;
+    uint32_t logM;        // transform size (twiddles are powers of w_(2^logM))
+    uint32_t logL;        // log2 of the array this pass addresses (per vector, per coset in the coset-major LDE)
+    uint32_t s, r, g;     // this pass: LOCAL stride 2^s, R = 2^r rows, G = 2^g adjacent elements per row
+    uint32_t log_expand;  // EXPAND load: src index = pos >> s on the first pass (zero-padded/replicated LDE input)
+    // Local index -> index of the size-2^logM transform: (local << tw_shift) | tw_low.  tw_shift = 0 for whole transforms;
+    // natural-order LDE sharded over 2^shard ranks: tw_shift = shard, tw_low = rank (this rank holds the cosets
+    // c = c_loc * 2^shard + rank interleaved); coset-major LDE: tw_shift = log2(blowup), tw_low = the coset's global index.
+    uint32_t tw_shift, tw_low;
+    // coset-major LDE: launch "vector" = column * coset_count + local coset; arrays at column * vec_stride + coset * coset_stride;
+    // the global coset index is (local coset << shard_log) | tw_low.  coset_count = 0: plain vectors.
+    uint32_t coset_count, shard_log;
+    uint64_t src_coset_stride, dst_coset_stride;
     // 1 on every pass but the last one of a transform: the stored data is only brought below 2p; 0: canonical values.
     uint32_t weak_out;
     uint32_t batch;       // vectors per launch (filled in by the launcher)
@@ -70,6 +76,10 @@ class NttEngine {
     // shard_log/shard_rank: compute only the cosets c = c_loc * 2^shard_log + shard_rank (dst holds n * 2^(logb - shard_log)
     // elements per vector, element (q, c_loc) at q * 2^(logb - shard_log) + c_loc).
     int lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride,
+                        int shard_log = 0, int shard_rank = 0);
+    // The same evaluations in COSET-MAJOR order: dst column v holds 2^(logb - shard_log) arrays of n elements, array c_loc =
+    // the coset c = c_loc * 2^shard_log + shard_rank, element m = p(h w_N^(m b + c))  (natural-order index m b + c).
+    int lde_coset_major(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t src_stride, uint64_t dst_stride,
                         int shard_log = 0, int shard_rank = 0);
 
     // dst[i] = src[i] * base^i * c  (natural index), c nullable. Used by the coset variants of sp_ntt.

@@ -51,17 +51,18 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 //    the bound, (y - x + kb p) w is < 2p again; the sum is brought back below 2p every third stage (kb = 2, 4, 8).
 //    Stores: fe_reduce_lazy_2p on every pass but the last of a transform (a.weak_out), fe_canonical_lazy on the last.
 // Twiddles are always canonical, so every product is fe_mul_lazy(data, twiddle).
-template <bool DIF, int LOADM, int STOREM, bool CONTIG>
+template <bool DIF, int LOADM, int STOREM, bool CONTIG, bool GTW>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
     const uint32_t r = a.r, g = a.g;
-    const uint32_t s = a.s - a.shard_log;  // local (address) stride; a.s / a.logM stay global for the twiddles
+    const uint32_t s = a.s;                // local (address) stride; the twiddles use the global stride s + a.tw_shift
     const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
-    constexpr bool GLOBAL_TW = !CONTIG;
+    constexpr bool GLOBAL_TW = GTW;
+    static_assert(GTW || CONTIG, "strided passes stage the twiddles of their own butterflies");
     uint4* Llo = smem;
     uint4* Lhi = smem + TILE;
     uint4* Twl = smem + 2 * TILE;
-    uint4* Twh = Twl + (GLOBAL_TW ? (TILE >> 1) : (R >> 1));
+    uint4* Twh = Twl + (GLOBAL_TW ? (CONTIG ? R : (TILE >> 1)) : (R >> 1));
     const uint32_t tid = threadIdx.x;
     // vector index fastest: consecutive work-groups run the same tile of different vectors, so the twiddles they gather
     // (the same table entries for every vector) are L2 hits for all but the first of them.
@@ -77,9 +78,22 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         tile = blockIdx.x / a.batch;
         vec = blockIdx.x - tile * a.batch;
     }
-    const fe* src = a.src + (uint64_t)vec * a.src_vec_stride;
-    fe* dst = a.dst + (uint64_t)vec * a.dst_vec_stride;
-    const uint32_t logM = a.logM;
+    // coset-major LDE: "vector" = (column v, local coset cl); every coset is its own array of 2^logL evaluations
+    uint32_t tw_low = a.tw_low;
+    const fe* src;
+    fe* dst;
+    if (a.coset_count) {
+        const uint32_t v = vec / a.coset_count, cl = vec - v * a.coset_count;
+        src = a.src + (uint64_t)v * a.src_vec_stride + (uint64_t)cl * a.src_coset_stride;
+        dst = a.dst + (uint64_t)v * a.dst_vec_stride + (uint64_t)cl * a.dst_coset_stride;
+        tw_low |= cl << a.shard_log;
+    } else {
+        src = a.src + (uint64_t)vec * a.src_vec_stride;
+        dst = a.dst + (uint64_t)vec * a.dst_vec_stride;
+    }
+    const uint32_t logM = a.logM;          // transform size (twiddles)
+    const uint32_t logL = a.logL;          // size of the array this pass addresses
+    const uint32_t sg = s + a.tw_shift;    // global stride of this pass
 
     // tile coordinates
     uint32_t lo0 = 0, hi = 0;
@@ -89,15 +103,21 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         hi = tile >> (s - g);
     }
     auto global_tw = [&](uint32_t jm1, uint32_t i, uint32_t gl) -> fe {
-        const uint32_t col = ((lo0 + gl) << a.shard_log) | a.shard_rank;
-        const uint32_t e = ((i << a.s) + col) << (logM - a.s - jm1 - 1u);
+        const uint32_t col = ((lo0 + gl) << a.tw_shift) | tw_low;
+        const uint32_t e = ((i << sg) + col) << (logM - sg - jm1 - 1u);
         if (!DIF) return ld_fe(a.big_tw + e);
         if (e == 0) return fe_neg_one();
         return ld_fe(a.big_tw + ((1u << (logM - 1)) - e));
     };
     constexpr int BPT = (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS;   // butterflies per thread and stage (at most)
-    fe tw_last[GLOBAL_TW ? BPT : 1];
-    if (GLOBAL_TW) {
+    fe tw_last[(GLOBAL_TW && !CONTIG) ? BPT : 1];
+    if (GLOBAL_TW && CONTIG) {
+        // contiguous tile: the twiddle depends on the row only, entry 2^(j-1) - 1 + i for stage j (R - 1 entries)
+        for (uint32_t x = tid; x + 1 < R; x += NTT_THREADS) {
+            const uint32_t y = x + 1u, jm1 = 31u - __clz(y);
+            lds_st(Twl, Twh, x, global_tw(jm1, y - (1u << jm1), 0u));
+        }
+    } else if (GLOBAL_TW) {
         if (r >= 1) {
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
@@ -128,7 +148,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     auto position = [&](uint32_t t, uint32_t gl) -> uint32_t {
         if (CONTIG) {
             if (LOADM == NTT_LOAD_GATHER_BITREV || STOREM == NTT_STORE_SCATTER_BITREV)
-                return (bitrev((tile << g) + gl, logM - r) << r) + t;   // row whose bit-reversed index is adjacent
+                return (bitrev((tile << g) + gl, logL - r) << r) + t;   // row whose bit-reversed index is adjacent
             return (tile << (r + g)) + (gl << r) + t;
         }
         return (hi << (s + r)) + (t << s) + lo0 + gl;
@@ -150,7 +170,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 xs[q] = ld_fe(src + position(t, gl));
             } else if (CONTIG) {  // gather from the natural-order source: x[rev(pos)]
                 gl = e & (G - 1); t = e >> g;
-                uint32_t sidx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
+                uint32_t sidx = (bitrev(t, r) << (logL - r)) + (tile << g) + gl;
                 xs[q] = ld_fe(src + sidx);
             } else {
                 gl = e & (G - 1); t = e >> g;
@@ -184,7 +204,8 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
             const uint32_t i0 = lidx(t0, gl), i1 = lidx(t0 + half, gl);
             fe w;
             bool has_w = true;
-            if (GLOBAL_TW) { if (j == r) w = tw_last[q]; else w = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl); }
+            if (GLOBAL_TW && CONTIG) w = lds_ld(Twl, Twh, half - 1u + i);
+            else if (GLOBAL_TW) { if (j == r) w = tw_last[q]; else w = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl); }
             else if (j > 1) w = lds_ld(Twl, Twh, i << (r - j));
             else has_w = false;                                 // w_2^0 = 1
             fe x = lds_ld(Llo, Lhi, i0), y = lds_ld(Llo, Lhi, i1);
@@ -216,7 +237,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         fe x = lds_ld(Llo, Lhi, lidx(t, gl));
         uint32_t pos = position(t, gl);
         uint32_t didx = pos;
-        if (CONTIG && STOREM == NTT_STORE_SCATTER_BITREV) didx = (bitrev(t, r) << (logM - r)) + (tile << g) + gl;
+        if (CONTIG && STOREM == NTT_STORE_SCATTER_BITREV) didx = (bitrev(t, r) << (logL - r)) + (tile << g) + gl;
         if (DIF && a.post_table) x = fe_mul_lazy(x, ld_fe(a.post_table + didx));
         if (has_scalar) x = fe_mul_lazy(x, scal);
         x = a.weak_out ? fe_reduce_lazy_2p(x) : fe_canonical_lazy(x);
@@ -321,32 +342,34 @@ int NttEngine::inv_roots_small(int k, const fe** out) {
     return SP_OK;
 }
 
-template <bool DIF, int LM, int SM, bool CONTIG>
+template <bool DIF, int LM, int SM, bool CONTIG, bool GTW>
 static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
-    uint32_t tiles = 1u << (a.logM - a.shard_log - tile_log);
+    uint32_t tiles = 1u << (a.logL - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
     if (!CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r
+    else if (GTW) lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)2 << a.r) * sizeof(uint4);
     NttPassArgs b = a;
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
-    hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
+    hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
 
 int NttEngine::launch_pass(bool dif, int lm, int sm, const NttPassArgs& a, uint32_t batch) {
-    bool contig = a.s == 0;
+    bool contig = a.s == 0 && lm != NTT_LOAD_EXPAND;
     if (!dif) {
-        if (contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true>(stream_, a, batch);
-        if (contig && lm == NTT_LOAD_GATHER_BITREV) return launch_t<false, NTT_LOAD_GATHER_BITREV, NTT_STORE_INPLACE, true>(stream_, a, batch);
-        if (!contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false>(stream_, a, batch);
-        if (!contig && lm == NTT_LOAD_EXPAND) return launch_t<false, NTT_LOAD_EXPAND, NTT_STORE_INPLACE, false>(stream_, a, batch);
+        if (contig && a.coset_count) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true, true>(stream_, a, batch);
+        if (contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true, false>(stream_, a, batch);
+        if (contig && lm == NTT_LOAD_GATHER_BITREV) return launch_t<false, NTT_LOAD_GATHER_BITREV, NTT_STORE_INPLACE, true, false>(stream_, a, batch);
+        if (!contig && lm == NTT_LOAD_INPLACE) return launch_t<false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false, true>(stream_, a, batch);
+        if (!contig && lm == NTT_LOAD_EXPAND) return launch_t<false, NTT_LOAD_EXPAND, NTT_STORE_INPLACE, false, true>(stream_, a, batch);
     } else {
-        if (contig && sm == NTT_STORE_INPLACE) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true>(stream_, a, batch);
-        if (contig && sm == NTT_STORE_SCATTER_BITREV) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_SCATTER_BITREV, true>(stream_, a, batch);
-        if (!contig) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false>(stream_, a, batch);
+        if (contig && sm == NTT_STORE_INPLACE) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, true, false>(stream_, a, batch);
+        if (contig && sm == NTT_STORE_SCATTER_BITREV) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_SCATTER_BITREV, true, false>(stream_, a, batch);
+        if (!contig) return launch_t<true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, false, true>(stream_, a, batch);
     }
     sp_set_error("ntt: unsupported pass mode");
     return SP_E_UNSUPPORTED;
@@ -397,7 +420,7 @@ int NttEngine::dit_bitrev_to_natural(fe* data, int k, uint32_t batch, uint64_t s
         NttPassArgs a{};
         a.src = data; a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
+        a.big_tw = big; a.logM = k; a.logL = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i + 1 < geo.size();
         SP_TRY(launch_pass(false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
     }
@@ -417,7 +440,7 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
         a.src = (src && i + 1 == geo.size()) ? src : data;  // the first pass executed may read another array (same stride)
         a.dst = data; a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
+        a.big_tw = big; a.logM = k; a.logL = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i != 0;
         if (i == 0) a.post_table = post_table;
         SP_TRY(launch_pass(true, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
@@ -443,7 +466,7 @@ int NttEngine::forward_natural(const fe* src, fe* dst, int k, uint32_t batch, ui
         a.src_vec_stride = cur_stride; a.dst_vec_stride = out_stride;
         cur = out; cur_stride = out_stride; ++pi;
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
+        a.big_tw = big; a.logM = k; a.logL = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = pi < geo.size();
         SP_TRY(launch_pass(false, first ? NTT_LOAD_GATHER_BITREV : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
         first = false;
@@ -476,7 +499,7 @@ int NttEngine::inverse_natural(fe* data, fe* tmp, int k, uint32_t batch, uint64_
         a.dst = (i == 0) ? data : tmp;
         a.src_vec_stride = a.dst_vec_stride = stride;
         SP_TRY(inv_roots_small(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = k; a.s = p.s; a.r = p.r; a.g = p.g;
+        a.big_tw = big; a.logM = k; a.logL = k; a.s = p.s; a.r = p.r; a.g = p.g;
         a.weak_out = i != 0;
         int sm = NTT_STORE_INPLACE;
         if (i == 0) { sm = NTT_STORE_SCATTER_BITREV; a.scalar = d_scalar_; }
@@ -508,10 +531,40 @@ int NttEngine::lde_from_bitrev(const fe* coeffs, fe* dst, int k, int logb, uint3
         a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
         a.weak_out = ++pi < geo.size();
         SP_TRY(roots(p.r, &a.small_tw));
-        a.big_tw = big; a.logM = K; a.s = p.s; a.r = p.r; a.log_expand = logb;
-        a.shard_log = (uint32_t)shard_log; a.shard_rank = (uint32_t)shard_rank;
+        a.big_tw = big; a.logM = K; a.logL = (uint32_t)(K - shard_log); a.s = (uint32_t)(p.s - shard_log); a.r = p.r; a.log_expand = logb;
+        a.tw_shift = (uint32_t)shard_log; a.tw_low = (uint32_t)shard_rank;   // local index -> global: (index << shard_log) | rank
         a.g = (uint32_t)std::min<int>(p.g, p.s - shard_log);  // adjacent elements per row cannot exceed the local stride
         SP_TRY(launch_pass(false, first ? NTT_LOAD_EXPAND : NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch));
+        first = false;
+    }
+    return SP_OK;
+}
+
+// Coset-major LDE: dst column v = [coset c_loc][m], element = p_v(h w_N^(m b + c)) with c = c_loc * 2^shard_log + rank.
+// Every coset is a size-n DIT of the same bit-reversed coefficients whose twiddles carry the coset index in their low
+// bits (w_N^(((m mod 2^(j-1)) b + c) << (K - logb - j)) at stage j): the first pass is a contiguous one (coalesced
+// reads of the coefficients, no replication), and what consumes one or two cosets - the constraint composition, the
+// DEEP quotient - reads contiguous memory instead of every b-th or (b/2)-th element of the natural order.
+int NttEngine::lde_coset_major(const fe* coeffs, fe* dst, int k, int logb, uint32_t batch, uint64_t ss, uint64_t ds, int shard_log, int shard_rank) {
+    const int K = k + logb;
+    if (shard_log < 0 || shard_log > logb) { sp_set_error("lde: more shards than cosets"); return SP_E_INVALID_ARG; }
+    const uint32_t b_loc = 1u << (logb - shard_log);
+    const uint64_t n = 1ull << k;
+    const fe* big = nullptr;
+    SP_TRY(roots(K, &big));
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch * b_loc << k) * sizeof(fe));
+    if (geo.empty()) geo.push_back({0, 0, 0});
+    bool first = true;
+    size_t pi = 0;
+    for (const PassGeom& p : geo) {
+        NttPassArgs a{};
+        a.src = first ? coeffs : dst; a.dst = dst;
+        a.src_vec_stride = first ? ss : ds; a.dst_vec_stride = ds;
+        a.coset_count = b_loc; a.src_coset_stride = first ? 0 : n; a.dst_coset_stride = n;
+        a.weak_out = ++pi < geo.size();
+        a.big_tw = big; a.logM = K; a.logL = (uint32_t)k; a.s = p.s; a.r = p.r; a.g = p.g;
+        a.tw_shift = (uint32_t)logb; a.tw_low = (uint32_t)shard_rank; a.shard_log = (uint32_t)shard_log;
+        SP_TRY(launch_pass(false, NTT_LOAD_INPLACE, NTT_STORE_INPLACE, a, batch * b_loc));
         first = false;
     }
     return SP_OK;

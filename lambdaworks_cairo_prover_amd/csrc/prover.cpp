@@ -58,7 +58,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
         return SP_OK;
     }
     free_all();
-    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; h_full_ = false;
+    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
@@ -120,9 +120,9 @@ int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes
 // natural order, then every rank reduces the (replicated) tree.
 int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]) {
     if (world_ == 1) {
-        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree));
+        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree, lde_order()));
     } else {
-        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, Nl_, reinterpret_cast<digest32*>(d_local_)));
+        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, Nl_, reinterpret_cast<digest32*>(d_local_), lde_order()));
         SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(digest32)));
         SP_TRY(interleave_shards(c_->stream, d_gather_, tree + (N_ - 1), n_, shard_map()));
         // Merkle combine: every rank reduces the subtree over its contiguous 1/G of the leaves,
@@ -172,7 +172,7 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
     // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    SP_TRY(c_->ntt->lde_from_bitrev(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
+    SP_TRY(c_->ntt->lde_coset_major(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     // batch_commit (reference prover.rs:96-104) straight from the column-major LDE
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
@@ -459,7 +459,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
         h_full_ = false;
-        SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+        SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else {
         fe* binv = d_scratch_;                  // [ndist][Nl]
         fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 Nl]
@@ -483,7 +483,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         h_full_ = flag != 0;
         if (!h_full_) {
             SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
-            SP_TRY(c_->ntt->lde_from_bitrev(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+            SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
         } else {
             if (world_ > 1) { sp_set_error("composition: the trace violates its constraints (deg H >= 2n); unsupported with coset sharding"); return SP_E_UNSUPPORTED; }
             if (!d_hfull_) SP_TRY(alloc((void**)&d_hfull_, sizeof(fe) * N_));
@@ -491,7 +491,10 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             fe Ninv = fe_inv(fe_from_u64(N_));
             SP_TRY(gen_power_table(c_->stream, t_half, N_ >> 1, logN_ - 1, hinv_, Ninv));
             SP_TRY(split_composition_full(c_->stream, comp, N_, t_half, hinv_, d_hfull_, d_hfull_ + (N_ >> 1)));
-            SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_h12_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
+            // H1, H2 of N/2 coefficients each: natural-order evaluations first, then into the coset-major order of every other column
+            if (!d_hnat_) SP_TRY(alloc((void**)&d_hnat_, sizeof(fe) * N_ * 2));
+            SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_hnat_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
+            SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, d_h12_, N_, 2, lde_order()));
         }
     }
     SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
@@ -647,7 +650,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         if ((2ull * npts + 1) * n_ > scratch_elems()) { sp_set_error("deep: scratch too small for this frame"); return SP_E_ALLOC; }
         SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
-        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order()));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         fe* post = d_scratch_;                                 // [n], the inverses are dead now
         SP_TRY(gen_power_table(c_->stream, post, n_, logn_, fe_inv(fe_pow_u64(wN, rank_)), fe_inv(fe_from_u64(n_))));
@@ -664,7 +667,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         fe* inv_scratch = inv + (uint64_t)npts * Nl_;
         SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * Nl_, c_->d_flag));
-        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0]));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0], lde_order()));
     }
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;
@@ -752,9 +755,15 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     digest32* p_main = (digest32*)carve(sizeof(digest32) * q * d0);
     digest32* p_aux = (digest32*)carve(sizeof(digest32) * q * d0);
     digest32* p_comp = (digest32*)carve(sizeof(digest32) * q * d0);
+    const LdeOrder ord = lde_order();
+    uint64_t* d_spos = d_positions_ + 1024;   // positions inside the coset-major columns
     if (world_ == 1) {
-        SP_TRY(gather_rows(st, d_lde_, N_, C_, d_positions_, q, g_trace));
-        SP_TRY(gather_rows(st, d_h12_, N_, 2, d_positions_, q, g_comp));
+        std::vector<uint64_t> spos(q);
+        for (uint32_t s = 0; s < q; ++s) spos[s] = ord.at(pos[s]);
+        SP_HIP_CHECK(hipMemcpyAsync(d_spos, spos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+        SP_TRY(gather_rows(st, d_lde_, N_, C_, d_spos, q, g_trace));
+        SP_TRY(gather_rows(st, d_h12_, N_, 2, d_spos, q, g_comp));
+        SP_HIP_CHECK(hipStreamSynchronize(st));  // spos is a local
     } else {
         // the LDE rows live on the rank that owns the coset of each queried index: gather local rows (index 0 for rows
         // owned elsewhere), all-gather the small row blocks and keep the owner's copy
@@ -762,7 +771,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
         std::vector<uint64_t> lpos(q);
         for (uint32_t s = 0; s < q; ++s) {
             uint64_t cg = pos[s] & (b - 1), qq = pos[s] >> logb_;
-            lpos[s] = ((cg & (world_ - 1)) == rank_) ? qq * b_loc + (cg >> logG_) : 0;
+            lpos[s] = ((cg & (world_ - 1)) == rank_) ? ord.at(qq * b_loc + (cg >> logG_)) : 0;
         }
         uint64_t* d_lpos = d_positions_ + 2048;
         SP_HIP_CHECK(hipMemcpyAsync(d_lpos, lpos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));

@@ -75,6 +75,8 @@ class StarkProver : public sp_deletable {
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
+    // order of the evaluations inside the trace / composition LDE columns this rank holds (coset-major, common.h)
+    LdeOrder lde_order() const { return LdeOrder{1u, logb_ - logG_, logn_}; }
     uint64_t scratch_elems() const { return std::max<uint64_t>(std::max<uint64_t>(Nl_ * 7, 4 * n_), 8192); }
     int composition_core(const CompositionConsts& K, const std::vector<fe>& points, const AirProgram* prog_dev, const fe* ex_roots_dev,
                          bool allow_sub_coset, uint8_t root_out[32]);
@@ -109,6 +111,7 @@ class StarkProver : public sp_deletable {
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
     AuxWorkspace auxws_{};
     fe* d_hfull_ = nullptr; bool h_full_ = false;  // general (degree >= 2n) composition polynomial: N/2 coefficients per half
+    fe* d_hnat_ = nullptr;    // natural-order staging of the same (exceptional path)
     fe z_; fe h1_z2_, h2_z2_;
     std::vector<fe> trace_ood_;
     std::vector<uint32_t> offsets_{0, 1};   // transition offsets of the AIR (frame rows); Cairo: {0, 1}

@@ -99,7 +99,7 @@ struct DeepConsts {
 // inv: [rows + 1][count] = 1/(x - z g^ofs_k) for each frame row, then 1/(x - z^2).
 // `count` points, point q = element (q << shift) of every column (columns at col_stride).
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
-                     const DeepConsts* consts_dev, const fe* inv, fe* out);
+                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order);
 
 // fold_polynomial + FriLayer::new (reference src/starks/fri/fri_functions.rs:4-27, fri_commitment.rs:30-47) in evaluation
 // form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.
@@ -111,6 +111,8 @@ int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN,
 int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uint64_t start, uint64_t count, unsigned long long* result_dev);
 
 // out[r*cols + j] = cols_base[j*col_stride + rows[r]]
+// dst column v (coset-major order) = src column v (natural order), `len` elements per column
+int natural_to_coset_major(hipStream_t st, const fe* src, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order);
 int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out);
 
 }  // namespace sp

@@ -123,11 +123,14 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
     // element indices are LOCAL under coset sharding (this rank holds b_loc = b >> shard_log cosets); logN, b, c are global
     const uint32_t b_loc = b >> shard_log;
     const ShardMap sm{logb, shard_log, shard_rank};
-    const uint64_t e = CHECK ? i : (i << stride_log);
-    const uint32_t iglob = CHECK ? 0u : shard_global_index((uint32_t)e, sm);
+    const uint64_t el = CHECK ? i : (i << stride_log);   // local natural-order index of the point
+    const uint32_t iglob = CHECK ? 0u : shard_global_index((uint32_t)el, sm);
     const uint32_t c = iglob & (b - 1);
     // frame row offset 1 = LDE index + blowup (reference frame.rs:40-59): same coset; on the trace: the next row
-    const uint64_t enext = (e + (CHECK ? 1u : b_loc)) & (col_len - 1);
+    const uint64_t elnext = (el + (CHECK ? 1u : b_loc)) & (col_len - 1);
+    // the LDE columns are coset-major (the trace of CHECK mode is a plain array): e, enext = storage indices
+    const LdeOrder ord{CHECK ? 0u : 1u, logb - shard_log, logN - logb};
+    const uint64_t e = ord.at(el), enext = ord.at(elnext);
     const fe* coef = sh_coef + c * W;
     const uint32_t A = K->main_cols;
     uint32_t gate = 0;  // see phase_gate
@@ -377,10 +380,10 @@ int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32
 // inv holds the three inverse arrays with `count` entries each, out[q] the value.
 __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, const fe* __restrict__ h1, const fe* __restrict__ h2, uint64_t count,
                                                    uint64_t col_stride, uint32_t shift, const DeepConsts* __restrict__ K,
-                                                   const fe* __restrict__ inv, fe* __restrict__ out) {
+                                                   const fe* __restrict__ inv, fe* __restrict__ out, LdeOrder ord) {
     uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (q >= count) return;
-    const uint64_t i = q << shift;
+    const uint64_t i = ord.at(q << shift);   // coset-major columns: the one coset of the n-point evaluation is contiguous
     const uint32_t C = K->cols, R = K->rows;
     fe a[AIR_MAX_OFFSETS];
 #pragma unroll
@@ -399,8 +402,8 @@ __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, c
     sk_st(out + q, r);
 }
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
-                     const DeepConsts* consts_dev, const fe* inv, fe* out) {
-    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out);
+                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order) {
+    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out, order);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -465,6 +468,19 @@ int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32
     return SP_OK;
 }
 
+// dst column v [coset-major] = src column v [natural order]; `len` elements per column (exceptional paths only)
+__global__ void __launch_bounds__(256) natural_to_coset_major_kernel(const fe* src, fe* dst, uint64_t len, LdeOrder ord) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    const uint64_t base = (uint64_t)blockIdx.y * len;
+    sk_st(dst + base + ord.at(i), sk_ld(src + base + i));
+}
+int natural_to_coset_major(hipStream_t st, const fe* src, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order) {
+    hipLaunchKernelGGL(natural_to_coset_major_kernel, dim3((unsigned)((len + 255) / 256), ncols), dim3(256), 0, st, src, dst, len, order);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- shard reassembly
 __global__ void __launch_bounds__(256) interleave_shards_kernel(const uint4* gathered, uint4* out, uint64_t n, ShardMap m) {
     const uint32_t lb_loc = m.logb - m.shard_log;
@@ -498,7 +514,8 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
     if (i >= count) return;
     const uint32_t b = 1u << logb, b_loc = b >> shard_log;
     const ShardMap sm{logb, shard_log, shard_rank};
-    const uint64_t e = CHECK ? i : (i << stride_log);
+    const uint64_t e = CHECK ? i : (i << stride_log);   // local natural-order index; storage index = ord.at(.)
+    const LdeOrder ord{CHECK ? 0u : 1u, logb - shard_log, logN - logb};
     const uint32_t iglob = CHECK ? 0u : shard_global_index((uint32_t)e, sm);
     const uint32_t c = iglob & (b - 1);
     const uint32_t T = K->n_transitions, B = K->n_boundary;
@@ -512,7 +529,7 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
         switch (o.op) {
             case 0: {   // frame row = trace row + offset: LDE index + offset * blowup (frame.rs:40-59), same coset
                 const uint64_t row = (e + (uint64_t)Pg->offsets[o.a] * (CHECK ? 1u : b_loc)) & (col_len - 1);
-                r = sk_ld(cols + (uint64_t)o.b * col_len + row);
+                r = sk_ld(cols + (uint64_t)o.b * col_len + ord.at(row));
                 break;
             }
             case 1: r = Pg->consts[o.a]; break;
@@ -548,7 +565,7 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
     }
     fe total = K->zerofier[c] * acc;
     for (uint32_t j = 0; j < B; ++j) {
-        fe num = sk_ld(cols + (uint64_t)K->bcol[j] * col_len + e) - K->bvalue[j];
+        fe num = sk_ld(cols + (uint64_t)K->bcol[j] * col_len + ord.at(e)) - K->bvalue[j];
         total = total + K->coef[c][T + j] * num * sk_ld(binv + (uint64_t)K->bden[j] * count + i);
     }
     sk_st(out + i, total);
