@@ -722,11 +722,14 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
 
 int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out) {
     SP_HIP_CHECK(hipSetDevice(c_->device));
-    const uint64_t batch = 1ULL << 22;
+    // expected number of trials 2^factor: ranges of about that size, four queued per host round trip (a range that starts
+    // beyond an already found nonce returns at once)
+    const uint64_t sub = 1ULL << std::min<uint32_t>(std::max<uint32_t>(factor, 16), 22);
+    const uint64_t batch = 4 * sub;
     unsigned long long init = ~0ULL;
     SP_HIP_CHECK(hipMemcpyAsync(d_nonce_, &init, sizeof(init), hipMemcpyHostToDevice, c_->stream));
     for (uint64_t start = 0;; start += batch) {
-        SP_TRY(grind_range(c_->stream, challenge, factor, start, batch, d_nonce_));
+        for (uint32_t u = 0; u < 4; ++u) SP_TRY(grind_range(c_->stream, challenge, factor, start + u * sub, sub, d_nonce_));
         unsigned long long r = 0;
         SP_HIP_CHECK(hipMemcpyAsync(&r, d_nonce_, sizeof(r), hipMemcpyDeviceToHost, c_->stream));
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));

@@ -432,6 +432,9 @@ struct GrindArgs { uint64_t ch[4]; };
 __global__ void __launch_bounds__(256) grind_kernel(GrindArgs a, uint32_t factor, uint64_t start, uint64_t count, unsigned long long* result) {
     uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (t >= count) return;
+    // ranges are queued in increasing order without host synchronisation: once an earlier range has produced a nonce,
+    // nothing in a later range can be the minimum
+    if (*reinterpret_cast<volatile unsigned long long*>(result) < start) return;
     uint64_t nonce = start + t;
     uint64_t s[25];
 #pragma unroll
