@@ -138,9 +138,8 @@ SP_HD fe fe_mul_lazy(const fe& a, const fe& b) {
 }
 SP_HD fe fe_mul(const fe& a, const fe& b) { return fe_reduce_once(fe_mul_lazy(a, b)); }
 
-// ---- lazily reduced arithmetic for the NTT butterflies (Harvey): values live in [0, 4p) (4p < 2^254), products come
-// back in [0, 2p) from fe_mul_lazy, and one conditional subtraction of 2p per butterfly replaces the three
-// conditional corrections of fe_mul + fe_add + fe_sub.
+// ---- lazily reduced arithmetic for the NTT butterflies: products come back in [0, 2p) from fe_mul_lazy, sums and
+// differences are left unreduced (see "deferred reduction" below); the helpers with 2p keep a value below 4p < 2^254.
 #define SP_2P0 0x00000002u
 #define SP_2P6 0x00000022u
 #define SP_2P7 0x10000000u

@@ -1,5 +1,4 @@
-// Stark252 NTT passes for gfx950. See ntt.h for the structure and DESIGN.md for the derivation of the
-// inter-pass twiddle exponent E(pos).
+// Stark252 NTT passes for gfx950. See ntt.h for the structure and DESIGN.md section 4.1 for the twiddle bookkeeping.
 #include "ntt.h"
 #include <algorithm>
 #include <cstdlib>

@@ -165,7 +165,7 @@ def test_merkle_build_dev_device_entry_point(hip_ctx, oracle, k, width):
 
 @pytest.mark.parametrize("k", [13, 18])
 def test_ntt_extreme_values_across_passes(hip_ctx, oracle, k):
-    """The passes keep their data lazily reduced ([0, 4p) / [0, 2p)) between stages and passes: inputs at the top of the
+    """The passes defer reduction (values up to (2 + 2 stages) p inside a pass, < 2p between passes): inputs at the top of the
     range (p - 1 everywhere, alternating 0 / p - 1, p - 1 on one residue class) must still come out canonical and
     equal to the oracle through two- and three-pass transforms, forward, inverse and on a coset."""
     n = 1 << k
