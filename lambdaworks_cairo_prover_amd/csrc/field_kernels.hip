@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(256) rows_to_columns_kernel(const uint8_t* row
             if (ENC == SP_FE_MONT_LIMBS) {
                 const uint64_t* l = reinterpret_cast<const uint64_t*>(p);
                 uint64_t w[4] = {l[0], l[1], l[2], l[3]};
-                x = fe_from_lw_limbs(w);
+                x = fe_canonical_lazy(fe_from_lw_limbs(w));   // lambdaworks limbs are < p; anything else is taken mod p
             } else {
                 const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
                 fe raw;
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256) decode_kernel(const uint8_t* in, uint64_t
     if (ENC == SP_FE_MONT_LIMBS) {
         const uint64_t* l = reinterpret_cast<const uint64_t*>(in + 32 * i);
         uint64_t w[4] = {l[0], l[1], l[2], l[3]};
-        x = fe_from_lw_limbs(w);
+        x = fe_canonical_lazy(fe_from_lw_limbs(w));   // lambdaworks limbs are < p; anything else is taken mod p
     } else {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(in + 32 * i);
         fe raw;
