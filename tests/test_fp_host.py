@@ -1,0 +1,80 @@
+"""csrc/fp.h on the host: the deferred-reduction helpers of the NTT passes (fe_reduce_lazy_2p, fe_canonical_lazy,
+fe_sub_add_kp, fe_sub_add_2p, fe_neg_one) and the Montgomery product on operands beyond p, against Python integers.
+The same header is compiled for gfx950; the GPU suites pin the kernels, this pins the arithmetic they rely on."""
+import os
+import random
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2**251 + 17 * 2**192 + 1
+R = 2**256
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def probe(tmp_path_factory):
+    if not os.path.exists(HIPCC):
+        pytest.skip("hipcc not available")
+    exe = str(tmp_path_factory.mktemp("fp") / "fp_host_check")
+    subprocess.check_call([HIPCC, "-O2", "-x", "hip", "--cuda-host-only", "-include", "cstring",
+                           "-I", os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc"),
+                           os.path.join(ROOT, "tests", "host_src", "fp_host_check.cpp"), "-o", exe], stderr=subprocess.DEVNULL)
+
+    def run(cases):
+        text = "".join(f"{op} {a:064x} {b:064x} {k}\n" for op, a, b, k in cases)
+        out = subprocess.run([exe], input=text.encode(), capture_output=True, check=True).stdout.decode().split()
+        assert len(out) == len(cases)
+        return [int(x, 16) for x in out]
+    return run
+
+
+def edge_values():
+    vals = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2 * P, 2**251 - 1, 2**251, 2**255, R - 1, 31 * P, 31 * P + 5, 22 * P - 1, 16 * P, 30 * P - 1]
+    for k in range(32):
+        vals += [k * P, k * P + 1, max(k * P - 1, 0), k * 2**251, min(k * 2**251 + 2**251 - 1, R - 1)]
+    return vals
+
+
+def test_quotient_estimate_reductions(probe):
+    rng = random.Random(11)
+    vals = edge_values() + [rng.randrange(R) for _ in range(4000)]
+    lazy = probe([("lazy2p", v, 0, 0) for v in vals])
+    canon = probe([("canon", v, 0, 0) for v in vals])
+    for v, r, c in zip(vals, lazy, canon):
+        assert r % P == v % P and r < 2 * P, hex(v)
+        assert c == v % P, hex(v)
+
+
+def test_biased_differences(probe):
+    rng = random.Random(12)
+    cases, want = [], []
+    for k in (2, 4, 8):
+        for _ in range(1500):
+            a, b = rng.randrange(k * P), rng.randrange(k * P)
+            cases.append(("subkp", a, b, k)); want.append(a - b + k * P)
+        for a, b in ((0, k * P - 1), (k * P - 1, 0), (k * P - 1, k * P - 1), (0, 0)):
+            cases.append(("subkp", a, b, k)); want.append(a - b + k * P)
+    for _ in range(1500):   # DIT: u up to 28p, t < 2p
+        a, b = rng.randrange(28 * P), rng.randrange(2 * P)
+        cases.append(("sub2p", a, b, 0)); want.append(a - b + 2 * P)
+    got = probe(cases)
+    for (op, a, b, k), g, w in zip(cases, got, want):
+        assert 0 <= w < R and g == w, (op, hex(a), hex(b), k)
+
+
+def test_lazy_product_accepts_any_256_bit_operand(probe):
+    rng = random.Random(13)
+    rinv = pow(R, -1, P)
+    cases = [("mullazy", rng.randrange(R), rng.randrange(P), 0) for _ in range(3000)]
+    cases += [("mullazy", R - 1, P - 1, 0), ("mullazy", R - 1, 0, 0), ("mullazy", 0, P - 1, 0), ("mullazy", 31 * P, P - 1, 0)]
+    for (op, a, b, k), g in zip(cases, probe(cases)):
+        assert g < 2 * P and g % P == a * b * rinv % P
+    cases = [("mul", rng.randrange(P), rng.randrange(P), 0) for _ in range(1000)]
+    for (op, a, b, k), g in zip(cases, probe(cases)):
+        assert g == a * b * rinv % P
+
+
+def test_minus_one(probe):
+    assert probe([("negone", 0, 0, 0)])[0] == (P - R % P) % P
