@@ -31,7 +31,7 @@ def program_words_from_proof_file(path):
 
 
 @pytest.mark.parametrize("fib_index,options", [(10, (4, 3, 3, 1)), (100, (4, 3, 3, 1)), (140, (4, 3, 3, 1)), (100, (8, 5, 3, 4)),
-                                               (60, (2, 4, 3, 2)), (300, (16, 7, 7, 6))])
+                                               (60, (2, 4, 3, 2)), (300, (16, 7, 7, 6)), (30, (32, 3, 5, 1))])
 def test_device_proof_bytes_equal_oracle(hip_ctx, oracle, fib_index, options):
     run = api.CairoRun.fibonacci(fib_index)
     trace = run.main_trace()
