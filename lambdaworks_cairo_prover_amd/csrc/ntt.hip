@@ -551,7 +551,8 @@ int NttEngine::lde_coset_major(const fe* coeffs, fe* dst, int k, int logb, uint3
     const uint64_t n = 1ull << k;
     const fe* big = nullptr;
     SP_TRY(roots(K, &big));
-    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : NTT_TILE_LOG - NTT_STRIDED_G_LOG, ((uint64_t)batch * b_loc << k) * sizeof(fe));
+    static const int contig_cap = std::getenv("SP_LDE_CONTIG") ? std::atoi(std::getenv("SP_LDE_CONTIG")) : NTT_TILE_LOG - NTT_STRIDED_G_LOG;
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : contig_cap, ((uint64_t)batch * b_loc << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0});
     bool first = true;
     size_t pi = 0;
