@@ -431,7 +431,8 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
     SP_TRY(roots(k, &big));
     // beyond one tile the contiguous pass is kept short (2^7 rows x 8 contiguous runs): a 2^10-row pass stages a 16 KB
     // twiddle table per 32 KB tile and fits only three work-groups per CU (measured 55 % of the strided passes' rate)
-    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : 7, ((uint64_t)batch << k) * sizeof(fe));
+    static const int contig_cap = std::getenv("SP_INTT_CONTIG") ? std::atoi(std::getenv("SP_INTT_CONTIG")) : 7;
+    std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : contig_cap, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0});
     for (size_t i = geo.size(); i-- > 0;) {
         const PassGeom& p = geo[i];

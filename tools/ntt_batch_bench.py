@@ -18,6 +18,6 @@ for _ in range(reps):
     ctx.ntt_dev(d.data_ptr(), n, batch); ctx.sync()
     ts.append(ctx.last_kernel_ms())
 ms = min(ts)
-print(f"SKIP={os.environ.get('SP_NTT_DEBUG_SKIP','0')} LIMBS={os.environ.get('SP_NTT_LIMBS','28')} log_n={k} batch={batch}: {ms:.3f} ms per batch, "
+print(f"log_n={k} batch={batch}: {ms:.3f} ms per batch, "
       f"{batch * n * k / 2 / ms / 1e6:.2f} G butterflies/s, {batch * n * 64 / ms / 1e6:.1f} GB/s per pass-equivalent of 64 B/elem")
 ctx.close()
