@@ -78,3 +78,12 @@ def test_lazy_product_accepts_any_256_bit_operand(probe):
 
 def test_minus_one(probe):
     assert probe([("negone", 0, 0, 0)])[0] == (P - R % P) % P
+
+
+def test_inverse_addition_chain(probe):
+    """fe_inv (Montgomery in, Montgomery out): a^(p-2) through the 2^192 - 1 doubling chain."""
+    rng = random.Random(14)
+    vals = [1, 2, P - 1, R % P, 3 * R % P] + [rng.randrange(1, P) for _ in range(300)]
+    for a, g in zip(vals, probe([("inv", a, 0, 0) for a in vals])):
+        # a = x R, result = x^-1 R  ->  a * g = R^2 (mod p)
+        assert g < P and a * g % P == R * R % P
