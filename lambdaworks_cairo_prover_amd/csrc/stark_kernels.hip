@@ -100,7 +100,7 @@ __device__ __forceinline__ uint32_t phase_gate(const fe& a, const fe& b) {
 //   row = i + 1 mod n): *flag |= 1 if any transition constraint is non-zero on a row it is enforced on, or a boundary
 //   value differs.  A clean flag means every quotient C_k / Z_k is a polynomial, hence deg H < 2n.
 #ifndef SP_COMP_WAVES
-#define SP_COMP_WAVES 2
+#define SP_COMP_WAVES 3
 #endif
 template <bool CHECK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SP_COMP_WAVES, SP_COMP_WAVES)))
