@@ -41,7 +41,8 @@ def _worker(rank, world, port, fib_index, options, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fib_index,options", [(2, 100, (4, 3, 3, 1)), (4, 100, (4, 5, 3, 2)), (4, 200, (8, 4, 3, 1)), (2, 60, (2, 3, 3, 1))])
+@pytest.mark.parametrize("world,fib_index,options", [(2, 100, (4, 3, 3, 1)), (4, 100, (4, 5, 3, 2)), (4, 200, (8, 4, 3, 1)), (2, 60, (2, 3, 3, 1)),
+                                                     (8, 100, (8, 4, 3, 1)), (8, 60, (16, 3, 3, 1))])
 def test_sharded_proof_bytes_identical(world, fib_index, options, oracle, hip_ctx):
     from lambdaworks_cairo_prover_amd import api
     run = api.CairoRun.fibonacci(fib_index)
