@@ -8,7 +8,8 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --proof 0 --no-cpu-baseline --steps 20 --warmup 3"
-rocprofv3 --kernel-trace --stats -d $O/ntt_kt -o ntt -- $B > $O/ntt_kt.log 2>&1
+# kernel trace of the DEFAULT bench command (200 timed steps: settled clocks, the durations bench.py itself reports)
+rocprofv3 --kernel-trace --stats -d $O/ntt_kt -o ntt -- python3 $R/bench.py --proof 0 --no-cpu-baseline > $O/ntt_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/ntt_pf -o f -- $B > $O/ntt_pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/ntt_pw -o w -- $B > $O/ntt_pw.log 2>&1
 rocprofv3 --kernel-trace --stats -d $O/prove_kt -o prove -- python3 $R/tools/prove_bench.py 149000 8 80 20 > $O/prove_kt.log 2>&1

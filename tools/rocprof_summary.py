@@ -11,6 +11,12 @@ def main():
     print(f"{'kernel':90s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
     for name, calls, total, avg, pct in kt.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
         print(f"{name[:90]:90s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:6.2f}")
+    passes = [(n, c, a) for n, c, t, a, p in kt.execute("select name,total_calls,total_duration,average,percentage from top_kernels") if "ntt_pass_kernel" in n]
+    if passes:
+        ntts = min(c for _, c, _ in passes)
+        per_ntt = sum(c * a for _, c, a in passes) / ntts
+        print(f"# NTT pass kernels: {sum(c for _, c, _ in passes)} launches = {ntts} transforms x {sum(c for _, c, _ in passes) / ntts:.0f} passes; "
+              f"sum of the pass durations per transform {per_ntt:.1f} us")
     print()
     print("# per-kernel launch geometry (first dispatch of each kernel)")
     for row in kt.execute("select name, grid_x, grid_y, workgroup_x, lds_size, vgpr_count, sgpr_count, scratch_size from kernels group by name"):
