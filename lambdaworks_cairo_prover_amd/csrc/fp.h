@@ -247,11 +247,40 @@ SP_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
 
 // canonical integer (little-endian limbs, < p) -> Montgomery
 SP_HD fe fe_to_mont(const fe& raw) { return fe_mul(raw, fe_r2()); }
-// Montgomery -> canonical integer
+// Montgomery -> canonical integer: a R^-1 mod p by four 64-bit Montgomery rounds.  p = 1 (mod 2^64), so the quotient
+// digit is m = -(t mod 2^64) and  t <- (t + m p) / 2^64 = (t >> 64) + [t mod 2^64 != 0] + 17 m 2^128 + m 2^187
+// (112 instead of 134 instructions for the product with the constant 1; every leaf element of a commitment takes this path).
 SP_HD fe fe_from_mont(const fe& a) {
-    fe one_raw = fe_zero();
-    one_raw.v[0] = 1;
-    return fe_mul(a, one_raw);  // a * 1 / R: the zero limbs of the constant fold away
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = a.v[j];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        unsigned br, bo, c, co, d, d2;
+        const uint32_t m0 = SP_SUBC(0u, t[0], 0u, br);
+        const uint32_t m1 = SP_SUBC(0u, t[1], br, bo);
+        const unsigned c0 = (t[0] | t[1]) != 0;
+        const uint64_t q0 = (uint64_t)m0 * 17u;
+        const uint64_t q1 = (uint64_t)m1 * 17u + (q0 >> 32);
+        const uint32_t s7 = m0 << 27, s8 = (m0 >> 5) | (m1 << 27), s9 = m1 >> 5;
+        uint32_t u[8];
+        u[0] = SP_ADDC(t[2], 0u, c0, c);
+        u[1] = SP_ADDC(t[3], 0u, c, co); c = co;
+        u[2] = SP_ADDC(t[4], 0u, c, co); c = co;
+        u[3] = SP_ADDC(t[5], 0u, c, co); c = co;
+        u[4] = SP_ADDC(t[6], (uint32_t)q0, c, co); c = co;
+        u[5] = SP_ADDC(t[7], (uint32_t)q1, c, co); c = co;
+        u[6] = SP_ADDC((uint32_t)(q1 >> 32), 0u, c, co);   // <= 17: no carry out
+        u[5] = SP_ADDC(u[5], s7, 0u, d);
+        u[6] = SP_ADDC(u[6], s8, d, d2);
+        u[7] = s9 + d2;                                    // the value stays below 2p < 2^253
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = u[j];
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = t[j];
+    return fe_reduce_once(r);
 }
 
 SP_HD fe fe_from_u64(uint64_t x) {

@@ -87,3 +87,13 @@ def test_inverse_addition_chain(probe):
     for a, g in zip(vals, probe([("inv", a, 0, 0) for a in vals])):
         # a = x R, result = x^-1 R  ->  a * g = R^2 (mod p)
         assert g < P and a * g % P == R * R % P
+
+
+def test_from_montgomery_by_64_bit_rounds(probe):
+    """fe_from_mont: a R^-1 mod p, canonical, for every canonical input (the conversion in front of every leaf hash)."""
+    rng = random.Random(15)
+    rinv = pow(R, -1, P)
+    vals = [0, 1, 2**64 - 1, 2**64, 2**128 - 1, 2**192, P - 1, P - 2**64, R % P] + [rng.randrange(P) for _ in range(4000)]
+    vals += [(k << 64) | lo for k in (0, 1, 2**187 - 1) for lo in (0, 1, 2**64 - 1)]
+    for a, g in zip(vals, probe([("frommont", a, 0, 0) for a in vals])):
+        assert g == a * rinv % P, hex(a)
