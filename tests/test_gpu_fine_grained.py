@@ -194,3 +194,11 @@ def test_lde_extreme_coefficients(hip_ctx, oracle):
     got = hip_ctx.lde(coeffs, blowup, api.felts_to_bytes([3]))
     want = np.stack([oracle.lde(coeffs[c], blowup, 3) for c in range(cols)])
     assert np.array_equal(got, want)
+
+
+def test_plain_c_caller_runs_on_the_gpu(hip_ctx, tmp_path):
+    """examples/c_abi_smoke.c: a C99 program through the C ABI - an NTT round trip on the device."""
+    import subprocess
+    from test_capi import _build_c_example
+    out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
+    assert out.returncode == 0 and "ntt round trip: rc 0, identical" in out.stdout, out.stdout + out.stderr
