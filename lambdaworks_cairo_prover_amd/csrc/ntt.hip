@@ -188,7 +188,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     // ------------------------------------------------------------------ radix-2 stages
     const uint32_t NB = TILE >> 1;
     uint32_t kb = 2;   // DIF: every element is < kb * p
-    for (uint32_t jj = 1; jj <= r; ++jj) {
+    // strided DIT passes on full tiles (TILE = 4 x threads): after an odd leading stage, two stages per LDS round trip - a
+    // radix-4 unit of the four rows t0 + {0, 1, 2, 3} * 2^(j-1) stays in registers between stage j and stage j + 1
+    const bool r4 = !DIF && GLOBAL_TW && !CONTIG && a.radix4 != 0;
+    const uint32_t singles = r4 ? (r & 1u) : r;
+    uint32_t jj = 1;
+    for (; jj <= singles; ++jj) {
         const uint32_t j = DIF ? r + 1 - jj : jj;
         const uint32_t half = 1u << (j - 1);
         const bool fold = DIF && kb == 8;   // the sums of this stage would reach 16p: bring them back below 2p
@@ -223,6 +228,29 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         }
         kb = fold ? 2u : 2u * kb;
         __syncthreads();
+    }
+    if (!DIF && GLOBAL_TW && !CONTIG) {
+        for (; jj + 1 <= r; jj += 2) {
+            const uint32_t j = jj, half = 1u << (j - 1);
+            const uint32_t u = tid;                                  // one unit per thread
+            const uint32_t gl = u & (G - 1), bq = u >> g;
+            const uint32_t i = bq & (half - 1);
+            const uint32_t t0 = ((bq >> (j - 1)) << (j + 1)) | i;
+            const uint32_t l0 = lidx(t0, gl), l1 = lidx(t0 + half, gl), l2 = lidx(t0 + 2 * half, gl), l3 = lidx(t0 + 3 * half, gl);
+            const fe wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
+            fe wb, wc;
+            if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }   // stage-r butterflies tid and tid + TILE/4
+            else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
+            fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
+            x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa);
+            fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
+            a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
+            lds_st(Llo, Lhi, l0, fe_add_raw(a0, a2));
+            lds_st(Llo, Lhi, l2, fe_sub_add_2p(a0, a2));
+            lds_st(Llo, Lhi, l1, fe_add_raw(a1, a3));
+            lds_st(Llo, Lhi, l3, fe_sub_add_2p(a1, a3));
+            __syncthreads();
+        }
     }
 
     // ------------------------------------------------------------------ store
@@ -351,6 +379,8 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     NttPassArgs b = a;
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
+    { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
+      b.radix4 = (r4 && !DIF && !CONTIG && (1u << tile_log) == 4u * NTT_THREADS && a.r >= 2) ? 1u : 0u; }
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
