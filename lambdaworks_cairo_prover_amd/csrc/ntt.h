@@ -45,7 +45,7 @@ struct NttPassArgs {
     uint64_t src_coset_stride, dst_coset_stride;
     // 1 on every pass but the last one of a transform: the stored data is only brought below 2p; 0: canonical values.
     uint32_t weak_out;
-    uint32_t radix4;      // strided DIT passes on 1024-element tiles: two stages per LDS round trip (filled in by the launcher)
+    uint32_t radix4;      // DIT passes: two stages per LDS round trip (filled in by the launcher)
     uint32_t batch;       // vectors per launch (filled in by the launcher)
     uint32_t xcd_map;     // 1: XCD-aware block -> (tile, vector) mapping (needs tiles % 8 == 0)
 };

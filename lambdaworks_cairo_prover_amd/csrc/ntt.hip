@@ -120,7 +120,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         if (r >= 1) {
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
-                const uint32_t b = tid + q * NTT_THREADS;
+                // stage-r butterflies of this thread: tid + q * threads, or - two stages per round trip (a.radix4) - the two
+                // of its radix-4 unit, tid and tid + TILE/4
+                const uint32_t b = tid + q * ((!DIF && a.radix4) ? (TILE >> 2) : (uint32_t)NTT_THREADS);
                 if (b < (TILE >> 1)) tw_last[q] = global_tw(r - 1, b >> g, b & (G - 1));
             }
             const uint32_t cnt = (TILE >> 1) - G;
@@ -188,9 +190,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     // ------------------------------------------------------------------ radix-2 stages
     const uint32_t NB = TILE >> 1;
     uint32_t kb = 2;   // DIF: every element is < kb * p
-    // strided DIT passes on full tiles (TILE = 4 x threads): after an odd leading stage, two stages per LDS round trip - a
-    // radix-4 unit of the four rows t0 + {0, 1, 2, 3} * 2^(j-1) stays in registers between stage j and stage j + 1
-    const bool r4 = !DIF && GLOBAL_TW && !CONTIG && a.radix4 != 0;
+    // DIT passes: after an odd leading stage, two stages per LDS round trip - a radix-4 unit of the four rows
+    // t0 + {0, 1, 2, 3} * 2^(j-1) stays in registers between stage j and stage j + 1 (one unit per thread, TILE/4 units)
+    const bool r4 = !DIF && a.radix4 != 0;
     const uint32_t singles = r4 ? (r & 1u) : r;
     uint32_t jj = 1;
     for (; jj <= singles; ++jj) {
@@ -229,26 +231,37 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         kb = fold ? 2u : 2u * kb;
         __syncthreads();
     }
-    if (!DIF && GLOBAL_TW && !CONTIG) {
+    if (!DIF) {
         for (; jj + 1 <= r; jj += 2) {
             const uint32_t j = jj, half = 1u << (j - 1);
-            const uint32_t u = tid;                                  // one unit per thread
-            const uint32_t gl = u & (G - 1), bq = u >> g;
-            const uint32_t i = bq & (half - 1);
-            const uint32_t t0 = ((bq >> (j - 1)) << (j + 1)) | i;
-            const uint32_t l0 = lidx(t0, gl), l1 = lidx(t0 + half, gl), l2 = lidx(t0 + 2 * half, gl), l3 = lidx(t0 + 3 * half, gl);
-            const fe wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
-            fe wb, wc;
-            if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }   // stage-r butterflies tid and tid + TILE/4
-            else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
-            fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
-            x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa);
-            fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
-            a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
-            lds_st(Llo, Lhi, l0, fe_add_raw(a0, a2));
-            lds_st(Llo, Lhi, l2, fe_sub_add_2p(a0, a2));
-            lds_st(Llo, Lhi, l1, fe_add_raw(a1, a3));
-            lds_st(Llo, Lhi, l3, fe_sub_add_2p(a1, a3));
+            const uint32_t u = tid;
+            if (u < (TILE >> 2)) {
+                uint32_t gl, bq;
+                if (CONTIG) { bq = u & ((R >> 2) - 1); gl = u >> (r - 2); } else { gl = u & (G - 1); bq = u >> g; }
+                const uint32_t i = bq & (half - 1);
+                const uint32_t t0 = ((bq >> (j - 1)) << (j + 1)) | i;
+                const uint32_t l0 = lidx(t0, gl), l1 = lidx(t0 + half, gl), l2 = lidx(t0 + 2 * half, gl), l3 = lidx(t0 + 3 * half, gl);
+                fe wa, wb, wc;
+                bool has_wa = true;
+                if (GLOBAL_TW && CONTIG) {
+                    wa = lds_ld(Twl, Twh, half - 1u + i); wb = lds_ld(Twl, Twh, 2 * half - 1u + i); wc = lds_ld(Twl, Twh, 3 * half - 1u + i);
+                } else if (GLOBAL_TW) {
+                    wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
+                    if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }
+                    else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
+                } else {   // pass-local table w_R^e
+                    if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;   // stage 1: w = 1, inputs < 2p
+                    wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
+                }
+                fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
+                if (has_wa) { x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa); }
+                fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
+                a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
+                lds_st(Llo, Lhi, l0, fe_add_raw(a0, a2));
+                lds_st(Llo, Lhi, l2, fe_sub_add_2p(a0, a2));
+                lds_st(Llo, Lhi, l1, fe_add_raw(a1, a3));
+                lds_st(Llo, Lhi, l3, fe_sub_add_2p(a1, a3));
+            }
             __syncthreads();
         }
     }
@@ -380,7 +393,8 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
     { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
-      b.radix4 = (r4 && !DIF && !CONTIG && (1u << tile_log) == 4u * NTT_THREADS && a.r >= 2) ? 1u : 0u; }
+      // only tiles that give every thread a unit (a half-empty work-group loses more than the saved round trips)
+      b.radix4 = (r4 && !DIF && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u; }
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
