@@ -122,7 +122,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
             for (int q = 0; q < BPT; ++q) {
                 // stage-r butterflies of this thread: tid + q * threads, or - two stages per round trip (a.radix4) - the two
                 // of its radix-4 unit, tid and tid + TILE/4
-                const uint32_t b = tid + q * ((!DIF && a.radix4) ? (TILE >> 2) : (uint32_t)NTT_THREADS);
+                const uint32_t b = tid + q * (a.radix4 ? (TILE >> 2) : (uint32_t)NTT_THREADS);
                 if (b < (TILE >> 1)) tw_last[q] = global_tw(r - 1, b >> g, b & (G - 1));
             }
             const uint32_t cnt = (TILE >> 1) - G;
@@ -192,11 +192,55 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     uint32_t kb = 2;   // DIF: every element is < kb * p
     // DIT passes: after an odd leading stage, two stages per LDS round trip - a radix-4 unit of the four rows
     // t0 + {0, 1, 2, 3} * 2^(j-1) stays in registers between stage j and stage j + 1 (one unit per thread, TILE/4 units)
-    const bool r4 = !DIF && a.radix4 != 0;
+    const bool r4 = a.radix4 != 0;
+    // DIF runs the stages downwards: pairs (r, r-1), (r-2, r-3), ... first, an odd stage 1 last
+    if (DIF && r4) {
+        for (uint32_t jt = r; jt >= 2; jt -= 2) {
+            const uint32_t j = jt - 1, half = 1u << (j - 1);       // stages j + 1 (first) and j
+            const uint32_t u = tid;
+            const bool foldA = kb == 8;
+            const uint32_t kbB = foldA ? 2u : 2u * kb;             // bound of the stage-(j+1) outputs
+            const bool foldB = kbB == 8;
+            if (u < (TILE >> 2)) {
+                uint32_t gl, bq;
+                if (CONTIG) { bq = u & ((R >> 2) - 1); gl = u >> (r - 2); } else { gl = u & (G - 1); bq = u >> g; }
+                const uint32_t i = bq & (half - 1);
+                const uint32_t t0 = ((bq >> (j - 1)) << (j + 1)) | i;
+                const uint32_t l0 = lidx(t0, gl), l1 = lidx(t0 + half, gl), l2 = lidx(t0 + 2 * half, gl), l3 = lidx(t0 + 3 * half, gl);
+                fe wa, wb, wc;          // stage j + 1: wb (rows 0, 2), wc (rows 1, 3); stage j: wa
+                bool has_wa = true;
+                if (GLOBAL_TW) {
+                    if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }
+                    else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
+                    wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
+                } else {                // pass-local table w_R^-e
+                    wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
+                    if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;
+                }
+                fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
+                // stage j + 1: (x0, x2), (x1, x3)
+                fe a0 = fe_add_raw(x0, x2), a1 = fe_add_raw(x1, x3);
+                if (foldA) { a0 = fe_reduce_lazy_2p(a0); a1 = fe_reduce_lazy_2p(a1); }
+                fe a2 = GLOBAL_TW ? fe_sub_add_kp(x2, x0, kb) : fe_sub_add_kp(x0, x2, kb);
+                fe a3 = GLOBAL_TW ? fe_sub_add_kp(x3, x1, kb) : fe_sub_add_kp(x1, x3, kb);
+                a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
+                // stage j: (a0, a1), (a2, a3); every input is < kbB p
+                fe s0 = fe_add_raw(a0, a1), s2 = fe_add_raw(a2, a3);
+                if (foldB) { s0 = fe_reduce_lazy_2p(s0); s2 = fe_reduce_lazy_2p(s2); }
+                fe d1 = GLOBAL_TW ? fe_sub_add_kp(a1, a0, kbB) : fe_sub_add_kp(a0, a1, kbB);
+                fe d3 = GLOBAL_TW ? fe_sub_add_kp(a3, a2, kbB) : fe_sub_add_kp(a2, a3, kbB);
+                if (has_wa) { d1 = fe_mul_lazy(d1, wa); d3 = fe_mul_lazy(d3, wa); }
+                lds_st(Llo, Lhi, l0, s0); lds_st(Llo, Lhi, l1, d1); lds_st(Llo, Lhi, l2, s2); lds_st(Llo, Lhi, l3, d3);
+            }
+            kb = foldB ? 2u : 2u * kbB;
+            __syncthreads();
+        }
+    }
+    // radix-2 stages: all of them without a.radix4; with it the odd leading stage of a DIT pass / the odd last stage (1) of DIF
     const uint32_t singles = r4 ? (r & 1u) : r;
     uint32_t jj = 1;
     for (; jj <= singles; ++jj) {
-        const uint32_t j = DIF ? r + 1 - jj : jj;
+        const uint32_t j = (DIF && !r4) ? r + 1 - jj : jj;     // (DIF with pairs: only stage 1 is left)
         const uint32_t half = 1u << (j - 1);
         const bool fold = DIF && kb == 8;   // the sums of this stage would reach 16p: bring them back below 2p
 #pragma unroll
@@ -394,7 +438,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
     { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
       // only tiles that give every thread a unit (a half-empty work-group loses more than the saved round trips)
-      b.radix4 = (r4 && !DIF && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u; }
+      b.radix4 = (r4 && !(DIF && r4 == 3) && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u; }
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
