@@ -301,13 +301,21 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 if (has_wa) { x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa); }
                 fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
                 a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
-                lds_st(Llo, Lhi, l0, fe_add_raw(a0, a2));
-                lds_st(Llo, Lhi, l2, fe_sub_add_2p(a0, a2));
-                lds_st(Llo, Lhi, l1, fe_add_raw(a1, a3));
-                lds_st(Llo, Lhi, l3, fe_sub_add_2p(a1, a3));
+                const fe y0 = fe_add_raw(a0, a2), y2 = fe_sub_add_2p(a0, a2), y1 = fe_add_raw(a1, a3), y3 = fe_sub_add_2p(a1, a3);
+                if (j + 1 == r && a.radix4 == 1) {
+                    // last pair of the pass: straight to global memory (no LDS write, barrier and re-read)
+                    const uint32_t q = half;   // = R/4
+                    st_fe(dst + position(t0, gl), a.weak_out ? fe_reduce_lazy_2p(y0) : fe_canonical_lazy(y0));
+                    st_fe(dst + position(t0 + q, gl), a.weak_out ? fe_reduce_lazy_2p(y1) : fe_canonical_lazy(y1));
+                    st_fe(dst + position(t0 + 2 * q, gl), a.weak_out ? fe_reduce_lazy_2p(y2) : fe_canonical_lazy(y2));
+                    st_fe(dst + position(t0 + 3 * q, gl), a.weak_out ? fe_reduce_lazy_2p(y3) : fe_canonical_lazy(y3));
+                } else {
+                    lds_st(Llo, Lhi, l0, y0); lds_st(Llo, Lhi, l2, y2); lds_st(Llo, Lhi, l1, y1); lds_st(Llo, Lhi, l3, y3);
+                }
             }
-            __syncthreads();
+            if (j + 1 != r || a.radix4 != 1) __syncthreads();
         }
+        if (a.radix4 == 1) return;   // the last pair has written the tile
     }
 
     // ------------------------------------------------------------------ store
@@ -438,7 +446,8 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
     { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
       // only tiles that give every thread a unit (a half-empty work-group loses more than the saved round trips)
-      b.radix4 = (r4 && !(DIF && r4 == 3) && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u; }
+      b.radix4 = (r4 && !(DIF && r4 == 3) && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u;
+      if (b.radix4 && r4 == 4) b.radix4 = 2; }   // 4: pairs without the fused store (A/B switch)
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
