@@ -158,7 +158,19 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
 
     // ------------------------------------------------------------------ load
     constexpr int LU = 4;   // loads in flight per thread
-    for (uint32_t e0 = tid; e0 < TILE; e0 += NTT_THREADS * LU) {
+    // strided DIT pass with an even number of stages, in pairs: the four rows of a thread's FIRST radix-4 unit (stages 1, 2:
+    // rows 4 bq .. 4 bq + 3) go from global memory straight to its registers - no LDS write and re-read of the tile
+    const bool fuse_ld = !DIF && !CONTIG && a.radix4 == 1 && !(r & 1u) && a.fuse_ld != 0;
+    fe x_first[LU];
+    if (fuse_ld) {
+        const uint32_t gl = tid & (G - 1), bq = tid >> g;
+#pragma unroll
+        for (int q = 0; q < LU; ++q) {
+            const uint32_t pos = position(4u * bq + (uint32_t)q, gl);
+            x_first[q] = (LOADM == NTT_LOAD_EXPAND) ? ld_fe(src + (pos >> s)) : ld_fe(src + pos);
+        }
+    }
+    for (uint32_t e0 = fuse_ld ? TILE : tid; e0 < TILE; e0 += NTT_THREADS * LU) {
         fe xs[LU];
         uint32_t li[LU];
 #pragma unroll
@@ -297,7 +309,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                     if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;   // stage 1: w = 1, inputs < 2p
                     wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
                 }
-                fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
+                fe x0, x1, x2, x3;
+                if (fuse_ld && j == 1) { x0 = x_first[0]; x1 = x_first[1]; x2 = x_first[2]; x3 = x_first[3]; }
+                else { x0 = lds_ld(Llo, Lhi, l0); x1 = lds_ld(Llo, Lhi, l1); x2 = lds_ld(Llo, Lhi, l2); x3 = lds_ld(Llo, Lhi, l3); }
                 if (has_wa) { x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa); }
                 fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
                 a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
@@ -447,7 +461,9 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
       // only tiles that give every thread a unit (a half-empty work-group loses more than the saved round trips)
       b.radix4 = (r4 && !(DIF && r4 == 3) && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u;
-      if (b.radix4 && r4 == 4) b.radix4 = 2; }   // 4: pairs without the fused store (A/B switch)
+      if (b.radix4 && r4 == 4) b.radix4 = 2;     // 4: pairs without the fused store (A/B switch)
+      static const int fl = std::getenv("SP_NTT_FUSE_LD") ? std::atoi(std::getenv("SP_NTT_FUSE_LD")) : 1;
+      b.fuse_ld = (uint32_t)fl; }
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
