@@ -104,6 +104,19 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
     SP_TRY(gen_power_table(c_->stream, d_t2_, n_, logn_, hinv_, Ninv));
     const fe* roots = nullptr;
     SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    // post factors of the 2n-point composition split and of the one-coset DEEP interpolation: functions of the shape and of
+    // this rank's first coset only, so they are generated once per setup instead of once per proof
+    {
+        SP_TRY(alloc((void**)&d_post_comp_, sizeof(fe) * 2 * n_));
+        SP_TRY(alloc((void**)&d_post_deep_, sizeof(fe) * n_));
+        const fe wN = host_primitive_root((int)logN_);
+        const fe u = fe_inv(fe_pow_u64(wN, rank_));  // w_N^-c0
+        const fe minv = fe_inv(fe_from_u64(2 * n_));
+        const fe base = fe_mul(hinv_, fe_sqr(u));
+        SP_TRY(gen_power_table(c_->stream, d_post_comp_, n_, logn_, base, minv));
+        SP_TRY(gen_power_table(c_->stream, d_post_comp_ + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
+        SP_TRY(gen_power_table(c_->stream, d_post_deep_, n_, logn_, u, fe_inv(fe_from_u64(n_))));
+    }
     stage_ = 1;
     return SP_OK;
 }
@@ -437,7 +450,6 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // pair of cosets and obtains the same polynomial, so the composition evaluations need no all-gather)
         const fe wN = host_primitive_root((int)logN_);
         const fe hp = fe_mul(h_, fe_pow_u64(wN, rank_));
-        const fe u = fe_inv(fe_pow_u64(wN, rank_));  // w_N^-c0
         fe* binv = d_scratch_;                    // [ndist][2n]
         fe* inv_scratch = d_scratch_ + 3 * M;     // [3 * 2n]
         if (nd) {
@@ -450,12 +462,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // interpolate_offset_fft + even/odd split in one inverse transform: position q < n of the bit-reversed output is
         // 2n c_j hp^j for j = 2k, position n + q for j = 2k + 1 (k = rev_n(q)); the post factors leave a_k h^k = c_2k h^k
         // and b_k h^k = c_(2k+1) h^k:  (2n)^-1 (h^-1 u^2)^k  and  (2n)^-1 (h^-1 u) (h^-1 u^2)^k,  u = w_N^-c0.
-        fe* post = d_scratch_;                    // [2n], the inverses are dead once the kernel above has run
-        const fe minv = fe_inv(fe_from_u64(M));
-        const fe base = fe_mul(hinv_, fe_sqr(u));
-        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, base, minv));
-        SP_TRY(gen_power_table(c_->stream, post + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, post));
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, d_post_comp_));   // (tables: setup())
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
         h_full_ = false;
@@ -652,9 +659,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order()));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
-        fe* post = d_scratch_;                                 // [n], the inverses are dead now
-        SP_TRY(gen_power_table(c_->stream, post, n_, logn_, fe_inv(fe_pow_u64(wN, rank_)), fe_inv(fe_from_u64(n_))));
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, post));
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, d_post_deep_));   // n^-1 w_N^(-c0 j): setup()
         SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
     } else {
         // deg H >= 2n (constraint-violating trace, single GPU only): the quotient form on the whole domain
