@@ -61,7 +61,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     uint4* Llo = smem;
     uint4* Lhi = smem + TILE;
     uint4* Twl = smem + 2 * TILE;
-    uint4* Twh = Twl + (GLOBAL_TW ? (CONTIG ? R : (TILE >> 1)) : (R >> 1));
+    uint4* Twh = Twl + (GLOBAL_TW ? (CONTIG ? R : (a.radix4 ? (TILE >> 2) : (TILE >> 1))) : (R >> 1));
     const uint32_t tid = threadIdx.x;
     // vector index fastest: consecutive work-groups run the same tile of different vectors, so the twiddles they gather
     // (the same table entries for every vector) are L2 hits for all but the first of them.
@@ -110,6 +110,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     };
     constexpr int BPT = (1 << (NTT_TILE_LOG - 1)) / NTT_THREADS;   // butterflies per thread and stage (at most)
     fe tw_last[(GLOBAL_TW && !CONTIG) ? BPT : 1];
+    fe tw_pen;   // strided passes in pairs: the stage-(r-1) twiddle of this thread's last unit
     if (GLOBAL_TW && CONTIG) {
         // contiguous tile: the twiddle depends on the row only, entry 2^(j-1) - 1 + i for stage j (R - 1 entries)
         for (uint32_t x = tid; x + 1 < R; x += NTT_THREADS) {
@@ -125,7 +126,10 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 const uint32_t b = tid + q * (a.radix4 ? (TILE >> 2) : (uint32_t)NTT_THREADS);
                 if (b < (TILE >> 1)) tw_last[q] = global_tw(r - 1, b >> g, b & (G - 1));
             }
-            const uint32_t cnt = (TILE >> 1) - G;
+            // in pairs the twiddle of stage r - 1 also serves one unit only (row i = unit index): a register as well, and the
+            // LDS table ends with stage r - 2 (40 KB per work-group instead of 48: four work-groups per CU)
+            if (a.radix4 && r >= 2 && tid < (TILE >> 2)) tw_pen = global_tw(r - 2, tid >> g, tid & (G - 1));
+            const uint32_t cnt = (a.radix4 ? (TILE >> 2) : (TILE >> 1)) - G;
             fe tmp[BPT];
 #pragma unroll
             for (int q = 0; q < BPT; ++q) {
@@ -160,7 +164,12 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     constexpr int LU = 4;   // loads in flight per thread
     // strided DIT pass with an even number of stages, in pairs: the four rows of a thread's FIRST radix-4 unit (stages 1, 2:
     // rows 4 bq .. 4 bq + 3) go from global memory straight to its registers - no LDS write and re-read of the tile
-    const bool fuse_ld = !DIF && !CONTIG && a.radix4 == 1 && !(r & 1u) && a.fuse_ld != 0;
+    // (compiled out by default: its registers cost the fourth work-group per CU that the 40 KB tile allows, and four
+    //  work-groups without it beat three with it - tools/sweep_fuse_ld.sh)
+#ifndef SP_NTT_FUSE_LD_BUILD
+#define SP_NTT_FUSE_LD_BUILD 0
+#endif
+    const bool fuse_ld = SP_NTT_FUSE_LD_BUILD && !DIF && !CONTIG && a.radix4 == 1 && !(r & 1u) && a.fuse_ld != 0;
     fe x_first[LU];
     if (fuse_ld) {
         const uint32_t gl = tid & (G - 1), bq = tid >> g;
@@ -222,9 +231,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 fe wa, wb, wc;          // stage j + 1: wb (rows 0, 2), wc (rows 1, 3); stage j: wa
                 bool has_wa = true;
                 if (GLOBAL_TW) {
-                    if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }
-                    else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
-                    wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
+                    if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; wa = tw_pen; }
+                    else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl);
+                           wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl); }
                 } else {                // pass-local table w_R^-e
                     wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
                     if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;
@@ -302,9 +311,9 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                 if (GLOBAL_TW && CONTIG) {
                     wa = lds_ld(Twl, Twh, half - 1u + i); wb = lds_ld(Twl, Twh, 2 * half - 1u + i); wc = lds_ld(Twl, Twh, 3 * half - 1u + i);
                 } else if (GLOBAL_TW) {
-                    wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
-                    if (j + 1 == r) { wb = tw_last[0]; wc = tw_last[BPT - 1]; }
-                    else { wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
+                    if (j + 1 == r) { wa = tw_pen; wb = tw_last[0]; wc = tw_last[BPT - 1]; }
+                    else { wa = lds_ld(Twl, Twh, ((half - 1u + i) << g) + gl);
+                           wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
                 } else {   // pass-local table w_R^e
                     if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;   // stage 1: w = 1, inputs < 2p
                     wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
@@ -453,7 +462,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     uint32_t tile_log = a.r + a.g;
     uint32_t tiles = 1u << (a.logL - tile_log);
     size_t lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)1 << a.r) * sizeof(uint4);
-    if (!CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r
+    if (!CONTIG) lds = ((size_t)3 << tile_log) * sizeof(uint4);   // tile + the global twiddles of its stages j < r (j < r - 1 in pairs, below)
     else if (GTW) lds = ((size_t)2 << tile_log) * sizeof(uint4) + ((size_t)2 << a.r) * sizeof(uint4);
     NttPassArgs b = a;
     b.batch = batch;
@@ -464,6 +473,7 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
       if (b.radix4 && r4 == 4) b.radix4 = 2;     // 4: pairs without the fused store (A/B switch)
       static const int fl = std::getenv("SP_NTT_FUSE_LD") ? std::atoi(std::getenv("SP_NTT_FUSE_LD")) : 1;
       b.fuse_ld = (uint32_t)fl; }
+    if (!CONTIG && b.radix4) lds = ((size_t)5 << (tile_log - 1)) * sizeof(uint4);
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
     SP_HIP_CHECK(hipGetLastError());
