@@ -500,14 +500,13 @@ int NttEngine::launch_pass(bool dif, int lm, int sm, const NttPassArgs& a, uint3
 // Builds the pass list for a size-2^k transform. first_contig_max limits the s = 0 pass (gather/scatter passes
 // want G >= 4 rows per tile so that their strided side is coalesced).
 struct PassGeom { int s, r, g; };
-// footprint = bytes the whole batched transform touches: beyond the 256 MB infinity cache the strided passes read HBM, where
-// 256-byte rows (8 elements, 1024-element tiles) beat 128-byte rows; cache-resident transforms prefer the smaller tiles
-// (more work-groups in flight).  Measured: single 2^22 NTT 3 % faster with 512-element tiles, the proof's large batches
-// indifferent to slightly better with 1024.
+// footprint = bytes the whole batched transform touches.  1024-element tiles (256-byte rows; the only ones that run their
+// stages in pairs) for everything beyond 64 MB, 512-element tiles (more work-groups in flight) for small transforms.
+// Measured with the pair kernels: single 2^22 transform 0.383 -> 0.371 ms with 1024, single 2^20 0.114 -> 0.117 ms.
 static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max, uint64_t footprint) {
     static const int tile_big = std::getenv("SP_NTT_TILE_BIG") ? std::atoi(std::getenv("SP_NTT_TILE_BIG")) : 10;
     static const int tile_small = std::getenv("SP_NTT_TILE_SMALL") ? std::atoi(std::getenv("SP_NTT_TILE_SMALL")) : 9;
-    const int min_tile_log = footprint > (256ull << 20) ? tile_big : tile_small;
+    const int min_tile_log = footprint > (64ull << 20) ? tile_big : tile_small;
     std::vector<PassGeom> out;
     int s = first_stride_log;
     int rem = k - first_stride_log;
