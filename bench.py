@@ -21,8 +21,10 @@ sys.path.insert(0, ROOT)
 
 LOG_N = 22
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_MUL_CEILING = 1.86e11
-VALU_BUTTERFLY_CEILING = 1.49e11  # measured, one MI355X, kernels >= 20 ms (tools/experiments/ubench_mul9.hip)
+VALU_MUL_CEILING = 1.97e11
+# registers-only chain of the butterfly the passes execute (fe_mul_lazy + fe_add_raw + fe_sub_add_2p), one MI355X, 25 ms
+# kernels: profiles/r01_mulvar_ubench_long.txt (1.49e11 for the fully reduced butterfly of the first version)
+VALU_BUTTERFLY_CEILING = 1.72e11
 
 
 def cpu_baseline(log_n=22, reps=3):
@@ -320,7 +322,7 @@ def main():
                      "traffic": traffic, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
                      "mulmod_per_s": butterflies / (avg_ms * 1e-3),
                      # the pass kernels are VALU-issue bound: the honest ceiling is the sustained rate
-                     # of a registers-only butterfly (mul + add + sub) chain, profiles/r01_mul9_ubench.txt
+                     # of a registers-only butterfly (lazy mul + add + sub) chain, profiles/r01_mulvar_ubench_long.txt
                      "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING,
                      "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING},
     }

@@ -127,6 +127,8 @@ __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
         else if (OP == 5) x = mul_pairs<1>(x, y);
         else if (OP == 6) x = mul_pairs<0>(x, y);
         else if (OP == 7) x = mul_shift17(x, y);
+        else if (OP == 8) { fe t = fe_mul_lazy(x, y); fe u = fe_add_raw(y, t); x = fe_reduce_lazy_2p(fe_sub_add_2p(y, t)); y = fe_reduce_lazy_2p(u); }   // deferred-reduction butterfly (+ a fold per output so the chain stays bounded)
+        else if (OP == 9) { fe t = fe_mul_lazy(x, y); fe u = fe_add_raw(y, t); x = fe_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x0fffffffu; }   // the same without the folds (top bits masked)
     }
     out[blockIdx.x * 256 + threadIdx.x] = x;
 }
@@ -153,5 +155,7 @@ int main() {
     run<2>("64 v_mad_u64_u32 + 128 xor", d_out, d_in); run<3>("fe_add + extra reduce", d_out, d_in);
     run<4>("fp.h fe_mul_lazy", d_out, d_in); run<5>("pairs, volatile zero init", d_out, d_in); run<6>("pairs, hoistable zero init", d_out, d_in);
     run<7>("17 m by shift and add (64 multiply-adds)", d_out, d_in);
+    run<8>("lazy butterfly: mul_lazy + add_raw + sub_add_2p + 2 folds", d_out, d_in);
+    run<9>("lazy butterfly: mul_lazy + add_raw + sub_add_2p", d_out, d_in);
     return 0;
 }
