@@ -2,6 +2,7 @@
 // CairoAIR::new (:587-658), build_auxiliary_trace (:660-729, helpers :475-572), boundary_constraints (:777-849).
 #pragma once
 #include "cairo_host.h"
+#include "../../include/stark252_hip.h"
 #include <vector>
 
 namespace sp {
@@ -24,5 +25,8 @@ std::vector<fe> build_auxiliary_trace(const fe* main_trace, uint64_t n, uint32_t
 std::vector<BoundaryConstraint> boundary_constraints(const PublicInputs& pub, const fe rap[3], uint64_t trace_length, bool has_rc_builtin);
 
 void host_batch_inverse(std::vector<fe>& a);  // throws std::runtime_error on a zero element
+
+// sp_cairo_public_inputs (C ABI view) -> PublicInputs; throws std::runtime_error on addresses beyond 64 bits (capi_host.cpp)
+PublicInputs public_inputs_from_c(const sp_cairo_public_inputs* p);
 
 }  // namespace sp

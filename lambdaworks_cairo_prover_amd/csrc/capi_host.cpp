@@ -31,6 +31,26 @@ int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, 
 }
 namespace sp { int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding); }
 
+namespace sp {
+// C view -> host PublicInputs, shared by the prover entry points and sp_cairo_verify so that both reject the same inputs.
+PublicInputs public_inputs_from_c(const sp_cairo_public_inputs* p) {
+    PublicInputs r;
+    r.pc_init = fe_from_bytes_be(p->pc_init); r.ap_init = fe_from_bytes_be(p->ap_init); r.fp_init = fe_from_bytes_be(p->fp_init);
+    r.pc_final = fe_from_bytes_be(p->pc_final); r.ap_final = fe_from_bytes_be(p->ap_final);
+    r.has_rc_min = r.has_rc_max = true;
+    r.range_check_min = p->range_check_min; r.range_check_max = p->range_check_max;
+    for (uint32_t i = 0; i < p->n_segments; ++i)
+        r.memory_segments.push_back({p->segment_types[i], p->segment_ranges[2 * i], p->segment_ranges[2 * i + 1]});
+    for (uint64_t i = 0; i < p->n_public_memory; ++i) {
+        fe a = fe_from_mont(fe_from_bytes_be(p->public_memory + 64 * i));
+        for (int k = 2; k < 8; ++k) if (a.v[k]) throw std::runtime_error("public memory address does not fit in 64 bits");
+        r.public_memory.push_back({(uint64_t)a.v[0] | ((uint64_t)a.v[1] << 32), fe_from_bytes_be(p->public_memory + 64 * i + 32)});
+    }
+    r.num_steps = p->num_steps;
+    return r;
+}
+}  // namespace sp
+
 extern "C" {
 
 const char* sp_version(void) { return "stark252-hip 0.1 (gfx950)"; }
@@ -142,17 +162,7 @@ int sp_cairo_run_public_inputs(const sp_cairo_run* crun, sp_cairo_public_inputs*
 int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* p, const sp_proof_options* opt) {
     if (!proof || !p || !opt) return SP_E_INVALID_ARG;
     try {
-        sp::PublicInputs r;
-        r.pc_init = fe_from_bytes_be(p->pc_init); r.ap_init = fe_from_bytes_be(p->ap_init); r.fp_init = fe_from_bytes_be(p->fp_init);
-        r.pc_final = fe_from_bytes_be(p->pc_final); r.ap_final = fe_from_bytes_be(p->ap_final);
-        r.has_rc_min = r.has_rc_max = true;
-        r.range_check_min = p->range_check_min; r.range_check_max = p->range_check_max;
-        for (uint32_t i = 0; i < p->n_segments; ++i) r.memory_segments.push_back({p->segment_types[i], p->segment_ranges[2 * i], p->segment_ranges[2 * i + 1]});
-        for (uint64_t i = 0; i < p->n_public_memory; ++i) {
-            fe a = fe_from_mont(fe_from_bytes_be(p->public_memory + 64 * i));
-            r.public_memory.push_back({(uint64_t)a.v[0] | ((uint64_t)a.v[1] << 32), fe_from_bytes_be(p->public_memory + 64 * i + 32)});
-        }
-        r.num_steps = p->num_steps;
+        sp::PublicInputs r = sp::public_inputs_from_c(p);
         return sp::cairo_verify_host(proof, proof_len, r, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }

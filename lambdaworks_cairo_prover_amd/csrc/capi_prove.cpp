@@ -26,22 +26,7 @@ ProverHolder* holder(sp_ctx* c, bool create) {
 int dec(sp_ctx* c, const uint8_t* in, uint64_t n, fe* out) { return sp_fe_to_device(c->enc, in, n, reinterpret_cast<uint8_t*>(out)); }
 int enc(sp_ctx* c, const fe* in, uint64_t n, uint8_t* out) { return sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(in), n, out); }
 
-PublicInputs to_host_pub(const sp_cairo_public_inputs* p) {
-    PublicInputs r;
-    r.pc_init = fe_from_bytes_be(p->pc_init); r.ap_init = fe_from_bytes_be(p->ap_init); r.fp_init = fe_from_bytes_be(p->fp_init);
-    r.pc_final = fe_from_bytes_be(p->pc_final); r.ap_final = fe_from_bytes_be(p->ap_final);
-    r.has_rc_min = r.has_rc_max = true;
-    r.range_check_min = p->range_check_min; r.range_check_max = p->range_check_max;
-    for (uint32_t i = 0; i < p->n_segments; ++i)
-        r.memory_segments.push_back({p->segment_types[i], p->segment_ranges[2 * i], p->segment_ranges[2 * i + 1]});
-    for (uint64_t i = 0; i < p->n_public_memory; ++i) {
-        fe a = fe_from_mont(fe_from_bytes_be(p->public_memory + 64 * i));
-        for (int k = 2; k < 8; ++k) if (a.v[k]) throw std::runtime_error("public memory address does not fit in 64 bits");
-        r.public_memory.push_back({(uint64_t)a.v[0] | ((uint64_t)a.v[1] << 32), fe_from_bytes_be(p->public_memory + 64 * i + 32)});
-    }
-    r.num_steps = p->num_steps;
-    return r;
-}
+PublicInputs to_host_pub(const sp_cairo_public_inputs* p) { return public_inputs_from_c(p); }
 }  // namespace
 
 extern "C" {
@@ -130,7 +115,8 @@ int sp_fri_fold_commit(sp_ctx* c, const uint8_t zeta[32], uint8_t out[32], int* 
 
 int sp_grind(sp_ctx* c, const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out) {
     if (!c || !challenge || !nonce_out) return SP_E_INVALID_ARG;
-    ProverHolder* h = holder(c, true);
+    ProverHolder* h = holder(c, false);   // never replaces a prover another entry point owns
+    if (!h || !h->prover.ready()) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
     return h->prover.grind(challenge, factor, nonce_out);
 }
 

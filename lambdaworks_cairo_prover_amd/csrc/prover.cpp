@@ -4,6 +4,7 @@
 #include <array>
 #include "keccak.h"
 #include <algorithm>
+#include <unordered_map>
 #include <cstring>
 #include <cmath>
 #include <stdexcept>
@@ -41,6 +42,15 @@ int StarkProver::alloc(void** p, size_t bytes) {
 }
 
 int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc, const ProofOptionsHost& opt) {
+    const int rc = setup_impl(n, main_cols, aux_cols, has_rc, opt);
+    if (rc != SP_OK) {   // a failed (re)shaping leaves nothing behind: the next setup() of the same shape starts from scratch
+        free_all();
+        n_ = 0; ready_ = false; stage_ = 0;
+    }
+    return rc;
+}
+
+int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc, const ProofOptionsHost& opt) {
     offsets_ = {0, 1};
     int k = sp_log2_exact(n), lb = sp_log2_exact(opt.blowup_factor);
     if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
@@ -51,13 +61,14 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
         return SP_E_INVALID_ARG;
     }
     if (c_->world > 1 && !c_->allgather) { sp_set_error("setup: world > 1 needs sp_set_collective / sp_comm_init_rccl"); return SP_E_STATE; }
-    if (!allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
+    if (ready_ && !allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
         opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == rank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
         return SP_OK;
     }
     free_all();
+    ready_ = false; stage_ = 0;
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
@@ -117,6 +128,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
         SP_TRY(gen_power_table(c_->stream, d_post_comp_ + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
         SP_TRY(gen_power_table(c_->stream, d_post_deep_, n_, logn_, u, fe_inv(fe_from_u64(n_))));
     }
+    ready_ = true;
     stage_ = 1;
     return SP_OK;
 }
@@ -210,17 +222,20 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     {
         std::vector<uint64_t> addrs;
         if (const MemorySegment* out = pub.segment(1)) {
+            if (out->end < out->start || out->end - out->start > pm) { sp_set_error("commit_aux_cairo: output segment larger than the public memory"); return SP_E_INVALID_ARG; }
             uint64_t output_section = out->end - out->start, program_section = pm - output_section;
             for (uint64_t i = 1; i <= program_section; ++i) addrs.push_back(i);
             for (uint64_t a = out->start; a < out->end; ++a) addrs.push_back(a);
         } else {
             for (uint64_t i = 1; i <= pm; ++i) addrs.push_back(i);
         }
+        std::unordered_map<uint64_t, const fe*> by_addr;   // the reference keeps the public memory in a HashMap (cairo/air.rs:163-181)
+        by_addr.reserve(pub.public_memory.size() * 2);
+        for (auto& kv : pub.public_memory) by_addr.emplace(kv.first, &kv.second);   // first entry of an address wins, as the linear scan did
         for (uint64_t a : addrs) {
-            const fe* val = nullptr;
-            for (auto& kv : pub.public_memory) if (kv.first == a) { val = &kv.second; break; }
-            if (!val) { sp_set_error("commit_aux_cairo: public memory address missing"); return SP_E_INVALID_ARG; }
-            pa.push_back(fe_from_u64(a)); pv.push_back(*val);
+            auto it = by_addr.find(a);
+            if (it == by_addr.end()) { sp_set_error("commit_aux_cairo: public memory address missing"); return SP_E_INVALID_ARG; }
+            pa.push_back(fe_from_u64(a)); pv.push_back(*it->second);
         }
     }
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
@@ -751,10 +766,18 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     const uint32_t L = logn_, d0 = logN_;
     o.n_queries = q; o.n_layers = L; o.n_cols = C_; o.depth0 = d0;
     hipStream_t st = c_->stream;
-    // device staging inside the scratch area
+    // device staging inside the scratch area; many queries on a tiny domain outgrow it and get their own buffer
     uint8_t* base = reinterpret_cast<uint8_t*>(d_scratch_);
     size_t off = 0;
     auto carve = [&](size_t bytes) { void* p = base + off; off += (bytes + 255) & ~size_t(255); return p; };
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp1, tmp;
+    {
+        const size_t need1 = 5 * 256 + sizeof(fe) * q * (C_ + 2) + 3 * sizeof(digest32) * q * d0;
+        if (need1 > scratch_elems() * sizeof(fe)) {
+            if (hipMalloc(&tmp1.p, need1) != hipSuccess) { sp_set_error("open: staging allocation failed"); return SP_E_ALLOC; }
+            base = static_cast<uint8_t*>(tmp1.p);
+        }
+    }
     std::vector<uint64_t> pos(q);
     for (uint32_t s = 0; s < q; ++s) pos[s] = iotas[s] % N_;
     SP_HIP_CHECK(hipMemcpyAsync(d_positions_, pos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
@@ -851,7 +874,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     }
     off = 0;
     const size_t need = 3 * 256 + sizeof(uint64_t) * idx.size() + sizeof(fe) * 2 * q * L + sizeof(digest32) * 2 * q * path_total;
-    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp;   // many queries on a tiny domain: own staging buffer
+    base = reinterpret_cast<uint8_t*>(d_scratch_);
     if (need > scratch_elems() * sizeof(fe)) {
         if (hipMalloc(&tmp.p, need) != hipSuccess) { sp_set_error("open: staging allocation failed"); return SP_E_ALLOC; }
         base = static_cast<uint8_t*>(tmp.p);
@@ -1009,8 +1032,12 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             delete ctx->prover_state_deleter_holder;
             ctx->prover_state_deleter_holder = P;
         }
-        hipEvent_t ev[6];
-        for (auto& e : ev) SP_HIP_CHECK(hipEventCreate(&e));
+        struct Events {   // released on every exit path
+            hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+            ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
+        } evs;
+        hipEvent_t* ev = evs.e;
+        for (auto& e : evs.e) SP_HIP_CHECK(hipEventCreate(&e));
         double _tp = wall_ms();
         SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
         SP_TIMEPOINT("setup (alloc + tables)");
@@ -1093,7 +1120,6 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             round_ms[0] = 0.f;
             for (int r = 0; r < 4; ++r) SP_HIP_CHECK(hipEventElapsedTime(&round_ms[r + 1], ev[r], ev[r + 1]));
         }
-        for (auto& e : ev) (void)hipEventDestroy(e);
         std::vector<std::array<uint8_t, 32>> roots(2);
         std::memcpy(roots[0].data(), main_root, 32); std::memcpy(roots[1].data(), aux_root, 32);
         serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);

@@ -61,6 +61,7 @@ class StarkProver : public sp_deletable {
     // AIRs other than Cairo: frame rows of the transition constraints (reset to {0, 1} by setup)
     void set_frame_offsets(const std::vector<uint32_t>& ofs) { offsets_ = ofs; }
     uint32_t frame_rows() const { return (uint32_t)offsets_.size(); }
+    bool ready() const { return ready_; }
     uint64_t n() const { return n_; }
     uint64_t N() const { return N_; }
     uint32_t cols() const { return C_; }
@@ -71,6 +72,8 @@ class StarkProver : public sp_deletable {
   private:
     void free_all();
     int alloc(void** p, size_t bytes);
+    int setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
+    bool ready_ = false;   // setup() completed: every buffer below exists
     int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]);
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the

@@ -42,6 +42,17 @@ def test_device_proof_bytes_equal_oracle(hip_ctx, oracle, fib_index, options):
     assert oracle.cairo_verify(got, run.public_inputs_c, options)
 
 
+def test_many_queries_on_a_tiny_domain(hip_ctx, oracle):
+    """200 queries on a 2^7-row trace (N = 512): the opening staging outgrows the shared scratch area and must move to its
+    own buffer instead of writing past it."""
+    run = api.CairoRun.fibonacci(10)
+    trace = run.main_trace()
+    for options in [(4, 200, 3, 1), (2, 600, 3, 0)]:
+        want = oracle.cairo_prove(trace, run.public_inputs_c, options)
+        got = hip_ctx.cairo_prove(trace, run.public_inputs_c, api.ProofOptions(*options))
+        assert got == want
+
+
 def test_device_proof_equals_reference_golden_70000(hip_ctx):
     """benches/proofs/fibonacci_70000.proof (n = 2^19, blowup 4 — BASELINE config #4's shape): identical bytes."""
     golden, words = program_words_from_proof_file(os.path.join(GOLDEN, "fibonacci_70000.proof"))
