@@ -2,51 +2,100 @@
 """bench.py — Stark252 NTT throughput (BASELINE.json configs[1]: NTT size 2^22 on one MI355X) with roofline and
 CPU-baseline objects.  One "step" = one forward natural-order NTT of 2^22 elements per GPU, inputs resident in HBM.
 
-python bench.py --gpus N --steps K --warmup W   (N > 1: launched by torch.distributed.run, one rank per GPU; the path
-shards by column with no data-path collective -> weak scaling, value = butterflies of all ranks / max time).
+python bench.py --gpus N --steps K --warmup W
+  * started by torch.distributed.run (WORLD_SIZE in the environment): one rank per GPU, as launched;
+  * started as a plain command with N > 1: this process spawns the N ranks itself, BEFORE anything touches the GPU, and
+    passes rank 0's JSON line through.
+The NTT workload shards by column with no data-path collective (weak scaling: value = butterflies of all ranks / max time).
+Before the timed region every leg runs until at least WARM_MS of device time has passed, whatever --warmup says: a cold
+MI355X needs ~100 ms to reach its clocks and a 20-step run would otherwise measure the ramp.
 
-The "proof" object of the same JSON line is BASELINE.json's second figure: whole-proof generation of the 2^20-row Cairo
-fibonacci trace (configs[2]) on the N GPUs - in process for N = 1, for N > 1 coset-sharded over the library's RCCL
-communicator in one child process per rank under a time limit (proof_isolated), so that the headline line survives
-whatever happens there.
+The "proof" objects of the same JSON line are BASELINE.json's second figure: whole-proof generation of the 2^20-row Cairo
+fibonacci trace (configs[2]) and of the 70k-step program of benches/criterion_prover_70k.rs (configs[3], "proof_cfg4") on the
+N GPUs - in process for N = 1; for N > 1 sharded over the library's RCCL communicator in one child process per rank under
+a time limit, so that the headline line survives whatever happens there.  "rccl" reports what that communicator moved.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LOG_N = 22
+WARM_MS = 300.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-VALU_MUL_CEILING = 1.97e11
 # registers-only chain of the butterfly the passes execute (fe_mul_lazy + fe_add_raw + fe_sub_add_2p), one MI355X, 25 ms
 # kernels: profiles/r01_mulvar_ubench_long.txt (1.49e11 for the fully reduced butterfly of the first version)
 VALU_BUTTERFLY_CEILING = 1.72e11
+# independent ceiling: the 72 v_mad_u64_u32 of one Montgomery product at the measured issue time of that instruction alone
+# (2.299 ns per wave-instruction, 8 waves per SIMD, profiles/r01_instruction_ubench3.txt) on 1024 SIMDs x 64 lanes
+MAD_ISSUE_NS = 2.299
+MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
+VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_ntt22_traffic.json")
 
 
-def cpu_baseline(log_n=22, reps=3):
-    """CPU oracle (faithful restatement of the reference's radix-2 FFT) timed on this host, 1 thread."""
+def ntt_source_sha16():
+    h = hashlib.sha256()
+    for f in ("ntt.hip", "ntt.h", "fp.h"):
+        h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def warm_until(ctx, fn, min_ms=WARM_MS, chunk=10, max_calls=100000):
+    """Run fn() until the HIP-event time of the calls adds up to min_ms (clock ramp), whatever the caller's --warmup."""
+    total, calls = 0.0, 0
+    while total < min_ms and calls < max_calls:
+        ctx.timer_start()
+        for _ in range(chunk):
+            fn()
+        total += ctx.timer_stop()
+        calls += chunk
+    return calls
+
+
+def cpu_baseline(log_n=22):
+    """CPU oracle (faithful restatement of the reference's radix-2 FFT) timed on this host: one thread, and one vector per
+    hardware thread (the reference's rayon decomposition is one column per worker); the 32-byte codec apart."""
+    import ctypes
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    os.environ["OMP_NUM_THREADS"] = "1"  # the oracle's codec loops are OpenMP-parallel; the reported baseline is 1 core
     import numpy as np
     import oracle_lib as oracle
+    lib = oracle.load()
     n = 1 << log_n
     rng = np.random.default_rng(1)
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     x[:, 0] &= 0x07
-    oracle.ntt(x[:1024])  # load + warm
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        oracle.ntt(x)
-    dt = (time.perf_counter() - t0) / reps
-    return {"value": (n // 2) * log_n / dt, "unit": "butterflies/s", "cores": 1, "kind": "port",
-            "sample": f"{reps} x forward NTT 2^{log_n} through oracle_ntt (includes 32-byte BE codec), single thread"}
-
-
-VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
+    cores = os.cpu_count() or 1
+    out = (ctypes.c_double * 3)()
+    xp = x.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    lib.oracle_ntt_bench(xp, ctypes.c_uint64(1 << 12), 1, 1, out)          # load + warm
+    assert lib.oracle_ntt_bench(xp, ctypes.c_uint64(n), 2, 1, out) == 0
+    one, codec_s = (n // 2) * log_n * 2 / out[1], out[0]
+    vectors = min(cores, 64)            # 128 MiB of vectors and temporaries per thread: bounded
+    assert lib.oracle_ntt_bench(xp, ctypes.c_uint64(n), vectors, vectors, out) == 0
+    allc = (n // 2) * log_n * vectors / out[1]
+    return {"value": one, "unit": "butterflies/s", "cores": 1, "kind": "port",
+            "sample": f"2 x forward NTT 2^{log_n} in the oracle's field representation, single thread (codec excluded)",
+            "codec_s_per_vector": codec_s, "cpu_model": cpu_model(), "nproc": cores,
+            "all_cores": {"value": allc, "unit": "butterflies/s", "cores": vectors,
+                          "sample": f"{vectors} x forward NTT 2^{log_n}, one vector per thread (OpenMP)"}}
 
 
 def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
@@ -58,7 +107,7 @@ def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
     data[..., 7] &= 0x07FFFFFF
     nodes = torch.empty((2 * n - 1, 32), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
-    ctx.merkle_build_dev(data.data_ptr(), n, cols, n, nodes.data_ptr())
+    warm_until(ctx, lambda: ctx.merkle_build_dev(data.data_ptr(), n, cols, n, nodes.data_ptr()), chunk=4)
     ctx.sync()
     ctx.timer_start()
     for _ in range(reps):
@@ -76,7 +125,7 @@ def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
             "valu_frac": perms / (ms * 1e-3) / VALU_KECCAK_CEILING}
 
 
-def cpu_proof_baseline(api, ctx):
+def cpu_proof_sample(api, ctx):
     """The CPU oracle's whole prover (OpenMP over columns / LDE points, the reference's rayon decomposition) on a bounded
     sample of the proof workload - the same Cairo fibonacci program at 2^14 trace rows, same options as configs[2] - next to
     the device prover on that very input; the two proofs must be the same bytes."""
@@ -102,22 +151,74 @@ def cpu_proof_baseline(api, ctx):
             "cpu_ms": cpu_ms, "cores": cores, "kind": "port", "gpu_ms_same_input": min(gpu_ms), "identical_bytes": got == want}
 
 
-def proof_benchmark(api, ctx, args, world, dist, force_rccl=False):
-    """Whole-proof generation (BASELINE configs[2] shape by default: fib trace 2^20 rows, blowup 8, 80 queries, grinding 20)
-    on the coset-sharded device prover; with N > 1 ranks the shards exchange through the library's RCCL communicator."""
-    run = api.CairoRun.fibonacci(args.proof_fib)
+def cpu_proof_child(args):
+    """Child of cpu_proof_cfg4: the oracle's whole prover on configs[3]'s real shape, result as JSON on a file."""
+    import ctypes
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as oracle
+    from lambdaworks_cairo_prover_amd import api
+    cores = os.cpu_count() or 1
+    try:
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
+    except OSError:
+        cores = 1
+    fib, blowup = args.cpu_proof_shape
+    run = api.CairoRun.fibonacci(fib)
     trace = run.main_trace()
-    opt = api.ProofOptions(args.proof_blowup, 80, 3, 20)
-    if world > 1 or force_rccl:
-        if dist.get_backend() == "nccl":
-            ctx.init_rccl()                                   # the library's own RCCL communicator (xGMI)
-        else:                                                 # development aid: ranks sharing one GPU, host-staged exchange
-            ctx.set_collective(world, dist.get_rank(), api.StagedAllGather())
+    t0 = time.perf_counter()
+    proof = oracle.cairo_prove(trace, run.public_inputs_c, (blowup, 80, 3, 20))
+    ms = (time.perf_counter() - t0) * 1e3
+    with open(args.cpu_proof_child, "w") as f:
+        json.dump({"cpu_ms": ms, "cores": cores, "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof), "trace_rows": run.n_rows}, f)
+
+
+def cpu_proof_cfg4(args, device_proof):
+    """configs[3] (2^19 rows, blowup 4, 80 queries, grinding 20 - benches/criterion_prover_70k.rs:46-57) on the CPU oracle at
+    FULL size under a time budget (a child process, killed when the budget runs out), beside the device time."""
+    fd, path = tempfile.mkstemp(prefix="sp_cpu_proof_", suffix=".json")
+    os.close(fd)
+    os.unlink(path)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-proof-child", path, "--cpu-proof-shape", str(args.cfg4_fib), str(args.cfg4_blowup)]
+    child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    base = {"sample": f"whole proof, fib({args.cfg4_fib}) program, blowup {args.cfg4_blowup}, 80 queries, grinding 20 (configs[3], full size)",
+            "kind": "port", "cpu_model": cpu_model(), "budget_s": args.cpu_proof_budget}
+    try:
+        rc = child.wait(timeout=args.cpu_proof_budget)
+    except subprocess.TimeoutExpired:
+        child.kill()
+        child.wait()
+        base["timeout"] = True
+        return base
+    try:
+        res = json.load(open(path))
+        os.unlink(path)
+    except Exception:
+        base["error"] = f"child exit code {rc}"
+        return base
+    base.update(res)
+    if isinstance(device_proof, dict) and "proof_sha256" in device_proof:
+        base["gpu_ms_same_input"] = device_proof.get("proof_gen_ms_from_host_buffer")
+        base["identical_bytes"] = device_proof["proof_sha256"] == res["proof_sha256"]
+    return base
+
+
+def proof_benchmark(api, ctx, fib, blowup, world, dist):
+    """Whole-proof generation (fib trace, 80 queries, grinding 20) on the sharded device prover; N > 1 ranks exchange through
+    whatever collective the caller installed on ctx."""
     import torch
+    run = api.CairoRun.fibonacci(fib)
+    trace = run.main_trace()
+    opt = api.ProofOptions(blowup, 80, 3, 20)
     dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))  # input resident in HBM
     torch.cuda.synchronize()
     n, cols = trace.shape[0], trace.shape[1]
-    proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)  # warm-up: allocations, tables
+    proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)  # allocations, tables
+    t_w = time.perf_counter()
+    while (time.perf_counter() - t_w) * 1e3 < WARM_MS and world == 1:                     # clock ramp (ranks must stay in step: N = 1 only)
+        ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+    if world > 1:
+        for _ in range(3):
+            ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
     times = []
     for _ in range(3):
         if dist is not None:
@@ -131,16 +232,20 @@ def proof_benchmark(api, ctx, args, world, dist, force_rccl=False):
             dt = float(t.item())
         times.append(dt)
     rounds_dev = ctx.last_round_ms()
-    t0 = time.perf_counter()
-    proof_h = ctx.cairo_prove(trace, run.public_inputs_c, opt)
-    pcie_ms = (time.perf_counter() - t0) * 1e3
+    host_ms = []
+    for _ in range(2):
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        proof_h = ctx.cairo_prove(trace, run.public_inputs_c, opt)
+        host_ms.append((time.perf_counter() - t0) * 1e3)
     assert proof_h == proof
-    import hashlib
     return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": rounds_dev, "trace_rows": run.n_rows,
-            "trace_cols": 52, "blowup": args.proof_blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
+            "trace_cols": 52, "blowup": blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
-            "proof_gen_ms_from_host_buffer": pcie_ms,
-            "note": "wall time of sp_cairo_prove_dev (main trace resident in HBM); the *_from_host_buffer figure adds the PCIe copy"}
+            "proof_gen_ms_from_host_buffer": min(host_ms),
+            "note": "wall time of sp_cairo_prove_dev (main trace resident in HBM); the *_from_host_buffer figure is sp_cairo_prove, "
+                    "the drop-in call, PCIe upload of the trace included"}
 
 
 def _free_port():
@@ -152,13 +257,16 @@ def _free_port():
     return port
 
 
-def _device_index(local_rank):
-    # SP_BENCH_FORCE_DEVICE: development aid (several ranks on the one GPU of the test box)
-    return int(os.environ.get("SP_BENCH_FORCE_DEVICE", local_rank))
-
-
-def _backend():
-    return os.environ.get("SP_BENCH_BACKEND", "nccl")
+def _placement(local_rank, world):
+    """(device index, backend): one GPU per rank over RCCL when the box has them; otherwise (development box) the ranks share
+    the devices there are and exchange through host-staged gloo hooks - reported as devices_shared in the JSON line."""
+    import torch
+    count = torch.cuda.device_count()          # does not initialise the GPU
+    if "SP_BENCH_FORCE_DEVICE" in os.environ:
+        return int(os.environ["SP_BENCH_FORCE_DEVICE"]), os.environ.get("SP_BENCH_BACKEND", "gloo"), True
+    if count >= world:
+        return local_rank, os.environ.get("SP_BENCH_BACKEND", "nccl"), False
+    return local_rank % max(count, 1), "gloo", True
 
 
 def proof_child(args):
@@ -168,19 +276,34 @@ def proof_child(args):
     from lambdaworks_cairo_prover_amd import api
     rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
     import torch.distributed as dist
-    dev_index = _device_index(local_rank)
+    dev_index, backend, shared = _placement(local_rank, world)
     torch.cuda.set_device(dev_index)
-    if _backend() == "nccl":
+    if backend == "nccl":
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
     else:
-        dist.init_process_group(_backend())
-    result = None
+        dist.init_process_group(backend)
+    result = {}
     try:
         ctx = api.Context(device=dev_index)
-        result = proof_benchmark(api, ctx, args, world, dist, force_rccl=True)
+        if backend == "nccl":
+            ctx.init_rccl()                                   # the library's own RCCL communicator (xGMI)
+        else:                                                 # development aid: ranks sharing one GPU, host-staged exchange
+            ctx.set_collective(world, rank, api.StagedAllGather())
+        for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
+            try:
+                before = ctx.comm_stats()
+                result[key] = proof_benchmark(api, ctx, fib, blowup, world, dist)
+                after = ctx.comm_stats()
+                result[key]["collective_bytes_per_proof"] = {k: (after[k] - before[k]) // 9 for k in ("allgather_bytes", "alltoall_bytes", "received_bytes")}
+            except Exception as e:
+                result[key] = {"error": repr(e)}
+        stats = ctx.comm_stats()
+        result["rccl"] = {"world": stats["world"], "backend": "rccl" if backend == "nccl" else "gloo-staged hook", "devices_shared": shared,
+                          "allgather_calls": stats["allgather_calls"], "allgather_bytes": stats["allgather_bytes"],
+                          "alltoall_calls": stats["alltoall_calls"], "alltoall_bytes": stats["alltoall_bytes"]}
         ctx.close()
     except Exception as e:
-        result = {"error": repr(e)}
+        result["error"] = repr(e)
     if rank == 0:
         with open(args.proof_child, "w") as f:
             json.dump(result, f)
@@ -188,11 +311,9 @@ def proof_child(args):
 
 
 def proof_isolated(args, rank, local_rank, world, dist):
-    """Whole-proof timing for N > 1 GPUs.  The sharded prover exchanges leaf digests through the library's RCCL communicator;
-    every rank runs it in a CHILD process under a time limit, so that a failure or a hang of that path cannot take the
-    headline measurement with it.  Returns the child's result (rank 0) or an error object."""
-    import subprocess
-    import tempfile
+    """Whole-proof timing for N > 1 GPUs.  The sharded prover exchanges digests and coefficients through the library's RCCL
+    communicator; every rank runs it in a CHILD process under a time limit, so that a failure or a hang of that path cannot
+    take the headline measurement with it.  Returns the child's result (rank 0) or an error object."""
     box = [None, None]
     if rank == 0:
         fd, path = tempfile.mkstemp(prefix="sp_proof_", suffix=".json")
@@ -205,7 +326,7 @@ def proof_isolated(args, rank, local_rank, world, dist):
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     cmd = [sys.executable, os.path.abspath(__file__), "--proof-child", path, "--proof-fib", str(args.proof_fib),
-           "--proof-blowup", str(args.proof_blowup)]
+           "--proof-blowup", str(args.proof_blowup), "--cfg4-fib", str(args.cfg4_fib), "--cfg4-blowup", str(args.cfg4_blowup)]
     err = tempfile.TemporaryFile()
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=err)
     status = "ok"
@@ -232,6 +353,26 @@ def proof_isolated(args, rank, local_rank, world, dist):
         return {"error": f"sharded proof child: {status}", "stderr_tail": tail}
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` as a plain command: start the N ranks as fresh child processes (this parent never touches
+    the GPU), wait for them, pass rank 0's JSON line through."""
+    port = _free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -240,16 +381,23 @@ def main():
     ap.add_argument("--log-n", type=int, default=LOG_N)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--proof", type=int, default=-1, help="also time whole-proof generation (default: on; N > 1 in child processes)")
-    ap.add_argument("--proof-isolated", action="store_true", help="run the proof timing in a child process also for 1 GPU")
-    ap.add_argument("--proof-timeout", type=int, default=240, help="seconds the child processes of the N > 1 proof timing may take")
+    ap.add_argument("--proof-timeout", type=int, default=360, help="seconds the child processes of the N > 1 proof timing may take")
     ap.add_argument("--proof-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--proof-fib", type=int, default=149000, help="fibonacci index of the proved Cairo program (149000 -> 2^20 rows)")
     ap.add_argument("--proof-blowup", type=int, default=8)
+    ap.add_argument("--cfg4-fib", type=int, default=70000, help="configs[3]: the 70k program of benches/criterion_prover_70k.rs (2^19 rows)")
+    ap.add_argument("--cfg4-blowup", type=int, default=4)
+    ap.add_argument("--cpu-proof-budget", type=int, default=150, help="seconds the CPU oracle may take for the full-size configs[3] proof (0: skip)")
+    ap.add_argument("--cpu-proof-child", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-proof-shape", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_proof_child:
+        return cpu_proof_child(args)
     if args.proof_child:
         return proof_child(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)
 
-    import numpy as np
     import torch
     from lambdaworks_cairo_prover_amd import api
 
@@ -257,14 +405,14 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
-    dev_index = _device_index(local_rank)
+    dev_index, backend, shared = _placement(local_rank, world)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if _backend() == "nccl":
+        if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
         else:
-            dist.init_process_group(_backend())
+            dist.init_process_group(backend)
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
 
@@ -285,6 +433,7 @@ def main():
             dist.barrier()
         ctx.sync()
 
+    self_warm = warm_until(ctx, lambda: ctx.ntt_dev(data.data_ptr(), n))   # clock ramp, independent of --warmup
     for _ in range(args.warmup):
         ctx.ntt_dev(data.data_ptr(), n)
     barrier()
@@ -296,15 +445,20 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev if _backend() == "nccl" else "cpu", dtype=torch.float64)
+        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    traffic = None  # HBM bytes per NTT from the committed PMC profile (same command, same size)
+    # HBM bytes per NTT from the committed PMC passes of this very kernel source (tools/profile_round.sh); a profile taken
+    # from other sources is reported as stale instead of being passed off as a measurement of this build
+    traffic, traffic_note = None, "no PMC profile committed for this size"
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_ntt22_traffic.json")))
+        tj = json.load(open(TRAFFIC_FILE))
         if tj.get("log_n") == args.log_n:
-            traffic = tj["traffic_bytes_per_ntt"]
+            if tj.get("ntt_source_sha16") == ntt_source_sha16():
+                traffic, traffic_note = tj["traffic_bytes_per_ntt"], os.path.relpath(TRAFFIC_FILE, ROOT)
+            else:
+                traffic_note = f"stale: {os.path.relpath(TRAFFIC_FILE, ROOT)} was taken from other kernel sources ({tj.get('traffic_bytes_per_ntt')} B)"
     except Exception:
         pass
     butterflies = (n // 2) * args.log_n
@@ -312,19 +466,23 @@ def main():
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     algo_bytes = 64.0 * n  # read once + write once
     achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+    rate = butterflies / (avg_ms * 1e-3)
     out = {
         "metric": "stark252_ntt_field_ops_per_s", "value": value, "unit": "butterflies/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
         "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
-                   "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)"},
+                   "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)",
+                   "self_warmup_steps": self_warm, "devices_shared": shared},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
-                     "mulmod_per_s": butterflies / (avg_ms * 1e-3),
-                     # the pass kernels are VALU-issue bound: the honest ceiling is the sustained rate
-                     # of a registers-only butterfly (lazy mul + add + sub) chain, profiles/r01_mulvar_ubench_long.txt
-                     "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING,
-                     "valu_frac": butterflies / (avg_ms * 1e-3) / VALU_BUTTERFLY_CEILING},
+                     "traffic": traffic, "traffic_source": traffic_note,
+                     "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
+                     "mulmod_per_s": rate,
+                     # the pass kernels are VALU-issue bound.  Two ceilings: the multiplier alone (72
+                     # v_mad_u64_u32 per product at that instruction's measured issue time - independent of this code), and
+                     # the sustained rate of a registers-only chain of this code's butterfly (lazy mul + add + sub)
+                     "mul_issue_ceiling_per_s": MUL_ISSUE_CEILING, "mul_issue_frac": rate / MUL_ISSUE_CEILING,
+                     "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING, "valu_frac": rate / VALU_BUTTERFLY_CEILING},
     }
     if rank == 0:
         try:
@@ -333,24 +491,37 @@ def main():
             out["roofline_merkle"] = {"error": repr(e)}
     if args.proof != 0:
         try:
-            if world == 1 and not args.proof_isolated:
-                out["proof"] = proof_benchmark(api, ctx, args, world, dist)
+            if world == 1:
+                out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
+                out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
             else:
-                out["proof"] = proof_isolated(args, rank, local_rank, world, dist)
+                res = proof_isolated(args, rank, local_rank, world, dist)
+                if rank == 0:
+                    for key in ("proof", "proof_cfg4", "rccl"):
+                        if isinstance(res, dict) and key in res:
+                            out[key] = res[key]
+                    if not isinstance(res, dict) or "proof" not in res:
+                        out["proof"] = res
         except Exception as e:  # the headline metric must survive a failure of the secondary one
             out["proof"] = {"error": repr(e)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         try:
-            out["cpu_baseline"]["proof"] = cpu_proof_baseline(api, ctx)
+            out["cpu_baseline"]["proof"] = cpu_proof_sample(api, ctx)
         except Exception as e:
             out["cpu_baseline"]["proof"] = {"error": repr(e)}
+        if args.cpu_proof_budget > 0 and args.proof != 0:
+            try:
+                out["cpu_baseline"]["proof_cfg4"] = cpu_proof_cfg4(args, out.get("proof_cfg4"))
+            except Exception as e:
+                out["cpu_baseline"]["proof_cfg4"] = {"error": repr(e)}
     if rank == 0:
         print(json.dumps(out))
     ctx.close()
     if dist is not None:
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

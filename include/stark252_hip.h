@@ -66,7 +66,7 @@ int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
 void sp_ctx_destroy(sp_ctx* ctx);
 
 /* ---- multi-GPU: one process and one context per GPU; the LDE cosets are sharded over `world` ranks
- * (world a power of two <= blowup factor). Every rank calls the same sequence (sp_cairo_prove or the round-level calls)
+ * (world a power of two; beyond the blowup factor the surplus ranks are replicas). Every rank calls the same sequence (sp_cairo_prove or the round-level calls)
  * with the same inputs and obtains the same roots / proof bytes. The data-path exchanges are all-gathers of 32-byte leaf
  * digests, composition evaluations and DEEP evaluations; everything else is local. Either install a hook ... */
 int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void* user);
@@ -75,6 +75,23 @@ int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void
  * sp_comm_init_rccl with it. */
 int sp_comm_unique_id(uint8_t id_out[128]);
 int sp_comm_init_rccl(sp_ctx* ctx, const uint8_t id[128], int world, int rank);
+/* Optional second hook ("Merkle combine"): blocking all-to-all of equal blocks, send_dev =
+ * [world][bytes_per_pair] (block d goes to rank d), recv_dev = [world][bytes_per_pair] (block s came from rank s).  With it
+ * the 32-byte leaf digests of a commitment travel once (each rank receives only the contiguous 1/world of the leaves whose
+ * subtree it reduces); without it the prover falls back to an all-gather of the digests.  sp_comm_init_rccl installs both
+ * (grouped ncclSend/ncclRecv on the context stream).  Call after sp_set_collective. */
+typedef int (*sp_alltoall_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_pair);
+int sp_set_alltoall(sp_ctx* ctx, sp_alltoall_fn fn);
+/* Collective traffic of this context since creation: out = {world, all-gather calls, bytes contributed to all-gathers,
+ * all-to-all calls, bytes sent in all-to-alls, bytes received in all collectives}. */
+int sp_comm_stats(sp_ctx* ctx, uint64_t out[6]);
+/* Tuning knobs of the sharded prover (defaults in parentheses):
+ *   SP_OPT_FRI_SHARD_MIN_LOG (16)  FRI layers with at least 2^value leaves keep their evaluations and trees sharded; smaller
+ *                                  layers are all-gathered once and continue replicated (fri/mod.rs:20-72 is sequential in the layers);
+ *   SP_OPT_SHARD_INTERPOLATION (1) 1: the size-n inverse transforms of a trace segment are split by column over the ranks and the
+ *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns. */
+enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2 };
+int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 
 /* ---- fine-grained layer: the lambdaworks seam the reference calls ------------------------ */
 

@@ -323,6 +323,7 @@ class StagedAllGather:
             self.hip = ctypes.CDLL("libamdhip64.so")
             self.hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
         self.cfn = ALLGATHER_FN(self._call)
+        self.a2a_cfn = ALLGATHER_FN(self._call_a2a)   # sp_alltoall_fn has the same C signature
 
     def _copy(self, dst, src, nbytes, kind):
         if self.device_memory:
@@ -348,9 +349,49 @@ class StagedAllGather:
             return -3
 
 
-def _ctx_set_collective(self, world, rank, hook):
-    self._hook = hook  # keep the callback alive
+def _staged_call_a2a(self, user, send, recv, nbytes):
+    """sp_alltoall_fn: block d of send goes to rank d, block s of recv came from rank s (host-staged all_to_all_single)."""
+    try:
+        import torch
+        total = nbytes * self.world
+        host = np.empty(total, dtype=np.uint8)
+        if self._copy(host.ctypes.data, send, total, 2) != 0:
+            return -1
+        out = torch.empty(total, dtype=torch.uint8)
+        self.dist.all_to_all_single(out, torch.from_numpy(host), group=self.group)
+        o = out.numpy()
+        if self._copy(recv, o.ctypes.data, total, 1) != 0:
+            return -2
+        return 0
+    except Exception:  # never let an exception cross the C boundary
+        import traceback
+        traceback.print_exc()
+        return -3
+
+
+StagedAllGather._call_a2a = _staged_call_a2a
+
+
+def _ctx_set_collective(self, world, rank, hook, alltoall=True):
+    """Install the blocking all-gather hook (and, unless alltoall=False, the all-to-all hook of the digest exchange)."""
+    self._hook = hook  # keep the callbacks alive
     check(self._lib.sp_set_collective(self._h, world, rank, hook.cfn if hook is not None else None, None))
+    if hook is not None and alltoall and hasattr(hook, "a2a_cfn"):
+        check(self._lib.sp_set_alltoall(self._h, hook.a2a_cfn))
+
+
+def _ctx_comm_stats(self):
+    out = (ctypes.c_uint64 * 6)()
+    check(self._lib.sp_comm_stats(self._h, out))
+    return {"world": out[0], "allgather_calls": out[1], "allgather_bytes": out[2], "alltoall_calls": out[3],
+            "alltoall_bytes": out[4], "received_bytes": out[5]}
+
+
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION = 1, 2
+
+
+def _ctx_set_option(self, key, value):
+    check(self._lib.sp_set_option(self._h, int(key), ctypes.c_int64(int(value))))
 
 
 def _ctx_init_rccl(self, group=None):
@@ -368,4 +409,7 @@ def _ctx_init_rccl(self, group=None):
 
 Context.set_collective = _ctx_set_collective
 Context.init_rccl = _ctx_init_rccl
-__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards"]
+Context.comm_stats = _ctx_comm_stats
+Context.set_option = _ctx_set_option
+__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION"]

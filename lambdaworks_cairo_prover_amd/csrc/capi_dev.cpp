@@ -67,7 +67,37 @@ void sp_ctx_destroy(sp_ctx* c) {
 
 int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) || (world > 1 && !fn)) return SP_E_INVALID_ARG;
-    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user;
+    delete c->prover_state_deleter_holder;   // a prover shaped for another world size must not survive
+    c->prover_state_deleter_holder = nullptr;
+    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr;
+    return SP_OK;
+}
+
+int sp_set_alltoall(sp_ctx* c, sp_alltoall_fn fn) {
+    if (!c) return SP_E_INVALID_ARG;
+    c->alltoall = fn;
+    return SP_OK;
+}
+
+int sp_comm_stats(sp_ctx* c, uint64_t out[6]) {
+    if (!c || !out) return SP_E_INVALID_ARG;
+    out[0] = (uint64_t)c->world; out[1] = c->stat_ag_calls; out[2] = c->stat_ag_bytes;
+    out[3] = c->stat_a2a_calls; out[4] = c->stat_a2a_bytes; out[5] = c->stat_recv_bytes;
+    return SP_OK;
+}
+
+int sp_set_option(sp_ctx* c, int key, int64_t value) {
+    if (!c) return SP_E_INVALID_ARG;
+    switch (key) {
+        case SP_OPT_FRI_SHARD_MIN_LOG:
+            if (value < 1 || value > 40) return SP_E_INVALID_ARG;
+            c->opt_fri_shard_min_log = (uint32_t)value;
+            break;
+        case SP_OPT_SHARD_INTERPOLATION: c->opt_shard_interpolation = value != 0; break;
+        default: sp_set_error("sp_set_option: unknown key"); return SP_E_INVALID_ARG;
+    }
+    delete c->prover_state_deleter_holder;   // the options shape the prover's buffers: start from a fresh one
+    c->prover_state_deleter_holder = nullptr;
     return SP_OK;
 }
 
@@ -75,11 +105,26 @@ namespace {
 struct RcclComm : public sp_deletable {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
+    int world = 1;
     ~RcclComm() override { if (comm) (void)ncclCommDestroy(comm); }
 };
 int rccl_allgather(void* user, const void* send, void* recv, uint64_t bytes) {
     RcclComm* rc = static_cast<RcclComm*>(user);
     if (ncclAllGather(send, recv, bytes, ncclUint8, rc->comm, rc->stream) != ncclSuccess) return -1;
+    if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
+    return 0;
+}
+// all-to-all of equal blocks as grouped point-to-point transfers (xGMI is point-to-point: every pair uses its own link)
+int rccl_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
+    RcclComm* rc = static_cast<RcclComm*>(user);
+    const uint8_t* s = static_cast<const uint8_t*>(send);
+    uint8_t* r = static_cast<uint8_t*>(recv);
+    if (ncclGroupStart() != ncclSuccess) return -1;
+    for (int peer = 0; peer < rc->world; ++peer) {
+        if (ncclSend(s + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) return -1;
+        if (ncclRecv(r + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) return -1;
+    }
+    if (ncclGroupEnd() != ncclSuccess) return -1;
     if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
     return 0;
 }
@@ -100,11 +145,12 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     ncclUniqueId id;
     std::memcpy(&id, id_bytes, 128);
     RcclComm* rc = new RcclComm();
-    rc->stream = c->stream;
+    rc->stream = c->stream; rc->world = world;
     if (ncclCommInitRank(&rc->comm, world, id, rank) != ncclSuccess) { delete rc; sp_set_error("ncclCommInitRank failed"); return SP_E_HIP; }
     delete c->comm_holder;
     c->comm_holder = rc;
-    return sp_set_collective(c, world, rank, rccl_allgather, rc);
+    SP_TRY(sp_set_collective(c, world, rank, rccl_allgather, rc));
+    return sp_set_alltoall(c, rccl_alltoall);
 }
 
 int sp_sync(sp_ctx* c) {

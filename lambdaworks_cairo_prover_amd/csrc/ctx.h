@@ -24,6 +24,10 @@ struct sp_ctx {
     // coset sharding across GPUs: world size (power of two), rank and the blocking all-gather hook (see sp_set_collective)
     int world = 1, rank = 0;
     sp_allgather_fn allgather = nullptr;
+    sp_alltoall_fn alltoall = nullptr;    // optional (sp_set_alltoall); same user pointer
     void* allgather_user = nullptr;
+    uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
+    uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
+    bool opt_shard_interpolation = true;
     sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

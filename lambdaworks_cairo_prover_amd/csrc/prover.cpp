@@ -56,13 +56,13 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
     if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c_->device));
-    if (c_->world < 1 || (c_->world & (c_->world - 1)) || c_->rank < 0 || c_->rank >= c_->world || c_->world > (1 << lb)) {
-        sp_set_error("setup: world size must be a power of two not exceeding the blowup factor (one or more LDE cosets per GPU)");
+    if (c_->world < 1 || (c_->world & (c_->world - 1)) || c_->rank < 0 || c_->rank >= c_->world) {
+        sp_set_error("setup: world size must be a power of two");
         return SP_E_INVALID_ARG;
     }
     if (c_->world > 1 && !c_->allgather) { sp_set_error("setup: world > 1 needs sp_set_collective / sp_comm_init_rccl"); return SP_E_STATE; }
     if (ready_ && !allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
-        opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == rank_) {
+        opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
         return SP_OK;
@@ -71,9 +71,15 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     ready_ = false; stage_ = 0;
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
+    d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
-    world_ = (uint32_t)c_->world; rank_ = (uint32_t)c_->rank; logG_ = (uint32_t)sp_log2_exact(world_); Nl_ = N_ >> logG_;
+    world_ = (uint32_t)c_->world; wrank_ = (uint32_t)c_->rank;
+    // one or more LDE cosets per group; with more ranks than cosets the surplus ranks replicate a role (moving half a coset's
+    // LDE over one xGMI link costs more than computing it)
+    G_ = std::min<uint32_t>(world_, 1u << lb); logG_ = (uint32_t)sp_log2_exact(G_); rank_ = wrank_ & (G_ - 1);
+    Nl_ = N_ >> logG_;
+    if (G_ > 1 && N_ < 2ull * G_ * G_) { sp_set_error("setup: the LDE domain is too small for this many ranks"); return SP_E_INVALID_ARG; }
     h_ = fe_from_u64(opt.coset_offset);
     if (fe_is_zero(h_)) return SP_E_INVALID_ARG;
     hinv_ = fe_inv(h_);
@@ -86,26 +92,36 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
     SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * Nl_ * 2));
     SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * scratch_elems()));
-    d_local_ = nullptr; d_gather_ = nullptr;
-    if (world_ > 1) {
+    if (G_ > 1) {
         SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
-        SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * N_));
+        SP_TRY(alloc((void**)&d_recv_, sizeof(fe) * Nl_));
+        SP_TRY(alloc((void**)&d_roots_, sizeof(digest32) * world_));
+        if (c_->opt_shard_interpolation) {
+            cpr_max_ = (std::max(Cm_, Ca_) + G_ - 1) / G_;
+            SP_TRY(alloc((void**)&d_cstage_, sizeof(fe) * (uint64_t)world_ * cpr_max_ * n_));
+        }
     }
-    SP_TRY(alloc((void**)&d_tree_main_, sizeof(digest32) * (2 * N_ - 1)));
-    SP_TRY(alloc((void**)&d_tree_aux_, sizeof(digest32) * (2 * N_ - 1)));
-    SP_TRY(alloc((void**)&d_tree_comp_, sizeof(digest32) * (2 * N_ - 1)));
+    SP_TRY(alloc_tree(tree_main_, N_, G_ > 1));
+    SP_TRY(alloc_tree(tree_aux_, N_, G_ > 1));
+    SP_TRY(alloc_tree(tree_comp_, N_, G_ > 1));
     SP_TRY(alloc((void**)&d_comp_consts_, sizeof(CompositionConsts)));
     SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
     SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
     SP_TRY(alloc((void**)&d_positions_, sizeof(uint64_t) * 4096));
     d_memcols_ = d_trace_ + 19 * n_;  // pc .. off_op1 columns of the main trace (input of the Cairo auxiliary trace)
-    d_fri_evals_.clear(); d_fri_trees_.clear();
+    // FRI: layers of at least 2^opt_fri_shard_min_log leaves (and at least 2 G^2, so that every rank owns whole blocks of the
+    // digest exchange) stay sharded; from layer fri_rep_ on every rank holds the whole layer.  The last, uncommitted fold
+    // output (layer log n) is always replicated.
+    fri_rep_ = 0;
+    if (G_ > 1)
+        while (fri_rep_ < logn_ && (N_ >> fri_rep_) >= std::max<uint64_t>(1ull << c_->opt_fri_shard_min_log, 2ull * G_ * G_)) ++fri_rep_;
+    d_fri_evals_.clear(); fri_trees_.clear();
     for (uint32_t l = 0; l <= logn_; ++l) {
-        fe* e = nullptr; digest32* t = nullptr;
-        uint64_t M = N_ >> l;
-        SP_TRY(alloc((void**)&e, sizeof(fe) * M));
+        fe* e = nullptr;
+        const uint64_t M = N_ >> l;
+        SP_TRY(alloc((void**)&e, sizeof(fe) * (fri_sharded(l) ? M >> logG_ : M)));
         d_fri_evals_.push_back(e);
-        if (l < logn_) { SP_TRY(alloc((void**)&t, sizeof(digest32) * (2 * M - 1))); d_fri_trees_.push_back(t); }
+        if (l < logn_) { TreeBuf t; SP_TRY(alloc_tree(t, M, fri_sharded(l))); fri_trees_.push_back(t); }
     }
     // T1[q] = n^-1 h^rev(q): turns the unscaled DIF output into h-scaled coefficients c_k h^k (bit-reversed order)
     fe ninv = fe_inv(fe_from_u64(n_));
@@ -133,38 +149,79 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     return SP_OK;
 }
 
-// Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank].
+int StarkProver::alloc_tree(TreeBuf& t, uint64_t leaves_total, bool sharded) {
+    t.sub_leaves = sharded ? leaves_total >> logG_ : leaves_total;
+    SP_TRY(alloc((void**)&t.sub, sizeof(digest32) * (2 * t.sub_leaves - 1)));
+    t.top = t.sub;
+    if (sharded) SP_TRY(alloc((void**)&t.top, sizeof(digest32) * (2ull * G_ - 1)));
+    return SP_OK;
+}
+
+int StarkProver::ensure_gather(uint64_t elems) {
+    if (elems <= gather_cap_) return SP_OK;
+    SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
+    gather_cap_ = elems;
+    return SP_OK;
+}
+
+// [N] scratch for the paths that need the whole domain on every rank (constraint-violating traces, G = b)
+int StarkProver::full_domain_buffer(fe** out) {
+    if (!fri_sharded(0)) { *out = d_fri_evals_[0]; return SP_OK; }   // free until round 4
+    if (!d_fullN_) SP_TRY(alloc((void**)&d_fullN_, sizeof(fe) * N_));
+    *out = d_fullN_;
+    return SP_OK;
+}
+
+// Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank]
+// (the first G slots are the G distinct roles).
 int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
     int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
     if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+    c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
     return SP_OK;
 }
 
-// Leaves are hashed from this rank's cosets; with several ranks the 32-byte leaf digests are all-gathered and put back in
-// natural order, then every rank reduces the (replicated) tree.
-int StarkProver::commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]) {
-    if (world_ == 1) {
-        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, N_, tree, lde_order()));
-    } else {
-        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, Nl_, reinterpret_cast<digest32*>(d_local_), lde_order()));
-        SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(digest32)));
-        SP_TRY(interleave_shards(c_->stream, d_gather_, tree + (N_ - 1), n_, shard_map()));
-        // Merkle combine: every rank reduces the subtree over its contiguous 1/G of the leaves,
-        // the G subtree roots are all-gathered and the top log2 G levels finished everywhere.  Authentication paths are
-        // served by the rank that owns the leaf's subtree (open()).
-        const uint64_t G = world_;
-        SP_TRY(merkle_reduce_subtree(c_->stream, tree, N_, logG_, rank_));
-        SP_HIP_CHECK(hipMemcpyAsync(d_local_, tree + (G - 1) + rank_, sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
-        SP_TRY(all_gather(d_local_, d_gather_, sizeof(digest32)));
-        SP_HIP_CHECK(hipMemcpyAsync(tree + (G - 1), d_gather_, G * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
-        SP_TRY(merkle_reduce(c_->stream, tree, G));
-        SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
+// Block d of `send` goes to the rank with role d; recv[s] = what role s addressed to this rank.  One all-to-all when the
+// hook exists (every rank is its own role then); otherwise an all-gather of the whole send array and a local selection.
+int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes) {
+    if (c_->alltoall && world_ == G_) {
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        int rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes);
+        if (rc != 0) { sp_set_error("all-to-all hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+        c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
         return SP_OK;
     }
-    SP_TRY(merkle_reduce(c_->stream, tree, N_));
-    SP_HIP_CHECK(hipMemcpyAsync(root_out, tree, 32, hipMemcpyDeviceToHost, c_->stream));
+    const uint64_t per_rank = bytes * G_;
+    SP_TRY(ensure_gather((per_rank * world_ + sizeof(fe) - 1) / sizeof(fe)));
+    SP_TRY(all_gather(send_dev, d_gather_, per_rank));
+    const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gather_);
+    for (uint32_t src = 0; src < G_; ++src)   // the first G slots are the G roles
+        SP_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(recv_dev) + (uint64_t)src * bytes, g + (uint64_t)src * per_rank + (uint64_t)rank_ * bytes, bytes,
+                                    hipMemcpyDeviceToDevice, c_->stream));
+    return SP_OK;
+}
+
+// batch_commit (reference prover.rs:96-104) / FriLayer::new's tree (fri_commitment.rs:39) over leaves this rank holds in local
+// natural order.  Several ranks: the 32-byte leaf digests are exchanged so that rank d owns the contiguous leaves
+// [d N/G, (d+1) N/G) - block d of the local digest array is exactly this rank's share of that range - then every rank reduces
+// its subtree, the G subtree roots are all-gathered and the top log2 G levels finished everywhere.
+int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32]) {
+    if (tree.top == tree.sub) {   // the whole tree on this rank
+        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, L, tree.sub, order));
+        SP_TRY(merkle_reduce(c_->stream, tree.sub, L));
+    } else {
+        if (L != tree.sub_leaves || L > Nl_) return SP_E_STATE;
+        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<digest32*>(d_local_), order));
+        SP_TRY(exchange_blocks(d_local_, d_recv_, (L >> logG_) * sizeof(digest32)));
+        // recv[s][j] = leaf (first + j) G + s of the global order = leaf j G + s of this rank's range
+        SP_TRY(interleave_shards(c_->stream, d_recv_, tree.sub + (L - 1), L >> logG_, ShardMap{logG_, logG_, 0}));
+        SP_TRY(merkle_reduce(c_->stream, tree.sub, L));
+        SP_TRY(all_gather(tree.sub, d_roots_, sizeof(digest32)));
+        SP_HIP_CHECK(hipMemcpyAsync(tree.top + (G_ - 1), d_roots_, G_ * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
+        SP_TRY(merkle_reduce(c_->stream, tree.top, G_));
+    }
+    SP_HIP_CHECK(hipMemcpyAsync(root_out, tree.top, 32, hipMemcpyDeviceToHost, c_->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
     return SP_OK;
 }
@@ -194,12 +251,26 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients (the trace stays intact)
-    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
+    if (G_ > 1 && d_cstage_ && cols >= G_) {
+        // columns are independent (prover.rs:174-183): role s interpolates the cpr columns from min(s cpr, cols - cpr) on
+        // (the last blocks overlap instead of being ragged), one all-gather brings every coefficient everywhere (§8(e) item 1)
+        const uint32_t cpr = (cols + G_ - 1) / G_;
+        auto first_col = [&](uint32_t role) { return std::min(role * cpr, cols - cpr); };
+        const uint64_t blk = (uint64_t)cpr * n_;
+        fe* mine = d_cstage_ + (uint64_t)wrank_ * blk;
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(mine, (int)logn_, cpr, n_, d_t1_, d_trace_ + (uint64_t)(col0 + first_col(rank_)) * n_));
+        SP_TRY(all_gather(mine, d_cstage_, blk * sizeof(fe)));   // in place: slot `rank` of the receive buffer is the send buffer
+        for (uint32_t role = 0; role < G_; ++role)
+            SP_HIP_CHECK(hipMemcpyAsync(coeffs + (uint64_t)first_col(role) * n_, d_cstage_ + (uint64_t)role * blk, blk * sizeof(fe),
+                                        hipMemcpyDeviceToDevice, c_->stream));
+    } else {
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
+    }
     // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     SP_TRY(c_->ntt->lde_coset_major(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     // batch_commit (reference prover.rs:96-104) straight from the column-major LDE
-    SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? d_tree_main_ : d_tree_aux_, root_out));
+    SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
     return SP_OK;
 }
@@ -431,8 +502,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
                                   const fe* ex_roots_dev, bool allow_sub_coset, uint8_t root_out[32]) {
     const fe* roots = nullptr;
     SP_TRY(c_->ntt->roots((int)logN_, &roots));
-    fe* comp = d_fri_evals_[0];              // [N] full composition evaluations (the FRI layer-0 buffer is free until round 4)
-    fe* comp_local = world_ == 1 ? comp : d_local_;
+    fe* comp = nullptr;                      // [N] whole-domain composition evaluations (exceptional paths only, fetched below)
     const uint32_t nd = (uint32_t)points.size();
     auto evaluate = [&](uint64_t count, uint32_t stride_log, const fe* binv, fe* out) -> int {
         if (prog_dev) return air_composition(c_->stream, d_lde_, count, Nl_, stride_log, logN_, logb_, roots, d_comp_consts_, prog_dev, ex_roots_dev, binv, out, logG_, rank_);
@@ -483,6 +553,8 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         h_full_ = false;
         SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else {
+        SP_TRY(full_domain_buffer(&comp));
+        fe* comp_local = G_ == 1 ? comp : d_local_;
         fe* binv = d_scratch_;                  // [ndist][Nl]
         fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 Nl]
         if (nd) {
@@ -490,7 +562,8 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
         }
         SP_TRY(evaluate(Nl_, 0, binv, comp_local));
-        if (world_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
+        if (G_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
+            SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
             SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
             SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
         }
@@ -507,19 +580,21 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
             SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
         } else {
-            if (world_ > 1) { sp_set_error("composition: the trace violates its constraints (deg H >= 2n); unsupported with coset sharding"); return SP_E_UNSUPPORTED; }
+            // the trace violates its constraints: deg H >= 2n and the reference still proves it (longer H1, H2).  Every rank
+            // holds all of H, evaluates H1, H2 on the whole domain and keeps the points of its own cosets.
             if (!d_hfull_) SP_TRY(alloc((void**)&d_hfull_, sizeof(fe) * N_));
             fe* t_half = d_scratch_;  // N/2 entries: N^-1 h^(-rev_{N/2}(q))
+            if ((N_ >> 1) > scratch_elems()) { sp_set_error("composition: scratch too small"); return SP_E_ALLOC; }
             fe Ninv = fe_inv(fe_from_u64(N_));
             SP_TRY(gen_power_table(c_->stream, t_half, N_ >> 1, logN_ - 1, hinv_, Ninv));
             SP_TRY(split_composition_full(c_->stream, comp, N_, t_half, hinv_, d_hfull_, d_hfull_ + (N_ >> 1)));
             // H1, H2 of N/2 coefficients each: natural-order evaluations first, then into the coset-major order of every other column
             if (!d_hnat_) SP_TRY(alloc((void**)&d_hnat_, sizeof(fe) * N_ * 2));
             SP_TRY(c_->ntt->lde_from_bitrev(d_hfull_, d_hnat_, (int)logN_ - 1, 1, 2, N_ >> 1, N_));
-            SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, d_h12_, N_, 2, lde_order()));
+            SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, N_, d_h12_, Nl_, 2, lde_order(), logG_, rank_));
         }
     }
-    SP_TRY(commit_columns(d_h12_, Nl_, 2, d_tree_comp_, root_out));
+    SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
     stage_ = 4;
     return SP_OK;
 }
@@ -675,9 +750,11 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order()));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, d_post_deep_));   // n^-1 w_N^(-c0 j): setup()
-        SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
+        // FRI layer 0: the evaluations this rank holds (local natural order) when the layer is sharded, the whole domain otherwise
+        if (fri_sharded(0)) SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, Nl_, (int)logG_, (int)rank_));
+        else SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
     } else {
-        // deg H >= 2n (constraint-violating trace, single GPU only): the quotient form on the whole domain
+        // deg H >= 2n (constraint-violating trace): the quotient form on every LDE point this rank holds
         fe* inv = d_scratch_;
         if (2ull * npts * Nl_ > scratch_elems()) {   // more than two frame rows: the inverses outgrow the shared scratch
             void* big = nullptr;
@@ -687,17 +764,20 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         fe* inv_scratch = inv + (uint64_t)npts * Nl_;
         SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * Nl_, c_->d_flag));
-        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, d_fri_evals_[0], lde_order()));
+        fe* p0_local = (G_ == 1 || fri_sharded(0)) ? d_fri_evals_[0] : d_local_;   // local natural order
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, p0_local, lde_order()));
+        if (G_ > 1 && !fri_sharded(0)) {
+            SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
+            SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe)));
+            SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[0], n_, shard_map()));
+        }
     }
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;
     fri_offset_ = h_;
-    SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[0], N_, 1, N_, d_fri_trees_[0]));
-    SP_TRY(merkle_reduce(c_->stream, d_fri_trees_[0], N_));
-    SP_HIP_CHECK(hipMemcpyAsync(root0_out, d_fri_trees_[0], 32, hipMemcpyDeviceToHost, c_->stream));
     int flag = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    SP_TRY(commit_local(d_fri_evals_[0], 0, 1, fri_trees_[0].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[0], root0_out));   // synchronises
     if (flag) { sp_set_error("deep composition: z lies on the LDE coset"); return SP_E_ZERO_INVERSE; }
     fri_layer_ = 1;
     stage_ = 6;
@@ -713,14 +793,22 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
     const uint64_t M = N_ >> k;
     fe half = fe_inv(fe_from_u64(2));
     fe cst = fe_mul(fe_mul(zeta, half), fe_inv(fri_offset_));
-    SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half, cst));
+    // In evaluation form the fold is local to a rank: the partner i + M/2 of index i has the same residue mod G (§8(e) item 4)
+    if (fri_sharded(k)) {
+        const uint64_t Ml = M >> logG_;
+        fe* next_local = fri_sharded(k + 1) ? d_fri_evals_[k + 1] : d_local_;
+        SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], next_local, Ml, logN_, k, roots, half, cst, logG_, rank_));
+        if (!fri_sharded(k + 1)) {   // from here on the layers are small: gather this one once and continue on every rank
+            SP_TRY(ensure_gather((uint64_t)world_ * (Ml >> 1)));
+            SP_TRY(all_gather(next_local, d_gather_, (Ml >> 1) * sizeof(fe)));
+            SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[k + 1], (Ml >> 1), ShardMap{logG_, logG_, 0}));
+        }
+    } else {
+        SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half, cst));
+    }
     fri_offset_ = fe_sqr(fri_offset_);
     if (k + 1 < logn_) {
-        uint64_t Mn = M >> 1;
-        SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], Mn, 1, Mn, d_fri_trees_[k + 1]));
-        SP_TRY(merkle_reduce(c_->stream, d_fri_trees_[k + 1], Mn));
-        SP_HIP_CHECK(hipMemcpyAsync(root_out, d_fri_trees_[k + 1], 32, hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_TRY(commit_local(d_fri_evals_[k + 1], 0, 1, fri_trees_[k + 1].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[k + 1], root_out));
         fri_layer_ += 1;
         *is_last = 0;
     } else {
@@ -758,6 +846,11 @@ int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* no
     }
 }
 
+// fri_query_phase + open_deep_composition_poly (reference fri/mod.rs:74-127, prover.rs:484-529).  Every queried value and
+// authentication path is gathered on the device into one staging block with the same layout on every rank; with several
+// ranks the blocks are all-gathered once and the copy of the rank that owns the item is kept: LDE rows and sharded FRI values
+// live on the rank with role index mod G, the lower levels of a sharded tree on the rank whose contiguous leaf range holds
+// the index, the top log2 G levels everywhere.
 int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     if (stage_ != 7) { sp_set_error("open: FRI commit phase not finished"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
@@ -766,148 +859,114 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     const uint32_t L = logn_, d0 = logN_;
     o.n_queries = q; o.n_layers = L; o.n_cols = C_; o.depth0 = d0;
     hipStream_t st = c_->stream;
-    // device staging inside the scratch area; many queries on a tiny domain outgrow it and get their own buffer
-    uint8_t* base = reinterpret_cast<uint8_t*>(d_scratch_);
-    size_t off = 0;
-    auto carve = [&](size_t bytes) { void* p = base + off; off += (bytes + 255) & ~size_t(255); return p; };
-    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp1, tmp;
-    {
-        const size_t need1 = 5 * 256 + sizeof(fe) * q * (C_ + 2) + 3 * sizeof(digest32) * q * d0;
-        if (need1 > scratch_elems() * sizeof(fe)) {
-            if (hipMalloc(&tmp1.p, need1) != hipSuccess) { sp_set_error("open: staging allocation failed"); return SP_E_ALLOC; }
-            base = static_cast<uint8_t*>(tmp1.p);
-        }
-    }
+    const LdeOrder ord = lde_order();
+    struct TreeJob { const TreeBuf* t; std::vector<uint64_t> idx; size_t lower_off = 0, upper_off = 0, ipos = 0, iown = 0; uint32_t dl = 0, du = 0; };
+    struct ValJob { const fe* base; uint64_t stride; uint32_t ncols; bool sharded; std::vector<uint64_t> idx, local; size_t off = 0, ipos = 0; };
+    std::vector<TreeJob> tj;
+    std::vector<ValJob> vj;
     std::vector<uint64_t> pos(q);
     for (uint32_t s = 0; s < q; ++s) pos[s] = iotas[s] % N_;
-    SP_HIP_CHECK(hipMemcpyAsync(d_positions_, pos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    fe* g_trace = (fe*)carve(sizeof(fe) * q * C_);
-    fe* g_comp = (fe*)carve(sizeof(fe) * q * 2);
-    digest32* p_main = (digest32*)carve(sizeof(digest32) * q * d0);
-    digest32* p_aux = (digest32*)carve(sizeof(digest32) * q * d0);
-    digest32* p_comp = (digest32*)carve(sizeof(digest32) * q * d0);
-    const LdeOrder ord = lde_order();
-    uint64_t* d_spos = d_positions_ + 1024;   // positions inside the coset-major columns
-    if (world_ == 1) {
-        std::vector<uint64_t> spos(q);
-        for (uint32_t s = 0; s < q; ++s) spos[s] = ord.at(pos[s]);
-        SP_HIP_CHECK(hipMemcpyAsync(d_spos, spos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        SP_TRY(gather_rows(st, d_lde_, N_, C_, d_spos, q, g_trace));
-        SP_TRY(gather_rows(st, d_h12_, N_, 2, d_spos, q, g_comp));
-        SP_HIP_CHECK(hipStreamSynchronize(st));  // spos is a local
-    } else {
-        // the LDE rows live on the rank that owns the coset of each queried index: gather local rows (index 0 for rows
-        // owned elsewhere), all-gather the small row blocks and keep the owner's copy
-        const uint32_t b = 1u << logb_, b_loc = b >> logG_;
-        std::vector<uint64_t> lpos(q);
-        for (uint32_t s = 0; s < q; ++s) {
-            uint64_t cg = pos[s] & (b - 1), qq = pos[s] >> logb_;
-            lpos[s] = ((cg & (world_ - 1)) == rank_) ? ord.at(qq * b_loc + (cg >> logG_)) : 0;
-        }
-        uint64_t* d_lpos = d_positions_ + 2048;
-        SP_HIP_CHECK(hipMemcpyAsync(d_lpos, lpos.data(), q * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-        const size_t blk = (size_t)q * (C_ + 2);
-        if (blk * world_ > N_ || blk > Nl_) { sp_set_error("open: too many queries for the staging buffers"); return SP_E_UNSUPPORTED; }
-        fe* send = d_local_;
-        SP_TRY(gather_rows(st, d_lde_, Nl_, C_, d_lpos, q, send));
-        SP_TRY(gather_rows(st, d_h12_, Nl_, 2, d_lpos, q, send + (size_t)q * C_));
-        SP_TRY(all_gather(send, d_gather_, blk * sizeof(fe)));
-        std::vector<fe> all(blk * world_);
-        SP_HIP_CHECK(hipMemcpy(all.data(), d_gather_, all.size() * sizeof(fe), hipMemcpyDeviceToHost));
-        std::vector<fe> tsel((size_t)q * C_), csel((size_t)q * 2);
-        for (uint32_t s = 0; s < q; ++s) {
-            uint32_t owner = (uint32_t)(pos[s] & (b - 1)) & (world_ - 1);
-            const fe* blkp = all.data() + (size_t)owner * blk;
-            std::copy(blkp + (size_t)s * C_, blkp + (size_t)(s + 1) * C_, tsel.begin() + (size_t)s * C_);
-            std::copy(blkp + (size_t)q * C_ + 2 * s, blkp + (size_t)q * C_ + 2 * s + 2, csel.begin() + 2 * s);
-        }
-        SP_HIP_CHECK(hipMemcpyAsync(g_trace, tsel.data(), tsel.size() * sizeof(fe), hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(hipMemcpyAsync(g_comp, csel.data(), csel.size() * sizeof(fe), hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(hipStreamSynchronize(st));  // tsel / csel are locals
+    auto local_row = [&](uint64_t i) -> uint64_t {   // position of LDE row i inside the coset-major columns of its owner
+        return ord.at(i >> logG_);
+    };
+    {   // trace and composition rows
+        ValJob t{d_lde_, Nl_, C_, G_ > 1, pos, {}}; ValJob c{d_h12_, Nl_, 2, G_ > 1, pos, {}};
+        for (uint32_t s = 0; s < q; ++s) { uint64_t l = ((pos[s] & (G_ - 1)) == rank_) ? local_row(pos[s]) : 0; t.local.push_back(l); c.local.push_back(l); }
+        vj.push_back(std::move(t)); vj.push_back(std::move(c));
     }
-    SP_TRY(merkle_gather_paths(st, d_tree_main_, N_, d_positions_, q, p_main));
-    if (Ca_) SP_TRY(merkle_gather_paths(st, d_tree_aux_, N_, d_positions_, q, p_aux));
-    SP_TRY(merkle_gather_paths(st, d_tree_comp_, N_, d_positions_, q, p_comp));
-    if (world_ > 1) {
-        // the trees are reduced in contiguous shares (commit_columns): below the replicated top only the rank that owns the
-        // leaf's subtree has the siblings.  All-gather every rank's view of the paths and keep the owner's.
-        const size_t per = (size_t)q * d0;                 // digests per tree
-        const size_t blk = 3 * per;
-        if (blk * world_ > N_ || blk > Nl_) { sp_set_error("open: too many queries for the staging buffers"); return SP_E_UNSUPPORTED; }
-        digest32* send = reinterpret_cast<digest32*>(d_local_);
-        SP_HIP_CHECK(hipMemcpyAsync(send, p_main, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
-        if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(send + per, p_aux, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
-        SP_HIP_CHECK(hipMemcpyAsync(send + 2 * per, p_comp, per * sizeof(digest32), hipMemcpyDeviceToDevice, st));
-        SP_TRY(all_gather(send, d_gather_, blk * sizeof(digest32)));
-        std::vector<digest32> all(blk * world_), sel(blk);
-        SP_HIP_CHECK(hipMemcpy(all.data(), d_gather_, all.size() * sizeof(digest32), hipMemcpyDeviceToHost));
-        const uint64_t leaves_per_rank = N_ >> logG_;
-        for (uint32_t s = 0; s < q; ++s) {
-            const size_t owner = (size_t)(pos[s] / leaves_per_rank);
-            for (int t3 = 0; t3 < 3; ++t3)
-                std::copy(all.begin() + owner * blk + t3 * per + (size_t)s * d0, all.begin() + owner * blk + t3 * per + (size_t)(s + 1) * d0,
-                          sel.begin() + t3 * per + (size_t)s * d0);
-        }
-        SP_HIP_CHECK(hipMemcpyAsync(p_main, sel.data(), per * sizeof(digest32), hipMemcpyHostToDevice, st));
-        if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(p_aux, sel.data() + per, per * sizeof(digest32), hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(hipMemcpyAsync(p_comp, sel.data() + 2 * per, per * sizeof(digest32), hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(hipStreamSynchronize(st));  // sel is a local
-    }
-    o.trace_evals.resize((size_t)q * C_); o.comp_evals.resize((size_t)q * 2);
-    o.main_paths.resize((size_t)q * d0); o.aux_paths.resize((size_t)q * d0); o.comp_paths.resize((size_t)q * d0);
-    SP_HIP_CHECK(hipMemcpyAsync(o.trace_evals.data(), g_trace, sizeof(fe) * q * C_, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipMemcpyAsync(o.comp_evals.data(), g_comp, sizeof(fe) * q * 2, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipMemcpyAsync(o.main_paths.data(), p_main, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
-    if (Ca_) SP_HIP_CHECK(hipMemcpyAsync(o.aux_paths.data(), p_aux, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipMemcpyAsync(o.comp_paths.data(), p_comp, sizeof(digest32) * q * d0, hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipStreamSynchronize(st));
-    // FRI layers (reference fri/mod.rs:74-127): index iota mod |D_k| and its symmetric index.  All layers in one go: one
-    // upload of the 2qL indices, the gathers queued back to back into one staging area, one download.
-    size_t path_total = 0;
-    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
-    o.fri_evals.assign((size_t)q * L, fe_zero()); o.fri_evals_sym.assign((size_t)q * L, fe_zero());
-    o.fri_paths.assign((size_t)q * path_total, digest32{}); o.fri_paths_sym.assign((size_t)q * path_total, digest32{});
-    std::vector<uint64_t> idx((size_t)2 * q * L);
-    for (uint32_t k = 0; k < L; ++k) {
+    tj.push_back(TreeJob{&tree_main_, pos});
+    if (Ca_) tj.push_back(TreeJob{&tree_aux_, pos});
+    tj.push_back(TreeJob{&tree_comp_, pos});
+    for (uint32_t k = 0; k < L; ++k) {   // FRI layers: index iota mod |D_k| and its symmetric index
         const uint64_t M = N_ >> k;
-        for (uint32_t s = 0; s < q; ++s) { idx[(size_t)2 * q * k + s] = iotas[s] % M; idx[(size_t)2 * q * k + q + s] = (iotas[s] + M / 2) % M; }
+        std::vector<uint64_t> idx(2 * (size_t)q);
+        for (uint32_t s = 0; s < q; ++s) { idx[s] = iotas[s] % M; idx[q + s] = (iotas[s] + M / 2) % M; }
+        ValJob v{d_fri_evals_[k], 0, 1, fri_sharded(k), idx, {}};
+        for (uint64_t i : idx) v.local.push_back(fri_sharded(k) ? (((i & (G_ - 1)) == rank_) ? (i >> logG_) : 0) : i);
+        vj.push_back(std::move(v));
+        tj.push_back(TreeJob{&fri_trees_[k], idx});
     }
-    off = 0;
-    const size_t need = 3 * 256 + sizeof(uint64_t) * idx.size() + sizeof(fe) * 2 * q * L + sizeof(digest32) * 2 * q * path_total;
-    base = reinterpret_cast<uint8_t*>(d_scratch_);
+    // staging layout (32-byte items) and the index array (uint64)
+    size_t items = 0, nidx = 0;
+    for (auto& v : vj) { v.off = items; items += v.idx.size() * v.ncols; v.ipos = nidx; nidx += v.idx.size(); }
+    for (auto& t : tj) {
+        t.dl = (uint32_t)sp_log2_exact(t.t->sub_leaves); t.du = t.t->top == t.t->sub ? 0u : logG_;
+        t.lower_off = items; items += t.idx.size() * t.dl;
+        t.upper_off = items; items += t.idx.size() * t.du;
+        t.ipos = nidx; nidx += t.idx.size();
+        t.iown = nidx; if (t.du) nidx += t.idx.size();
+    }
+    std::vector<uint64_t> hidx(nidx);
+    for (auto& v : vj) std::copy(v.local.begin(), v.local.end(), hidx.begin() + v.ipos);
+    for (auto& t : tj)
+        for (size_t s = 0; s < t.idx.size(); ++s) {
+            hidx[t.ipos + s] = t.idx[s] & (t.t->sub_leaves - 1);
+            if (t.du) hidx[t.iown + s] = t.idx[s] / t.t->sub_leaves;
+        }
+    const size_t idx_bytes = (nidx * sizeof(uint64_t) + 255) & ~size_t(255);
+    const size_t blk_bytes = items * 32;
+    const size_t need = idx_bytes + blk_bytes * (G_ > 1 ? 1 + (size_t)world_ : 1);
+    struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp;   // many queries on a tiny domain: own staging buffer
+    uint8_t* base = reinterpret_cast<uint8_t*>(d_scratch_);
     if (need > scratch_elems() * sizeof(fe)) {
         if (hipMalloc(&tmp.p, need) != hipSuccess) { sp_set_error("open: staging allocation failed"); return SP_E_ALLOC; }
         base = static_cast<uint8_t*>(tmp.p);
     }
-    uint64_t* d_idx = (uint64_t*)carve(sizeof(uint64_t) * idx.size());
-    fe* gv = (fe*)carve(sizeof(fe) * 2 * q * L);
-    digest32* gp = (digest32*)carve(sizeof(digest32) * 2 * q * path_total);
-    SP_HIP_CHECK(hipMemcpyAsync(d_idx, idx.data(), idx.size() * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    {
-        size_t po = 0;
-        for (uint32_t k = 0; k < L; ++k) {
-            const uint64_t M = N_ >> k;
-            const uint32_t depth = d0 - k;
-            SP_TRY(gather_rows(st, d_fri_evals_[k], M, 1, d_idx + (size_t)2 * q * k, 2 * q, gv + (size_t)2 * q * k));
-            SP_TRY(merkle_gather_paths(st, d_fri_trees_[k], M, d_idx + (size_t)2 * q * k, 2 * q, gp + 2 * q * po));
-            po += depth;
-        }
+    uint64_t* d_idx = reinterpret_cast<uint64_t*>(base);
+    fe* blk = reinterpret_cast<fe*>(base + idx_bytes);
+    fe* all_dev = blk + items;
+    SP_HIP_CHECK(hipMemcpyAsync(d_idx, hidx.data(), nidx * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+    for (auto& v : vj) SP_TRY(gather_rows(st, v.base, v.stride, v.ncols, d_idx + v.ipos, (uint32_t)v.idx.size(), blk + v.off));
+    for (auto& t : tj) {
+        SP_TRY(merkle_gather_paths(st, t.t->sub, t.t->sub_leaves, d_idx + t.ipos, (uint32_t)t.idx.size(), reinterpret_cast<digest32*>(blk + t.lower_off)));
+        if (t.du) SP_TRY(merkle_gather_paths(st, t.t->top, G_, d_idx + t.iown, (uint32_t)t.idx.size(), reinterpret_cast<digest32*>(blk + t.upper_off)));
     }
-    std::vector<fe> hv((size_t)2 * q * L);
-    std::vector<digest32> hp((size_t)2 * q * path_total);
-    SP_HIP_CHECK(hipMemcpyAsync(hv.data(), gv, sizeof(fe) * hv.size(), hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipMemcpyAsync(hp.data(), gp, sizeof(digest32) * hp.size(), hipMemcpyDeviceToHost, st));
-    SP_HIP_CHECK(hipStreamSynchronize(st));
+    std::vector<fe> host(items * (G_ > 1 ? world_ : 1));
+    if (G_ > 1) {
+        SP_TRY(all_gather(blk, all_dev, blk_bytes));
+        SP_HIP_CHECK(hipMemcpyAsync(host.data(), all_dev, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
+    } else {
+        SP_HIP_CHECK(hipMemcpyAsync(host.data(), blk, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
+    }
+    SP_HIP_CHECK(hipStreamSynchronize(st));   // (hidx is a local)
+    auto slot = [&](uint32_t owner) -> const fe* { return host.data() + (G_ > 1 ? (size_t)owner * items : 0); };
+    auto take_values = [&](const ValJob& v, size_t s, fe* dst) {
+        const uint32_t owner = v.sharded ? (uint32_t)(v.idx[s] & (G_ - 1)) : rank_;
+        const fe* src = slot(owner) + v.off + s * v.ncols;
+        std::copy(src, src + v.ncols, dst);
+    };
+    auto take_path = [&](const TreeJob& t, size_t s, digest32* dst) {
+        const uint32_t owner = t.du ? (uint32_t)(t.idx[s] / t.t->sub_leaves) : rank_;
+        std::memcpy(dst, slot(owner) + t.lower_off + s * t.dl, (size_t)t.dl * 32);
+        if (t.du) std::memcpy(dst + t.dl, slot(rank_) + t.upper_off + s * t.du, (size_t)t.du * 32);
+    };
+    o.trace_evals.resize((size_t)q * C_); o.comp_evals.resize((size_t)q * 2);
+    o.main_paths.assign((size_t)q * d0, digest32{}); o.aux_paths.assign((size_t)q * d0, digest32{}); o.comp_paths.assign((size_t)q * d0, digest32{});
+    size_t path_total = 0;
+    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
+    o.fri_evals.assign((size_t)q * L, fe_zero()); o.fri_evals_sym.assign((size_t)q * L, fe_zero());
+    o.fri_paths.assign((size_t)q * path_total, digest32{}); o.fri_paths_sym.assign((size_t)q * path_total, digest32{});
+    size_t ti = 0;
+    const TreeJob& jm = tj[ti++];
+    const TreeJob* ja = Ca_ ? &tj[ti++] : nullptr;
+    const TreeJob& jc = tj[ti++];
+    for (uint32_t s = 0; s < q; ++s) {
+        take_values(vj[0], s, &o.trace_evals[(size_t)s * C_]);
+        take_values(vj[1], s, &o.comp_evals[(size_t)s * 2]);
+        take_path(jm, s, &o.main_paths[(size_t)s * d0]);
+        if (ja) take_path(*ja, s, &o.aux_paths[(size_t)s * d0]);
+        take_path(jc, s, &o.comp_paths[(size_t)s * d0]);
+    }
     size_t path_off = 0;
     for (uint32_t k = 0; k < L; ++k) {
         const uint32_t depth = d0 - k;
-        const fe* v = hv.data() + (size_t)2 * q * k;
-        const digest32* pp = hp.data() + (size_t)2 * q * path_off;
+        const ValJob& v = vj[2 + k];
+        const TreeJob& t = tj[ti + k];
         for (uint32_t s = 0; s < q; ++s) {
-            o.fri_evals[(size_t)s * L + k] = v[s];
-            o.fri_evals_sym[(size_t)s * L + k] = v[q + s];
-            std::copy(pp + (size_t)s * depth, pp + (size_t)(s + 1) * depth, o.fri_paths.begin() + (size_t)s * path_total + path_off);
-            std::copy(pp + (size_t)(q + s) * depth, pp + (size_t)(q + s + 1) * depth, o.fri_paths_sym.begin() + (size_t)s * path_total + path_off);
+            take_values(v, s, &o.fri_evals[(size_t)s * L + k]);
+            take_values(v, q + s, &o.fri_evals_sym[(size_t)s * L + k]);
+            take_path(t, s, &o.fri_paths[(size_t)s * path_total + path_off]);
+            take_path(t, q + s, &o.fri_paths_sym[(size_t)s * path_total + path_off]);
         }
         path_off += depth;
     }

@@ -70,11 +70,21 @@ class StarkProver : public sp_deletable {
     float round_ms[5] = {0, 0, 0, 0, 0};
 
   private:
+    // One commitment tree.  Single GPU: `sub` is the whole tree (lambdaworks node order, 2 leaves - 1 nodes), top == sub.
+    // Sharded: `sub` is the subtree over this rank's CONTIGUOUS 1/G of the leaves, `top` the replicated tree over the G
+    // subtree roots; root = top[0].
+    struct TreeBuf { digest32* sub = nullptr; digest32* top = nullptr; uint64_t sub_leaves = 0; };
     void free_all();
     int alloc(void** p, size_t bytes);
+    int alloc_tree(TreeBuf& t, uint64_t leaves_total, bool sharded);
     int setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
     bool ready_ = false;   // setup() completed: every buffer below exists
-    int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, digest32* tree, uint8_t root_out[32]);
+    // Commitment over `L` leaves this rank holds in local natural order (leaf l = global leaf (l << logG) | rank): hash,
+    // exchange the digests so that every rank owns a contiguous range, reduce the subtree, combine the G roots.
+    int commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32]);
+    int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, TreeBuf& tree, uint8_t root_out[32]) {
+        return commit_local(cols_dev, stride, ncols, Nl_, lde_order(), tree, root_out);
+    }
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
@@ -88,11 +98,23 @@ class StarkProver : public sp_deletable {
     ProofOptionsHost opt_{};
     uint64_t n_ = 0, N_ = 0;
     uint32_t logn_ = 0, logb_ = 0, logN_ = 0, Cm_ = 0, Ca_ = 0, C_ = 0;
-    // coset sharding: this rank holds the cosets c = c_loc * G + rank; Nl_ = N / G local LDE points
-    uint32_t world_ = 1, rank_ = 0, logG_ = 0;
+    // Sharding: G = min(world, blowup) groups; the rank with role r = rank mod G holds the LDE points with
+    // global index i = r (mod G) - the cosets c = c_loc * G + r - as Nl_ = N / G local points, local natural index
+    // l = i div G.  Ranks beyond the blowup factor are replicas of the role they share (world_ > G_).
+    uint32_t world_ = 1, wrank_ = 0;   // communicator size and rank
+    uint32_t G_ = 1, rank_ = 0, logG_ = 0;   // groups, this rank's role, log2(G_)
     uint64_t Nl_ = 0;
-    fe *d_local_ = nullptr, *d_gather_ = nullptr;   // 32-byte staging: local shard [Nl], all-gathered shards [G][Nl]
+    fe* d_local_ = nullptr;    // [Nl] 32-byte items: local leaf digests (send side of the exchange)
+    fe* d_recv_ = nullptr;     // [Nl] 32-byte items: the digests of this rank's contiguous leaf range, by source rank
+    fe* d_gather_ = nullptr; uint64_t gather_cap_ = 0;   // all-gather landing zone, grown on demand
+    fe* d_cstage_ = nullptr; uint32_t cpr_max_ = 0;       // [world][cpr_max][n] coefficient all-gather (column-sharded interpolation)
+    digest32* d_roots_ = nullptr;                          // [world] subtree roots
+    fe* d_fullN_ = nullptr;                                // [N] whole-domain scratch when FRI layer 0 is sharded (exceptional paths)
+    int ensure_gather(uint64_t elems);
+    int full_domain_buffer(fe** out);
     int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+    // recv[s] = the block rank s addressed to this role: send = [G][bytes], recv = [G][bytes]
+    int exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes_per_block);
     ShardMap shard_map() const { return ShardMap{logb_, logG_, rank_}; }
     bool has_rc_ = false;
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
@@ -100,9 +122,13 @@ class StarkProver : public sp_deletable {
     fe *d_coeffs_ = nullptr, *d_lde_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr;
     fe* d_trace_ = nullptr;  // [C][n] the trace itself, natural order (kept for the constraint check of round 2)
     fe *d_h12s_ = nullptr, *d_h12_ = nullptr, *d_scratch_ = nullptr;  // scratch: 4N elements
-    digest32 *d_tree_main_ = nullptr, *d_tree_aux_ = nullptr, *d_tree_comp_ = nullptr;
-    std::vector<fe*> d_fri_evals_;          // layer k: N >> k elements
-    std::vector<digest32*> d_fri_trees_;
+    TreeBuf tree_main_, tree_aux_, tree_comp_;
+    // FRI layer k: N >> k evaluations; layers below fri_rep_ are sharded (local natural order, N >> k >> logG elements and
+    // a sharded tree), the others replicated on every rank
+    std::vector<fe*> d_fri_evals_;
+    std::vector<TreeBuf> fri_trees_;
+    uint32_t fri_rep_ = 0;                  // first replicated layer (0: the whole FRI is replicated)
+    bool fri_sharded(uint32_t k) const { return k < fri_rep_; }
     uint32_t fri_layer_ = 0;                // number of committed layers so far
     fe fri_offset_;                         // h^(2^layer)
     CompositionConsts* d_comp_consts_ = nullptr;

@@ -104,15 +104,19 @@ int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, 
 // fold_polynomial + FriLayer::new (reference src/starks/fri/fri_functions.rs:4-27, fri_commitment.rs:30-47) in evaluation
 // form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.
 // roots_N: half table of w_N; M = N >> layer. c = zeta / (2 * offset).
-int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c);
+// Sharded layer: M = the elements this rank holds, local index l = global index (l << shard_log) | shard_rank.
+int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
+             uint32_t shard_log = 0, uint32_t shard_rank = 0);
 
 // generate_nonce_with_grinding (reference src/starks/grinding.rs:17-48): smallest nonce in [start, start+count) whose
 // Keccak256(challenge || nonce_le)[0..8] (BE) has >= factor trailing zeros; *result_dev = min(*result_dev, nonce).
 int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uint64_t start, uint64_t count, unsigned long long* result_dev);
 
 // out[r*cols + j] = cols_base[j*col_stride + rows[r]]
-// dst column v (coset-major order) = src column v (natural order), `len` elements per column
-int natural_to_coset_major(hipStream_t st, const fe* src, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order);
+// dst column v (coset-major order, the `len` evaluations this rank holds) = src column v (natural order of the whole domain,
+// columns at src_stride); local natural index l is the global index (l << shard_log) | shard_rank
+int natural_to_coset_major(hipStream_t st, const fe* src, uint64_t src_stride, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order,
+                           uint32_t shard_log = 0, uint32_t shard_rank = 0);
 int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out);
 
 }  // namespace sp

@@ -410,19 +410,24 @@ int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, 
 
 // ---------------------------------------------------------------------------------------------- FRI fold
 struct FriArgs { fe half, c; };
-__global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, uint64_t Mh, uint32_t logN, uint32_t layer, const fe* roots, FriArgs a) {
+// Sharded layers: this rank holds the elements with global index i = (local << shard_log) | shard_rank; the partner
+// i + M/2 has the same residue, so the fold is local and only the twiddle exponent needs the global index.
+__global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, uint64_t Mh, uint32_t logN, uint32_t layer, const fe* roots, FriArgs a,
+                                                       uint32_t shard_log, uint32_t shard_rank) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Mh) return;
     fe x = sk_ld(cur + i), y = sk_ld(cur + Mh + i);
     uint32_t Nm = (1u << logN) - 1;
-    uint32_t e = (0u - ((uint32_t)i << layer)) & Nm;  // w_M^-i = w_N^(-i 2^layer)
+    const uint32_t ig = ((uint32_t)i << shard_log) | shard_rank;
+    uint32_t e = (0u - (ig << layer)) & Nm;  // w_M^-i = w_N^(-i 2^layer)
     fe w = root_pow(roots, e, logN);
     sk_st(next + i, a.half * (x + y) + a.c * (w * (x - y)));
 }
-int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c) {
-    uint64_t Mh = M >> 1;
+int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
+             uint32_t shard_log, uint32_t shard_rank) {
+    uint64_t Mh = M >> 1;   // M = elements this rank holds
     FriArgs a; a.half = half; a.c = c;
-    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a, shard_log, shard_rank);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -471,15 +476,18 @@ int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32
     return SP_OK;
 }
 
-// dst column v [coset-major] = src column v [natural order]; `len` elements per column (exceptional paths only)
-__global__ void __launch_bounds__(256) natural_to_coset_major_kernel(const fe* src, fe* dst, uint64_t len, LdeOrder ord) {
+// dst column v [coset-major, the `len` evaluations this rank holds] = src column v [natural order, whole domain]: local
+// natural index l is the global index (l << shard_log) | shard_rank  (exceptional paths only)
+__global__ void __launch_bounds__(256) natural_to_coset_major_kernel(const fe* src, uint64_t src_stride, fe* dst, uint64_t len, LdeOrder ord,
+                                                                     uint32_t shard_log, uint32_t shard_rank) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= len) return;
-    const uint64_t base = (uint64_t)blockIdx.y * len;
-    sk_st(dst + base + ord.at(i), sk_ld(src + base + i));
+    sk_st(dst + (uint64_t)blockIdx.y * len + ord.at(i), sk_ld(src + (uint64_t)blockIdx.y * src_stride + ((i << shard_log) | shard_rank)));
 }
-int natural_to_coset_major(hipStream_t st, const fe* src, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order) {
-    hipLaunchKernelGGL(natural_to_coset_major_kernel, dim3((unsigned)((len + 255) / 256), ncols), dim3(256), 0, st, src, dst, len, order);
+int natural_to_coset_major(hipStream_t st, const fe* src, uint64_t src_stride, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order,
+                           uint32_t shard_log, uint32_t shard_rank) {
+    hipLaunchKernelGGL(natural_to_coset_major_kernel, dim3((unsigned)((len + 255) / 256), ncols), dim3(256), 0, st, src, src_stride, dst, len, order,
+                       shard_log, shard_rank);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }

@@ -10,6 +10,7 @@
 #include "stark.hpp"
 #include "example_airs.hpp"
 #include <memory>
+#include <omp.h>
 #include <cstdlib>
 #include <cstdio>
 
@@ -72,6 +73,31 @@ int oracle_ntt(uint8_t* data, uint64_t n, int inverse, const uint8_t* coset) {
             store_felts(c, data);
         }
         return 0;
+    } catch (...) { return -2; }
+}
+
+// bench.py cpu_baseline: `vectors` forward NTTs of the same n elements, one vector per OpenMP thread (the reference runs
+// its column transforms under rayon the same way, prover.rs:171-172).  The 32-byte big-endian codec is timed apart:
+// out[0] = seconds to decode + encode one vector (1 thread), out[1] = wall seconds of all transforms, out[2] = threads.
+int oracle_ntt_bench(const uint8_t* data, uint64_t n, uint32_t vectors, uint32_t threads, double out[3]) {
+    try {
+        double t0 = omp_get_wtime();
+        std::vector<Fp> a = load_felts(data, n);
+        std::vector<uint8_t> back(n * 32);
+        store_felts(a, back.data());
+        out[0] = omp_get_wtime() - t0;
+        Poly p(a.begin(), a.end());
+        if (threads == 0) threads = 1;
+        std::vector<Fp> keep(vectors);
+        double t1 = omp_get_wtime();
+#pragma omp parallel for num_threads(threads) schedule(dynamic, 1)
+        for (int64_t v = 0; v < (int64_t)vectors; ++v) {
+            std::vector<Fp> ev = evaluate_offset_fft(p, 1, n, Fp::one());
+            keep[v] = ev[(size_t)v % n];
+        }
+        out[1] = omp_get_wtime() - t1;
+        out[2] = (double)threads;
+        return keep.empty() ? -1 : 0;   // (keep: the transforms cannot be optimised away)
     } catch (...) { return -2; }
 }
 

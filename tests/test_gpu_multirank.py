@@ -1,6 +1,10 @@
-"""Coset-sharded prover: world_size 2 and 4 ranks (sharing the one GPU of the test box, exchanging through the gloo-staged
-all-gather hook) produce the SAME proof bytes as the single-rank prover and the CPU oracle (SURVEY.md §8(e) gate)."""
+"""Sharded prover: world_size 2, 4 and 8 ranks produce the SAME proof bytes as the single-rank prover and
+the CPU oracle - for valid and for constraint-violating traces, with the digest exchange as an all-to-all or through its
+all-gather fallback, with sharded and with replicated FRI layers, with column-sharded and with replicated interpolation, and
+with more ranks than cosets.  On the one-GPU test box the ranks share device 0 and exchange through the host-staged gloo hooks
+(`test_rccl_on_distinct_devices` runs the library's own RCCL communicator when the box has two GPUs or more)."""
 import os
+import random
 import socket
 
 import pytest
@@ -17,7 +21,30 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, fib_index, options, q):
+def _inputs(case):
+    """(main trace, public inputs for the product, options) of a named case, rebuilt identically in every process."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    from lambdaworks_cairo_prover_amd import api
+    kind = case["kind"]
+    if kind == "fib":
+        run = api.CairoRun.fibonacci(case["fib"])
+        return run.main_trace(), run.public_inputs_c, run
+    import oracle_lib as oracle
+    from test_gpu_random_traces import random_trace
+    rng = random.Random(case["seed"])
+    cols = 43 if case.get("rc") else 34
+    n = case["n"]
+    trace = random_trace(rng, n, cols)
+    pm = [(a, rng.randrange(api.P)) for a in range(1, 6)]
+    segments = [(0, 1000, 1010)] if case.get("rc") else []
+    pub, keep = oracle.make_public_inputs(rng.randrange(1, 100), rng.randrange(1, 100), rng.randrange(1, 100), rng.randrange(1, 100),
+                                          rng.randrange(1, 100), 5, 65000, pm, n - 7, segments)
+    return trace, pub, keep
+
+
+def _worker(rank, world, port, case, options, knobs, q):
     import sys
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
@@ -27,36 +54,121 @@ def _worker(rank, world, port, fib_index, options, q):
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        run = api.CairoRun.fibonacci(fib_index)
+        trace, pub, keep = _inputs(case)
         ctx = api.Context(device=0)
-        ctx.set_collective(world, rank, api.StagedAllGather())
-        proof = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
-        proof2 = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))  # buffer reuse path
-        q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE"))
+        ctx.set_collective(world, rank, api.StagedAllGather(), alltoall=knobs.get("alltoall", True))
+        if "fri_min_log" in knobs:
+            ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
+        if "shard_interp" in knobs:
+            ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, knobs["shard_interp"])
+        proof = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+        proof2 = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))  # buffer reuse path
+        stats = ctx.comm_stats()
+        q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE", stats))
         ctx.close()
     except Exception:
         import traceback
-        q.put((rank, ("fail: " + traceback.format_exc()).encode()))
+        q.put((rank, ("fail: " + traceback.format_exc()).encode(), None))
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,fib_index,options", [(2, 100, (4, 3, 3, 1)), (4, 100, (4, 5, 3, 2)), (4, 200, (8, 4, 3, 1)), (2, 60, (2, 3, 3, 1)),
-                                                     (8, 100, (8, 4, 3, 1)), (8, 60, (16, 3, 3, 1))])
-def test_sharded_proof_bytes_identical(world, fib_index, options, oracle, hip_ctx):
-    from lambdaworks_cairo_prover_amd import api
-    run = api.CairoRun.fibonacci(fib_index)
-    want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
-    single = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
-    assert single == want
+def _run_world(world, case, options, knobs):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, fib_index, options, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, case, options, knobs, q)) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=600) for _ in procs)
+    got = [q.get(timeout=600) for _ in procs]
     for p in procs:
         p.join(timeout=60)
+    return {r: (proof, stats) for r, proof, stats in got}
+
+
+FIB = lambda i: {"kind": "fib", "fib": i}          # noqa: E731
+RND = lambda n, seed, rc=False: {"kind": "random", "n": n, "seed": seed, "rc": rc}   # noqa: E731
+
+CASES = [
+    # (world, case, options, knobs)
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5}),
+    (4, FIB(100), (4, 5, 3, 2), {"fri_min_log": 6}),
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "alltoall": False}),          # digest exchange through the all-gather fallback
+    (2, FIB(60), (2, 3, 3, 1), {"fri_min_log": 4, "shard_interp": 0}),           # replicated interpolation
+    (8, FIB(100), (8, 4, 3, 1), {"fri_min_log": 8}),                             # one coset per rank
+    (8, FIB(60), (16, 3, 3, 1), {"fri_min_log": 8}),                             # two cosets per rank (configs[4]'s shape in small)
+    (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7}),                             # more ranks than cosets: ranks 4..7 replicate roles 0..3
+    (4, FIB(140), (4, 6, 3, 1), {}),                                             # default knobs: the whole FRI replicated at this size
+    (2, RND(128, 11), (4, 3, 3, 1), {"fri_min_log": 5}),                         # constraint-violating traces (deg H >= 2n)
+    (4, RND(256, 12), (8, 4, 3, 2), {"fri_min_log": 6}),
+    (4, RND(128, 13, rc=True), (4, 3, 3, 1), {"fri_min_log": 5, "alltoall": False}),
+    (8, RND(256, 14), (8, 3, 3, 1), {}),
+]
+
+
+@pytest.mark.parametrize("world,case,options,knobs", CASES)
+def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_ctx):
+    from lambdaworks_cairo_prover_amd import api
+    trace, pub, keep = _inputs(case)
+    want = oracle.cairo_prove(trace, pub, options)
+    single = hip_ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+    assert single == want
+    results = _run_world(world, case, options, knobs)
     for r in range(world):
-        assert results[r] == want, (r, results[r][:300])
+        proof, stats = results[r]
+        assert proof == want, (r, proof[:300])
+        assert stats["world"] == world and stats["allgather_calls"] > 0
+        if knobs.get("alltoall", True) and world <= options[0]:
+            assert stats["alltoall_calls"] >= 3          # main, aux and composition commitments at least
+
+
+def _rccl_worker(rank, world, port, fib_index, options, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    from lambdaworks_cairo_prover_amd import api
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{rank}"))
+    try:
+        run = api.CairoRun.fibonacci(fib_index)
+        ctx = api.Context(device=rank)
+        ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, 8)
+        ctx.init_rccl()                       # ncclAllGather / grouped ncclSend+ncclRecv on the context stream
+        proof = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+        q.put((rank, proof, ctx.comm_stats()))
+        ctx.close()
+    except Exception:
+        import traceback
+        q.put((rank, ("fail: " + traceback.format_exc()).encode(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_on_distinct_devices(oracle, hip_ctx, hip_lib):
+    """The library's own RCCL transport with one rank per GPU (skipped on a one-GPU box)."""
+    import ctypes
+    from lambdaworks_cairo_prover_amd import api
+    n = ctypes.c_int(0)
+    hip_lib.sp_device_count(ctypes.byref(n))
+    if n.value < 2:
+        pytest.skip("needs at least two GPUs")
+    world = 2 if n.value < 4 else 4
+    fib_index, options = 2000, (4, 8, 3, 4)
+    run = api.CairoRun.fibonacci(fib_index)
+    want = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+    assert want == oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, fib_index, options, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for r, proof, stats in got:
+        assert proof == want, (r, proof[:300])
+        assert stats["world"] == world and stats["alltoall_calls"] >= 3

@@ -56,6 +56,25 @@ def _worker(rank, world, port, q):
         while len(level) > 1:
             level = [O.keccak256(level[i] + level[i + 1]) for i in range(0, len(level), 2)]
         assert level[0] == O.merkle_build(full.reshape(-1, 1, 32))
+        # Merkle combine through the all-to-all hook: block d of the local digest array (local natural
+        # order, leaf l = global leaf l*G + rank) is this rank's share of the contiguous leaf range of rank d
+        N = n * b
+        per = N // world // world
+        send = np.ascontiguousarray(local_leaves)
+        recv = np.empty_like(send)
+        assert hook.a2a_cfn(None, send.ctypes.data, recv.ctypes.data, per * 32) == 0
+        mine = api.interleave_shards(recv.reshape(world, per, 32), per, shard_log, shard_log)   # out[j*G + s] = recv[s][j]
+        assert np.array_equal(mine, leaves[rank * (N // world):(rank + 1) * (N // world)])
+        sub = [bytes(x) for x in mine]
+        while len(sub) > 1:
+            sub = [O.keccak256(sub[i] + sub[i + 1]) for i in range(0, len(sub), 2)]
+        roots = np.empty((world, 32), dtype=np.uint8)
+        mine_root = np.frombuffer(sub[0], dtype=np.uint8).copy()
+        assert hook.cfn(None, mine_root.ctypes.data, roots.ctypes.data, 32) == 0
+        top = [bytes(x) for x in roots]
+        while len(top) > 1:
+            top = [O.keccak256(top[i] + top[i + 1]) for i in range(0, len(top), 2)]
+        assert top[0] == level[0]
         # frame rows i and i+b stay inside one coset: local index + b_loc
         for i in range(n * b_loc):
             nxt = (i + b_loc) % (n * b_loc)
