@@ -368,7 +368,8 @@ def launch_ranks(args):
     rc = procs[0].returncode
     for p in procs[1:]:
         rc = p.wait() or rc
-    sys.stdout.write(out.decode())
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]   # (gloo prints its connection banner on stdout)
+    sys.stdout.write((lines[-1] if lines else out.decode()) + "\n")
     sys.stdout.flush()
     return rc
 

@@ -46,7 +46,6 @@ struct NttPassArgs {
     // 1 on every pass but the last one of a transform: the stored data is only brought below 2p; 0: canonical values.
     uint32_t weak_out;
     uint32_t radix4;      // two stages per LDS round trip (filled in by the launcher)
-    uint32_t fuse_ld;     // strided DIT pass, even r: first stage pair straight from global memory (filled in by the launcher)
     uint32_t batch;       // vectors per launch (filled in by the launcher)
     uint32_t xcd_map;     // 1: XCD-aware block -> (tile, vector) mapping (needs tiles % 8 == 0)
 };

@@ -1,7 +1,6 @@
 // Stark252 NTT passes for gfx950. See ntt.h for the structure and DESIGN.md section 4.1 for the twiddle bookkeeping.
 #include "ntt.h"
 #include <algorithm>
-#include <cstdlib>
 
 namespace sp {
 
@@ -53,6 +52,12 @@ __device__ __forceinline__ uint32_t bitrev(uint32_t x, uint32_t bits) { return b
 template <bool DIF, int LOADM, int STOREM, bool CONTIG, bool GTW>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
+#ifndef SP_NTT_PRIO
+#define SP_NTT_PRIO 0
+#endif
+    // A fresh work-group competes with up to three computing ones for issue slots and, as the youngest, loses: raise its
+    // priority until its tile and twiddle loads are on their way (SP_NTT_PRIO & 1) and again for the final stores (& 2)
+    if (SP_NTT_PRIO & 1) __builtin_amdgcn_s_setprio(3);
     const uint32_t r = a.r, g = a.g;
     const uint32_t s = a.s;                // local (address) stride; the twiddles use the global stride s + a.tw_shift
     const uint32_t R = 1u << r, G = 1u << g, TILE = R << g;
@@ -162,24 +167,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
 
     // ------------------------------------------------------------------ load
     constexpr int LU = 4;   // loads in flight per thread
-    // strided DIT pass with an even number of stages, in pairs: the four rows of a thread's FIRST radix-4 unit (stages 1, 2:
-    // rows 4 bq .. 4 bq + 3) go from global memory straight to its registers - no LDS write and re-read of the tile
-    // (compiled out by default: its registers cost the fourth work-group per CU that the 40 KB tile allows, and four
-    //  work-groups without it beat three with it - tools/sweep_fuse_ld.sh)
-#ifndef SP_NTT_FUSE_LD_BUILD
-#define SP_NTT_FUSE_LD_BUILD 0
-#endif
-    const bool fuse_ld = SP_NTT_FUSE_LD_BUILD && !DIF && !CONTIG && a.radix4 == 1 && !(r & 1u) && a.fuse_ld != 0;
-    fe x_first[LU];
-    if (fuse_ld) {
-        const uint32_t gl = tid & (G - 1), bq = tid >> g;
-#pragma unroll
-        for (int q = 0; q < LU; ++q) {
-            const uint32_t pos = position(4u * bq + (uint32_t)q, gl);
-            x_first[q] = (LOADM == NTT_LOAD_EXPAND) ? ld_fe(src + (pos >> s)) : ld_fe(src + pos);
-        }
-    }
-    for (uint32_t e0 = fuse_ld ? TILE : tid; e0 < TILE; e0 += NTT_THREADS * LU) {
+    for (uint32_t e0 = tid; e0 < TILE; e0 += NTT_THREADS * LU) {
         fe xs[LU];
         uint32_t li[LU];
 #pragma unroll
@@ -206,6 +194,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
         for (int q = 0; q < LU; ++q)
             if (e0 + q * NTT_THREADS < TILE) lds_st(Llo, Lhi, li[q], xs[q]);
     }
+    if (SP_NTT_PRIO & 1) __builtin_amdgcn_s_setprio(0);
     __syncthreads();
 
     // ------------------------------------------------------------------ radix-2 stages
@@ -318,14 +307,13 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                     if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;   // stage 1: w = 1, inputs < 2p
                     wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
                 }
-                fe x0, x1, x2, x3;
-                if (fuse_ld && j == 1) { x0 = x_first[0]; x1 = x_first[1]; x2 = x_first[2]; x3 = x_first[3]; }
-                else { x0 = lds_ld(Llo, Lhi, l0); x1 = lds_ld(Llo, Lhi, l1); x2 = lds_ld(Llo, Lhi, l2); x3 = lds_ld(Llo, Lhi, l3); }
+                fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
                 if (has_wa) { x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa); }
                 fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
                 a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
                 const fe y0 = fe_add_raw(a0, a2), y2 = fe_sub_add_2p(a0, a2), y1 = fe_add_raw(a1, a3), y3 = fe_sub_add_2p(a1, a3);
                 if (j + 1 == r && a.radix4 == 1) {
+                    if (SP_NTT_PRIO & 2) __builtin_amdgcn_s_setprio(3);
                     // last pair of the pass: straight to global memory (no LDS write, barrier and re-read)
                     const uint32_t q = half;   // = R/4
                     st_fe(dst + position(t0, gl), a.weak_out ? fe_reduce_lazy_2p(y0) : fe_canonical_lazy(y0));
@@ -342,6 +330,7 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     }
 
     // ------------------------------------------------------------------ store
+    if (SP_NTT_PRIO & 2) __builtin_amdgcn_s_setprio(3);
     fe scal;
     const bool has_scalar = a.scalar != nullptr;
     if (has_scalar) scal = ld_fe(a.scalar);
@@ -467,12 +456,9 @@ static int launch_t(hipStream_t st, const NttPassArgs& a, uint32_t batch) {
     NttPassArgs b = a;
     b.batch = batch;
     b.xcd_map = (tiles % 8 == 0) ? 1u : 0u;
-    { static const int r4 = std::getenv("SP_NTT_RADIX4") ? std::atoi(std::getenv("SP_NTT_RADIX4")) : 1;
-      // only tiles that give every thread a unit (a half-empty work-group loses more than the saved round trips)
-      b.radix4 = (r4 && !(DIF && r4 == 3) && a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS && !(r4 == 2 && CONTIG)) ? 1u : 0u;
-      if (b.radix4 && r4 == 4) b.radix4 = 2;     // 4: pairs without the fused store (A/B switch)
-      static const int fl = std::getenv("SP_NTT_FUSE_LD") ? std::atoi(std::getenv("SP_NTT_FUSE_LD")) : 1;
-      b.fuse_ld = (uint32_t)fl; }
+    // two stages per LDS round trip on the tiles that give every thread a unit (a half-empty work-group loses more than the
+    // saved round trips)
+    b.radix4 = (a.r >= 2 && (1u << tile_log) == 4u * NTT_THREADS) ? 1u : 0u;
     if (!CONTIG && b.radix4) lds = ((size_t)5 << (tile_log - 1)) * sizeof(uint4);
     if ((uint64_t)tiles * batch >= (1ull << 31)) { sp_set_error("ntt: batch too large for one launch"); return SP_E_INVALID_ARG; }
     hipLaunchKernelGGL((ntt_pass_kernel<DIF, LM, SM, CONTIG, GTW>), dim3(tiles * batch), dim3(NTT_THREADS), lds, st, b);
@@ -504,9 +490,7 @@ struct PassGeom { int s, r, g; };
 // stages in pairs) for everything beyond 64 MB, 512-element tiles (more work-groups in flight) for small transforms.
 // Measured with the pair kernels: single 2^22 transform 0.383 -> 0.371 ms with 1024, single 2^20 0.114 -> 0.117 ms.
 static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_contig_max, uint64_t footprint) {
-    static const int tile_big = std::getenv("SP_NTT_TILE_BIG") ? std::atoi(std::getenv("SP_NTT_TILE_BIG")) : 10;
-    static const int tile_small = std::getenv("SP_NTT_TILE_SMALL") ? std::atoi(std::getenv("SP_NTT_TILE_SMALL")) : 9;
-    const int min_tile_log = footprint > (64ull << 20) ? tile_big : tile_small;
+    const int min_tile_log = footprint > (64ull << 20) ? 10 : 9;
     std::vector<PassGeom> out;
     int s = first_stride_log;
     int rem = k - first_stride_log;
@@ -553,7 +537,7 @@ int NttEngine::dif_natural_to_bitrev_inverse(fe* data, int k, uint32_t batch, ui
     SP_TRY(roots(k, &big));
     // beyond one tile the contiguous pass is kept short (2^7 rows x 8 contiguous runs): a 2^10-row pass stages a 16 KB
     // twiddle table per 32 KB tile and fits only three work-groups per CU (measured 55 % of the strided passes' rate)
-    static const int contig_cap = std::getenv("SP_INTT_CONTIG") ? std::atoi(std::getenv("SP_INTT_CONTIG")) : 7;
+    constexpr int contig_cap = 7;
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : contig_cap, ((uint64_t)batch << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0});
     for (size_t i = geo.size(); i-- > 0;) {
@@ -674,7 +658,7 @@ int NttEngine::lde_coset_major(const fe* coeffs, fe* dst, int k, int logb, uint3
     const uint64_t n = 1ull << k;
     const fe* big = nullptr;
     SP_TRY(roots(K, &big));
-    static const int contig_cap = std::getenv("SP_LDE_CONTIG") ? std::atoi(std::getenv("SP_LDE_CONTIG")) : NTT_TILE_LOG - NTT_STRIDED_G_LOG;
+    constexpr int contig_cap = NTT_TILE_LOG - NTT_STRIDED_G_LOG;
     std::vector<PassGeom> geo = geometry(k, 0, k <= NTT_TILE_LOG ? NTT_TILE_LOG : contig_cap, ((uint64_t)batch * b_loc << k) * sizeof(fe));
     if (geo.empty()) geo.push_back({0, 0, 0});
     bool first = true;
