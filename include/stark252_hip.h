@@ -225,6 +225,10 @@ int sp_cairo_prove_dev(sp_ctx* ctx, const void* main_trace_dev, uint64_t n, uint
                        const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
 void sp_free(void* p);
 /* Device time (ms, HIP events on the context stream) of rounds 0..4 of the last sp_cairo_prove. */
+/* What the last proof on this context did: out[0] = composition path (1: 2n-point evaluation after a clean trace check,
+ * 2: whole LDE domain, deg H < 2n, 3: whole domain, deg H >= 2n - a constraint-violating trace), out[1] = FRI layers kept
+ * sharded, out[2] = groups the LDE is sharded over, out[3] = 1 when the trace interpolation was split by column. */
+int sp_last_proof_info(sp_ctx* ctx, uint32_t out[4]);
 int sp_last_round_ms(sp_ctx* ctx, float out[5]);
 
 /* ---- AIRs other than Cairo ------------------------------------------------------------------ */
@@ -270,6 +274,13 @@ typedef struct sp_cairo_run sp_cairo_run;  /* register trace + memory + public i
 int sp_cairo_run_program(const uint8_t* program_words, uint64_t n_words, uint64_t max_steps, sp_cairo_run** out);
 /* Same with main's entry point at address `entry_pc` (1-based; the compiled program's "main" identifier pc + 1). */
 int sp_cairo_run_program_at(const uint8_t* program_words, uint64_t n_words, uint64_t entry_pc, uint64_t max_steps, sp_cairo_run** out);
+/* Same for a hint-free program that declares builtins (reference tests/integration_tests.rs:151-172 `rc_program`,
+ * `signed_div_rem`; run.rs:211-222): builtins_mask bit 0 = output, bit 1 = range_check.  The builtin base pointers are main's
+ * implicit arguments, main returns the advanced pointers; the used range of each builtin segment becomes a memory segment of
+ * the public inputs (the range-check segment switches the AIR to its 43 + 18 column layout, cairo/air.rs:623-629; the output
+ * cells join the public memory, air.rs:200-206).  Range-checked values must lie in [0, 2^128). */
+int sp_cairo_run_program_builtins(const uint8_t* program_words, uint64_t n_words, uint64_t entry_pc, uint64_t max_steps,
+                                  uint32_t builtins_mask, sp_cairo_run** out);
 /* The 22-word fibonacci program of benches/proofs/fibonacci_70000.proof with index `fib_index`. */
 int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out);
 /* From cairo-run's binary dumps: .trace (24 B/row LE, register_states.rs:51-78) and .memory (8+32 B/row LE,

@@ -152,6 +152,12 @@ class Context:
         self._lib.sp_free(out)
         return proof
 
+    def last_proof_info(self):
+        """{'composition_path': 1 (2n points) | 2 (whole domain) | 3 (whole domain, deg H >= 2n), 'fri_sharded_layers', 'groups', ...}"""
+        out = (ctypes.c_uint32 * 4)()
+        check(self._lib.sp_last_proof_info(self._h, out))
+        return {"composition_path": out[0], "fri_sharded_layers": out[1], "groups": out[2], "interpolation_sharded": out[3]}
+
     def last_round_ms(self):
         ms = (ctypes.c_float * 5)()
         check(self._lib.sp_last_round_ms(self._h, ms))
@@ -223,6 +229,17 @@ class CairoRun:
         a = felts_to_bytes(words)
         check(lib.sp_cairo_run_program_at(_u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.c_uint64(entry_pc),
                                           ctypes.c_uint64(max_steps), ctypes.byref(h)))
+        return CairoRun(h)
+
+    @staticmethod
+    def from_program_builtins(words, output=False, range_check=True, max_steps=1 << 26, entry_pc=1):
+        """A hint-free program that declares the output and / or range_check builtins (sp_cairo_run_program_builtins)."""
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        a = felts_to_bytes(words)
+        mask = (1 if output else 0) | (2 if range_check else 0)
+        check(lib.sp_cairo_run_program_builtins(_u8p(a), ctypes.c_uint64(a.shape[0]), ctypes.c_uint64(entry_pc),
+                                                ctypes.c_uint64(max_steps), ctypes.c_uint32(mask), ctypes.byref(h)))
         return CairoRun(h)
 
     @staticmethod

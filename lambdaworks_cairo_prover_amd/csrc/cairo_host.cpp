@@ -215,18 +215,31 @@ std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const C
     return t;
 }
 
-void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps, uint64_t entry_pc) {
+// cairo-run's non-proof-mode layout (reference src/cairo/runner/run.rs:64-240 drives cairo-vm 0.6.0 that way): program at
+// 1..L, execution segment behind it, then one segment per builtin the program declares (layout order: output, range_check),
+// then the two empty segments whose address is the return fp / end pc of main.  main's initial stack is
+// [builtin bases ..., return fp, end pc]; it returns the advanced builtin pointers on top of the stack, which give the
+// used length of every builtin segment (cairo-vm's read_return_values -> stop_ptr; run.rs:211-222 for range_check).
+// The bases depend on the length of the execution segment, known only after the run: a first run with far-away
+// placeholder bases measures the segments, the second one uses the real addresses (no hint-free program can branch on them).
+void run_program_builtins(const std::vector<fe>& program, uint32_t builtins_mask, std::vector<RegisterState>& regs, CairoMemory& mem,
+                          uint64_t max_steps, uint64_t entry_pc, std::vector<MemorySegment>& segments_out) {
     const uint64_t L = program.size();
-    // Two passes: the two initial stack cells hold the address one past the execution segment (= final ap),
-    // which is only known after the run; their VALUE is only consumed by main's final `ret`.
-    uint64_t end_marker = ~0ULL;
+    std::vector<uint8_t> kinds;   // segment types in stack order (air.rs:156-160: 0 RangeCheck, 1 Output)
+    if (builtins_mask & 1u) kinds.push_back(1);
+    if (builtins_mask & 2u) kinds.push_back(0);
+    const size_t nb = kinds.size();
+    std::vector<uint64_t> base(nb), used(nb, 0);
+    for (size_t b = 0; b < nb; ++b) base[b] = (1ULL << 40) * (b + 1);
+    uint64_t end_marker = ~0ULL >> 8;
     for (int pass = 0; pass < 2; ++pass) {
         mem.data.clear();
         regs.clear();
         for (uint64_t i = 0; i < L; ++i) mem.data[i + 1] = program[i];
-        mem.data[L + 1] = fe_from_u64(end_marker);  // return fp
-        mem.data[L + 2] = fe_from_u64(end_marker);  // return pc
-        uint64_t pc = entry_pc, ap = L + 3, fp = L + 3;
+        for (size_t b = 0; b < nb; ++b) mem.data[L + 1 + b] = fe_from_u64(base[b]);
+        mem.data[L + 1 + nb] = fe_from_u64(end_marker);  // return fp
+        mem.data[L + 2 + nb] = fe_from_u64(end_marker);  // return pc
+        uint64_t pc = entry_pc, ap = L + 3 + nb, fp = L + 3 + nb;
         const uint64_t fp0 = fp;
         bool done = false;
         while (!done) {
@@ -288,8 +301,37 @@ void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState
             }
             pc = next_pc; ap = next_ap; fp = next_fp;
         }
-        end_marker = regs.back().ap;
+        // main leaves the advanced builtin pointers on top of its stack (read_return_values)
+        const uint64_t final_ap = regs.back().ap;
+        for (size_t b = 0; b < nb; ++b) {
+            const fe* stop = mem.get(final_ap - nb + b);
+            if (!stop) throw std::runtime_error("builtin stop pointer missing from the final stack");
+            const uint64_t sp = fe_low_u64(*stop);
+            if (sp < base[b] || sp - base[b] > (1ULL << 32)) throw std::runtime_error("invalid builtin stop pointer");
+            used[b] = sp - base[b];
+        }
+        uint64_t next = final_ap;   // the execution segment ends where ap ends
+        for (size_t b = 0; b < nb; ++b) { base[b] = next; next += used[b]; }
+        end_marker = next;
     }
+    segments_out.clear();
+    for (size_t b = 0; b < nb; ++b) {
+        // every cell of a builtin segment must have been written; range-checked values lie in [0, 2^128)
+        for (uint64_t a = base[b]; a < base[b] + used[b]; ++a) {
+            const fe* v = mem.get(a);
+            if (!v) throw std::runtime_error("hole in a builtin segment");
+            if (kinds[b] == 0) {
+                fe raw = fe_from_mont(*v);
+                for (int k = 4; k < 8; ++k) if (raw.v[k]) throw std::runtime_error("range-check builtin: value out of [0, 2^128)");
+            }
+        }
+        segments_out.push_back(MemorySegment{kinds[b], base[b], base[b] + used[b]});
+    }
+}
+
+void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps, uint64_t entry_pc) {
+    std::vector<MemorySegment> none;
+    run_program_builtins(program, 0, regs, mem, max_steps, entry_pc, none);
 }
 
 std::vector<fe> fibonacci_program(uint64_t fib_index) {

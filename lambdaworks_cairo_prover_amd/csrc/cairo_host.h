@@ -3,7 +3,7 @@
 //   * binary .trace / .memory readers   reference src/cairo/register_states.rs:51-78, src/cairo/cairo_mem.rs:35-61
 //   * instruction decode                reference src/cairo/decode/instruction_flags.rs:1-77, instruction_offsets.rs:18-56
 //   * build_main_trace                  reference src/cairo/execution_trace.rs:57-87, :261-356 (+ helpers)
-//   * a small Cairo VM for hint-free, builtin-free programs (stands in for cairo-vm 0.6.0 that
+//   * a small Cairo VM for hint-free programs, with the output and range_check builtins (stands in for cairo-vm 0.6.0 that
 //     reference src/cairo/runner/run.rs:64-240 drives; non-proof-mode layout)
 #pragma once
 #include "fp.h"
@@ -52,6 +52,11 @@ std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const C
 // Runs `program` (field elements, address 1..L) from pc = 1 in cairo-run's non-proof-mode layout until main returns.
 // Fills the relocated register trace and memory. Supports every hint-free, builtin-free instruction.
 void run_program_plain(const std::vector<fe>& program, std::vector<RegisterState>& regs, CairoMemory& mem, uint64_t max_steps, uint64_t entry_pc = 1);
+// The same for a program that declares builtins (builtins_mask: bit 0 output, bit 1 range_check): their base pointers are
+// main's implicit arguments, main returns the advanced pointers; segments_out receives the used range of each builtin
+// segment (what run.rs:211-222 reads back from cairo-vm).  Hint-free programs only; range-checked values must be < 2^128.
+void run_program_builtins(const std::vector<fe>& program, uint32_t builtins_mask, std::vector<RegisterState>& regs, CairoMemory& mem,
+                          uint64_t max_steps, uint64_t entry_pc, std::vector<MemorySegment>& segments_out);
 
 // The 22-word fibonacci program of tests/golden/fibonacci_70000.proof with the index replaced by `fib_index`
 // (fib(1, 1, fib_index), no final assert): 7*fib_index + 9 steps.

@@ -77,8 +77,8 @@ int sp_fe_from_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
     return SP_OK;
 }
 
-static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out) {
-    r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, {});
+static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out, const std::vector<sp::MemorySegment>& segments = {}) {
+    r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, segments);
     r->main_trace = sp::build_main_trace(r->regs, r->mem, r->pub, &r->n_rows, &r->n_cols);
     *out = r;
     return SP_OK;
@@ -92,6 +92,19 @@ int sp_cairo_run_program_at(const uint8_t* words, uint64_t n_words, uint64_t ent
         for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
         sp::run_program_plain(prog, r->regs, r->mem, max_steps, entry_pc);
         return finish_run(r, n_words, out);
+    } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+int sp_cairo_run_program_builtins(const uint8_t* words, uint64_t n_words, uint64_t entry_pc, uint64_t max_steps, uint32_t builtins_mask,
+                                  sp_cairo_run** out) {
+    if (!words || !out || n_words == 0 || entry_pc == 0 || entry_pc > n_words || (builtins_mask & ~3u)) return SP_E_INVALID_ARG;
+    sp_cairo_run* r = new sp_cairo_run();
+    try {
+        std::vector<fe> prog(n_words);
+        for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
+        std::vector<sp::MemorySegment> segs;
+        sp::run_program_builtins(prog, builtins_mask, r->regs, r->mem, max_steps, entry_pc, segs);
+        return finish_run(r, n_words, out, segs);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
 }
 

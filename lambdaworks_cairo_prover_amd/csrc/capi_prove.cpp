@@ -174,6 +174,12 @@ static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, ui
 
 void sp_free(void* p) { std::free(p); }
 
+int sp_last_proof_info(sp_ctx* c, uint32_t out[4]) {
+    if (!c || !out) return SP_E_INVALID_ARG;
+    std::memcpy(out, c->proof_info, sizeof(uint32_t) * 4);
+    return SP_OK;
+}
+
 int sp_last_round_ms(sp_ctx* c, float out[5]) {
     if (!c || !out) return SP_E_INVALID_ARG;
     std::memcpy(out, c->round_ms, sizeof(float) * 5);

@@ -53,10 +53,11 @@ template <bool DIF, int LOADM, int STOREM, bool CONTIG, bool GTW>
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint4 smem[];
 #ifndef SP_NTT_PRIO
-#define SP_NTT_PRIO 0
+#define SP_NTT_PRIO 1
 #endif
     // A fresh work-group competes with up to three computing ones for issue slots and, as the youngest, loses: raise its
-    // priority until its tile and twiddle loads are on their way (SP_NTT_PRIO & 1) and again for the final stores (& 2)
+    // priority until its tile and twiddle loads are on their way (SP_NTT_PRIO & 1: 34 x 2^22 10.95 -> 10.7 ms); doing the same
+    // for the final stores (& 2) changes nothing (tools/sweep_ntt_variants.sh, profiles/r02_ntt_prio_sweep.txt)
     if (SP_NTT_PRIO & 1) __builtin_amdgcn_s_setprio(3);
     const uint32_t r = a.r, g = a.g;
     const uint32_t s = a.s;                // local (address) stride; the twiddles use the global stride s + a.tw_shift

@@ -594,6 +594,8 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, N_, d_h12_, Nl_, 2, lde_order(), logG_, rank_));
         }
     }
+    c_->proof_info[0] = sub_coset ? 1u : (h_full_ ? 3u : 2u);
+    c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && d_cstage_) ? 1u : 0u;
     SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
     stage_ = 4;
     return SP_OK;

@@ -1,0 +1,82 @@
+"""A few Cairo instructions assembled by hand (Cairo whitepaper section 4.5; decoder: reference src/cairo/decode/
+instruction_flags.rs:1-77, instruction_offsets.rs:18-56) and small hint-free programs that use the range_check and output
+builtins - the shapes of the reference's `rc_program`, `lt_comparison` and `signed_div_rem` tests
+(tests/integration_tests.rs:151-172), whose compiled forms need cairo-vm hints and are not available here."""
+P = 2**251 + 17 * 2**192 + 1
+
+DST_FP, OP0_FP, OP1_IMM, OP1_FP, OP1_AP, RES_ADD, RES_MUL, PC_ABS, PC_REL, PC_JNZ, AP_ADD, AP_ADD1, CALL, RET, ASSERT = (1 << i for i in range(15))
+
+
+def word(flags, off_dst=0, off_op0=-1, off_op1=-1):
+    enc = lambda o: (o + 0x8000) & 0xFFFF   # noqa: E731
+    return enc(off_dst) | (enc(off_op0) << 16) | (enc(off_op1) << 32) | (flags << 48)
+
+
+def push_imm(v):                      # [ap] = v; ap++
+    return [word(OP0_FP | OP1_IMM | AP_ADD1 | ASSERT, 0, -1, 1), v % P]
+
+
+def push_fp(k):                       # [ap] = [fp + k]; ap++
+    return [word(OP0_FP | OP1_FP | AP_ADD1 | ASSERT, 0, -1, k)]
+
+
+def push_fp_plus(k, imm):             # [ap] = [fp + k] + imm; ap++
+    return [word(OP0_FP | OP1_IMM | RES_ADD | AP_ADD1 | ASSERT, 0, k, 1), imm % P]
+
+
+def assert_fp_eq_deref_fp(kd, kp, off=0):   # [fp + kd] = [[fp + kp] + off]
+    return [word(DST_FP | OP0_FP | ASSERT, kd, kp, off)]
+
+
+def assert_ap_eq_deref_fp(kd, kp, off=0):   # [ap + kd] = [[fp + kp] + off]
+    return [word(OP0_FP | ASSERT, kd, kp, off)]
+
+
+def call_rel(delta):
+    return [word(OP1_IMM | PC_REL | CALL, 0, 1, 1), delta % P]
+
+
+def jnz_fp(k, delta):                 # jmp rel delta if [fp + k] != 0
+    return [word(DST_FP | OP0_FP | OP1_IMM | PC_JNZ, k, -1, 1), delta % P]
+
+
+def ret():
+    return [word(DST_FP | OP0_FP | OP1_FP | PC_ABS | RET, -2, -1, -1)]
+
+
+def rc_program():
+    """%builtins range_check; main{range_check_ptr}: assert_nn(5); assert_nn(2)  (cairo_programs/cairo0/rc_program.cairo).
+    Returns (words, entry_pc)."""
+    assert_nn = assert_fp_eq_deref_fp(-3, -4) + push_fp_plus(-4, 1) + ret()          # a = [range_check_ptr]; return range_check_ptr + 1
+    main_at = 1 + len(assert_nn)
+    main = push_fp(-3) + push_imm(5)
+    main += call_rel(1 - (main_at + len(main)))
+    main += push_imm(2)
+    main += call_rel(1 - (main_at + len(main)))
+    main += ret()
+    return assert_nn + main, main_at
+
+
+def rc_loop_program(count, start=3, step=5):
+    """%builtins range_check; range-checks start, start + step, ... (count values) in a recursive loop.  Returns (words, entry_pc)."""
+    # loop(range_check_ptr [fp-5], x [fp-4], n [fp-3]) -> range_check_ptr
+    head = jnz_fp(-3, 4) + push_fp(-5) + ret()                                       # n == 0: return range_check_ptr
+    body = assert_fp_eq_deref_fp(-4, -5) + push_fp_plus(-5, 1) + push_fp_plus(-4, step) + push_fp_plus(-3, -1)
+    body += call_rel(1 - (1 + len(head) + len(body)))
+    body += ret()
+    loop = head + body
+    main_at = 1 + len(loop)
+    main = push_fp(-3) + push_imm(start) + push_imm(count)
+    main += call_rel(1 - (main_at + len(main)))
+    main += ret()
+    return loop + main, main_at
+
+
+def output_rc_program():
+    """%builtins output range_check; writes two output cells, range-checks one of the values, returns both pointers."""
+    main = push_imm(7) + assert_ap_eq_deref_fp(-1, -4, 0)        # assert [output_ptr] = 7
+    main += push_imm(2**100 + 9) + assert_ap_eq_deref_fp(-1, -4, 1)   # assert [output_ptr + 1] = 2^100 + 9
+    main += assert_ap_eq_deref_fp(-1, -3, 0)                     # assert [range_check_ptr] = 2^100 + 9
+    main += assert_ap_eq_deref_fp(-3, -3, 1)                     # assert [range_check_ptr + 1] = 7
+    main += push_fp_plus(-4, 2) + push_fp_plus(-3, 2) + ret()
+    return main, 1
