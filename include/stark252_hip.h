@@ -243,17 +243,22 @@ int sp_last_round_ms(sp_ctx* ctx, float out[5]);
  * dummy_air}.rs) are given in this form by lambdaworks_cairo_prover_amd/air.py. */
 typedef struct { uint8_t op; uint8_t pad; uint16_t a; uint16_t b; uint16_t pad2; } sp_air_op;
 typedef struct { uint32_t col; uint32_t pad; uint64_t step; uint8_t value[32]; /* canonical BE */ } sp_air_boundary;
+/* build_auxiliary_trace(main_trace, rap_challenges) of the caller's AIR (traits.rs:25-29), for aux_kind 2: called once, after
+ * the main commitment, with the n_rap challenges (32 bytes each, context encoding); must write the row-major n x aux_cols
+ * auxiliary trace (context encoding) to aux_rows_out and return 0. */
+typedef int (*sp_aux_trace_fn)(void* user, const uint8_t* rap, uint32_t n_rap, uint8_t* aux_rows_out);
 typedef struct {
-    uint32_t main_cols, aux_cols;            /* AirContext::trace_columns = main_cols + aux_cols */
-    uint32_t n_offsets; uint32_t offsets[4]; /* transition_offsets */
-    uint32_t n_transitions; uint32_t degrees[16]; uint32_t exemptions[16]; /* transition_degrees / transition_exemptions */
+    uint32_t main_cols, aux_cols;            /* AirContext::trace_columns = main_cols + aux_cols (<= 64) */
+    uint32_t n_offsets; uint32_t offsets[8]; /* transition_offsets */
+    uint32_t n_transitions; uint32_t degrees[64]; uint32_t exemptions[64]; /* transition_degrees / transition_exemptions */
     uint32_t num_transition_exemptions;      /* AirContext::num_transition_exemptions */
     uint32_t degree_bound_factor;            /* composition_poly_degree_bound() / trace_length (1 or 2) */
-    uint32_t n_ops; const sp_air_op* ops;
+    uint32_t n_ops; const sp_air_op* ops;    /* <= 2048 ops, <= 64 values alive at any point of the program */
     uint32_t n_consts; const uint8_t* consts; /* canonical BE */
     uint32_t n_rap;                          /* build_rap_challenges: this many transcript_to_field samples */
-    uint32_t aux_kind;                       /* build_auxiliary_trace: 0 none, 1 fibonacci_rap permutation column */
-    uint32_t n_boundary; const sp_air_boundary* boundary;
+    uint32_t aux_kind;                       /* build_auxiliary_trace: 0 none, 1 fibonacci_rap permutation column, 2 aux_fn */
+    uint32_t n_boundary; const sp_air_boundary* boundary;   /* <= 16, at most 3 distinct steps */
+    sp_aux_trace_fn aux_fn; void* aux_user;  /* aux_kind 2 */
 } sp_air_desc;
 
 /* prove::<Stark252PrimeField, A> (reference src/starks/prover.rs:532-766) + Serializable::serialize for the AIR `air`.

@@ -14,7 +14,8 @@ import ctypes
 P = 2**251 + 17 * 2**192 + 1
 
 OP_LOAD, OP_CONST, OP_ADD, OP_SUB, OP_MUL, OP_OUT = range(6)
-MAX_OFFSETS, MAX_TRANSITIONS = 4, 16
+MAX_OFFSETS, MAX_TRANSITIONS = 8, 64
+AUX_TRACE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_uint8), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint8))
 
 
 class AirOpC(ctypes.Structure):
@@ -34,10 +35,11 @@ class AirDescC(ctypes.Structure):
                 ("n_ops", ctypes.c_uint32), ("ops", ctypes.POINTER(AirOpC)),
                 ("n_consts", ctypes.c_uint32), ("consts", ctypes.c_void_p),
                 ("n_rap", ctypes.c_uint32), ("aux_kind", ctypes.c_uint32),
-                ("n_boundary", ctypes.c_uint32), ("boundary", ctypes.POINTER(AirBoundaryC))]
+                ("n_boundary", ctypes.c_uint32), ("boundary", ctypes.POINTER(AirBoundaryC)),
+                ("aux_fn", AUX_TRACE_FN), ("aux_user", ctypes.c_void_p)]
 
 
-AUX_NONE, AUX_FIBONACCI_RAP = 0, 1
+AUX_NONE, AUX_FIBONACCI_RAP, AUX_CALLBACK = 0, 1, 2
 _RAP_TAG = 0x8000
 
 
@@ -60,8 +62,11 @@ class Value:
 
 
 class AirBuilder:
-    def __init__(self, main_cols, offsets, degree_bound_factor, aux_cols=0, n_rap=0, aux_kind=AUX_NONE, num_transition_exemptions=1):
+    def __init__(self, main_cols, offsets, degree_bound_factor, aux_cols=0, n_rap=0, aux_kind=AUX_NONE, num_transition_exemptions=1,
+                 aux_builder=None):
+        """aux_builder(rap: list[int]) -> (n, aux_cols) nested list of ints: the AIR's build_auxiliary_trace (aux_kind AUX_CALLBACK)."""
         assert 1 <= len(offsets) <= MAX_OFFSETS
+        self.aux_builder = aux_builder
         self.main_cols, self.aux_cols, self.offsets = main_cols, aux_cols, list(offsets)
         self.degree_bound_factor, self.n_rap, self.aux_kind = degree_bound_factor, n_rap, aux_kind
         self.num_transition_exemptions = num_transition_exemptions
@@ -121,7 +126,25 @@ class AirBuilder:
         d.n_consts, d.consts = len(self.consts), ctypes.cast(consts, ctypes.c_void_p)
         d.n_rap, d.aux_kind = self.n_rap, self.aux_kind
         d.n_boundary, d.boundary = len(self.bcs), ctypes.cast(bcs, ctypes.POINTER(AirBoundaryC))
-        return d, (ops, consts, bcs)
+        cb = None
+        if self.aux_kind == AUX_CALLBACK:
+            builder, aux_cols = self.aux_builder, self.aux_cols
+
+            def _aux(user, rap_ptr, n_rap, out_ptr):   # canonical big-endian contexts (the default encoding)
+                try:
+                    raw = ctypes.string_at(rap_ptr, 32 * n_rap)
+                    rows = builder([int.from_bytes(raw[32 * i:32 * i + 32], "big") for i in range(n_rap)])
+                    flat = b"".join((int(v) % P).to_bytes(32, "big") for row in rows for v in row)
+                    assert len(flat) == 32 * aux_cols * len(rows)
+                    ctypes.memmove(out_ptr, flat, len(flat))
+                    return 0
+                except Exception:  # never let an exception cross the C boundary
+                    import traceback
+                    traceback.print_exc()
+                    return -1
+            cb = AUX_TRACE_FN(_aux)
+            d.aux_fn = cb
+        return d, (ops, consts, bcs, cb)
 
 
 # ---- the reference's example AIRs in program form (src/starks/example/*.rs) ------------------------------------------

@@ -185,7 +185,7 @@ int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_pub
 int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d, const sp_proof_options* opt) {
     if (!proof || !d || !opt) return SP_E_INVALID_ARG;
     try {
-        if (d->n_offsets == 0 || d->n_offsets > 4 || d->n_transitions == 0 || d->n_transitions > 16 || (d->n_ops && !d->ops) ||
+        if (d->n_offsets == 0 || d->n_offsets > 8 || d->n_transitions == 0 || d->n_transitions > 64 || (d->n_ops && !d->ops) ||
             (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) return 0;
         std::vector<uint32_t> offsets(d->offsets, d->offsets + d->n_offsets), degrees(d->degrees, d->degrees + d->n_transitions),
             exemptions(d->exemptions, d->exemptions + d->n_transitions);

@@ -189,7 +189,7 @@ int sp_last_round_ms(sp_ctx* c, float out[5]) {
 int sp_air_prove(sp_ctx* c, const sp_air_desc* d, const uint8_t* main_trace, uint64_t n, const sp_proof_options* opt,
                  uint8_t** proof_out, uint64_t* proof_len) {
     if (!c || !d || !main_trace || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
-    if (d->n_offsets == 0 || d->n_offsets > 4 || d->n_transitions == 0 || d->n_transitions > 16 || (d->n_ops && !d->ops) ||
+    if (d->n_offsets == 0 || d->n_offsets > 8 || d->n_transitions == 0 || d->n_transitions > 64 || (d->n_ops && !d->ops) ||
         (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) { sp_set_error("sp_air_prove: malformed descriptor"); return SP_E_INVALID_ARG; }
     sp::AirDescHost a;
     a.main_cols = d->main_cols; a.aux_cols = d->aux_cols;
@@ -198,9 +198,9 @@ int sp_air_prove(sp_ctx* c, const sp_air_desc* d, const uint8_t* main_trace, uin
     a.exemptions.assign(d->exemptions, d->exemptions + d->n_transitions);
     a.num_transition_exemptions = d->num_transition_exemptions;
     a.degree_bound_factor = d->degree_bound_factor;
-    for (uint32_t i = 0; i < d->n_ops; ++i) { sp::AirOpDev o{}; o.op = d->ops[i].op; o.a = d->ops[i].a; o.b = d->ops[i].b; a.ops.push_back(o); }
+    for (uint32_t i = 0; i < d->n_ops; ++i) a.ops.push_back(sp::AirOpHost{d->ops[i].op, d->ops[i].a, d->ops[i].b});
     for (uint32_t i = 0; i < d->n_consts; ++i) a.consts.push_back(fe_from_bytes_be(d->consts + 32 * (size_t)i));
-    a.n_rap = d->n_rap; a.aux_kind = d->aux_kind;
+    a.n_rap = d->n_rap; a.aux_kind = d->aux_kind; a.aux_fn = d->aux_fn; a.aux_user = d->aux_user;
     for (uint32_t i = 0; i < d->n_boundary; ++i)
         a.boundary.push_back(sp::BoundaryConstraint{d->boundary[i].col, d->boundary[i].step, fe_from_bytes_be(d->boundary[i].value)});
     sp::ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
+#include <memory>
 
 namespace sp {
 
@@ -22,11 +24,19 @@ static bool timing_enabled() { static int v = -1; if (v < 0) v = std::getenv("SP
     do { if (timing_enabled()) { (void)hipStreamSynchronize(ctx->stream); double _t = wall_ms(); \
          std::fprintf(stderr, "[sp_timing] %-28s %9.2f ms\n", label, _t - _tp); _tp = _t; } } while (0)
 
-StarkProver::~StarkProver() { free_all(); }
+StarkProver::~StarkProver() {
+    free_all();
+    for (auto& e : ev_dma_) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
+    if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+}
 
 void StarkProver::free_all() {
     (void)hipSetDevice(c_->device);
     (void)hipStreamSynchronize(c_->stream);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
+    stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
 }
@@ -233,6 +243,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         return SP_E_STATE;
     }
     SP_HIP_CHECK(hipSetDevice(c_->device));
+    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20)) return commit_trace_pipelined(segment, rows_host, cols, root_out);
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
@@ -244,6 +255,63 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, trace, n_));
     }
     return commit_segment_resident(segment, cols, root_out);
+}
+
+// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace, split over a few threads
+static void host_gather_columns(const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
+    const unsigned T = (unsigned)std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, n >> 12));
+    auto work = [&](uint64_t r0, uint64_t r1) {
+        const uint8_t* s = src + r0 * row_bytes + off;
+        uint8_t* d = dst + r0 * width;
+        for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width) std::memcpy(d, s, width);
+    };
+    std::vector<std::thread> th;
+    const uint64_t per = (n + T - 1) / T;
+    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, std::min<uint64_t>(n, t * per), std::min<uint64_t>(n, (t + 1) * per));
+    work(0, std::min<uint64_t>(n, per));
+    for (auto& x : th) x.join();
+}
+
+// interpolate_and_commit (reference prover.rs:126-159) from a HOST buffer, in column groups: while group g is interpolated and
+// extended on the compute stream, group g + 1 crosses PCIe on a second stream and group g + 2 is gathered out of the
+// row-major trace into pinned memory by a few host threads.  The 1.1 GB upload of a 2^20 x 34 trace (22 ms at PCIe speed)
+// hides behind the transforms of the main segment instead of preceding them.
+int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+    const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    const uint32_t K = (cols + 7) / 8, gc = (cols + K - 1) / K;
+    const size_t chunk = (size_t)n_ * gc * 32;
+    if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    if (!copy_stream_) {
+        SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
+    }
+    if (stage_bytes_ < chunk) {
+        for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
+        stage_bytes_ = 0;
+        for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
+        stage_bytes_ = chunk;
+    }
+    uint8_t* landing[2] = {reinterpret_cast<uint8_t*>(d_scratch_), reinterpret_cast<uint8_t*>(d_scratch_) + chunk};
+    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
+    fe* trace = d_trace_ + (uint64_t)col0 * n_;
+    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
+    for (uint32_t g = 0; g < K; ++g) {
+        const uint32_t c0 = g * gc, w = std::min(gc, cols - c0), slot = g & 1u;
+        if (g >= 2) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));                  // the pinned slot has crossed PCIe
+        host_gather_columns(rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
+        if (g >= 2) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been consumed
+        SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)n_ * w * 32, hipMemcpyHostToDevice, copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_dma_[slot], 0));
+        SP_TRY(rows_to_columns(c_->stream, c_->enc, landing[slot], n_, w, trace + (uint64_t)c0 * n_, n_));
+        SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], c_->stream));
+        // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
+        SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
+    }
+    SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
+    stage_ = segment == 0 ? 2 : 3;
+    return SP_OK;
 }
 
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.
@@ -391,7 +459,7 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
                                  const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta, uint8_t root_out[32]) {
     if (stage_ != 3 && !(stage_ == 2 && Ca_ == 0)) { sp_set_error("composition: trace segments not committed"); return SP_E_STATE; }
     const uint32_t T = (uint32_t)air.degrees.size(), B = (uint32_t)air.boundary.size(), R = (uint32_t)air.offsets.size();
-    if (T == 0 || T > AIR_MAX_TRANSITIONS || B > CAIRO_MAX_BOUNDARY || R == 0 || R > AIR_MAX_OFFSETS || air.exemptions.size() != T ||
+    if (T == 0 || T > AIR_MAX_TRANSITIONS || B > COMP_MAX_BOUNDARY || R == 0 || R > AIR_MAX_OFFSETS || air.exemptions.size() != T ||
         t_alpha.size() != T || t_beta.size() != T || b_alpha.size() != B || b_beta.size() != B || air.ops.size() > AIR_MAX_OPS ||
         air.consts.size() + rap.size() > AIR_MAX_CONSTS || rap.size() != air.n_rap || air.main_cols != Cm_ || air.aux_cols != Ca_ ||
         air.degree_bound_factor < 1) {
@@ -400,27 +468,52 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
     }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const uint32_t b = 1u << logb_, f = air.degree_bound_factor;
-    // --- validate the program (every operand refers to an earlier value, cells exist) and build the device copy
-    AirProgram prog;
+    // --- validate the program (every operand refers to an earlier value, cells exist) and build the device copy: every
+    //     value gets a slot of the per-point value file, released after its last use (the program is straight-line)
+    std::unique_ptr<AirProgram> prog_holder(new AirProgram());
+    AirProgram& prog = *prog_holder;
     std::memset(&prog, 0, sizeof(prog));
     prog.n_ops = (uint32_t)air.ops.size();
     prog.n_offsets = R;
     for (uint32_t k = 0; k < R; ++k) prog.offsets[k] = air.offsets[k];
     std::vector<bool> produced(T, false);
+    std::vector<uint32_t> last_use(prog.n_ops, 0);
     for (uint32_t t = 0; t < prog.n_ops; ++t) {
-        const AirOpDev& o = air.ops[t];
+        const AirOpHost& o = air.ops[t];
         bool ok = true;
         switch (o.op) {
             case 0: ok = o.a < R && o.b < C_; break;
             case 1: ok = o.a < air.consts.size() + rap.size(); break;
-            case 2: case 3: case 4: ok = o.a < t && o.b < t && air.ops[o.a].op != 5 && air.ops[o.b].op != 5; break;
-            case 5: ok = o.a < T && o.b < t && air.ops[o.b].op != 5; if (ok) produced[o.a] = true; break;
+            case 2: case 3: case 4: ok = o.a < t && o.b < t && air.ops[o.a].op != 5 && air.ops[o.b].op != 5; if (ok) { last_use[o.a] = t; last_use[o.b] = t; } break;
+            case 5: ok = o.a < T && o.b < t && air.ops[o.b].op != 5; if (ok) { produced[o.a] = true; last_use[o.b] = t; } break;
             default: ok = false;
         }
         if (!ok) { sp_set_error("composition_air: malformed constraint program"); return SP_E_INVALID_ARG; }
-        prog.ops[t] = o;
     }
-    for (uint32_t k = 0; k < T; ++k) if (!produced[k]) { sp_set_error("composition_air: a constraint has no OUT op"); return SP_E_INVALID_ARG; }
+    {
+        std::vector<uint16_t> slot_of(prog.n_ops, 0), free_slots;
+        for (int sl = AIR_MAX_LIVE - 1; sl >= 0; --sl) free_slots.push_back((uint16_t)sl);
+        std::vector<std::vector<uint32_t>> dying(prog.n_ops);    // values whose last use is op t
+        for (uint32_t t = 0; t < prog.n_ops; ++t) if (air.ops[t].op != 5 && last_use[t] > t) dying[last_use[t]].push_back(t);
+        for (uint32_t t = 0; t < prog.n_ops; ++t) {
+            const AirOpHost& o = air.ops[t];
+            AirOpDev d{};
+            d.op = o.op;
+            if (o.op >= 2 && o.op <= 4) { d.a = slot_of[o.a]; d.b = slot_of[o.b]; }
+            else if (o.op == 5) { d.a = o.a; d.b = slot_of[o.b]; }
+            else { d.a = o.a; d.b = o.b; }
+            for (uint32_t v : dying[t]) free_slots.push_back(slot_of[v]);   // operands read before the result is written
+            if (o.op != 5) {
+                if (last_use[t] <= t) { d.dst = AIR_MAX_LIVE - 1; if (free_slots.empty()) { /* unused value: any slot */ } else d.dst = free_slots.back(); }
+                else {
+                    if (free_slots.empty()) { sp_set_error("composition_air: more than 64 values alive at once in the constraint program"); return SP_E_UNSUPPORTED; }
+                    d.dst = free_slots.back(); free_slots.pop_back();
+                }
+                slot_of[t] = d.dst;
+            }
+            prog.ops[t] = d;
+        }
+    }
     for (size_t i = 0; i < air.consts.size(); ++i) prog.consts[i] = air.consts[i];
     for (size_t i = 0; i < rap.size(); ++i) prog.consts[air.consts.size() + i] = rap[i];
     // --- transition exemptions (traits.rs:49-79, evaluator.rs:299-323): distinct non-zero counts; with
@@ -746,10 +839,14 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         fe* inv = d_scratch_;                                  // [npts][n]
         fe* inv_scratch = d_scratch_ + (uint64_t)npts * n_;    // [npts n]
         fe* p0n = d_scratch_ + 2ull * npts * n_;               // [n]
-        if ((2ull * npts + 1) * n_ > scratch_elems()) { sp_set_error("deep: scratch too small for this frame"); return SP_E_ALLOC; }
+        if ((2ull * npts + 1) * n_ > scratch_elems()) {   // many frame rows on a small blowup: the inverses outgrow the shared scratch
+            void* big = nullptr;
+            SP_TRY(alloc(&big, sizeof(fe) * (2ull * npts + 1) * n_));   // stays until the next reshaping setup()
+            inv = static_cast<fe*>(big); inv_scratch = inv + (uint64_t)npts * n_; p0n = inv + 2ull * npts * n_;
+        }
         SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
-        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order()));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order(), R));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, d_post_deep_));   // n^-1 w_N^(-c0 j): setup()
         // FRI layer 0: the evaluations this rank holds (local natural order) when the layer is sharded, the whole domain otherwise
@@ -767,7 +864,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * Nl_, c_->d_flag));
         fe* p0_local = (G_ == 1 || fri_sharded(0)) ? d_fri_evals_[0] : d_local_;   // local natural order
-        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, p0_local, lde_order()));
+        SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, p0_local, lde_order(), R));
         if (G_ > 1 && !fri_sharded(0)) {
             SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
             SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe)));
@@ -1214,9 +1311,18 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         tr.append(root, 32);
         std::vector<fe> rap(air.n_rap);
         for (auto& x : rap) x = tr.to_field();
-        if (air.aux_cols) {
+        if (air.aux_cols && air.aux_kind == 2) {
+            // build_auxiliary_trace of the caller's AIR (traits.rs:25-29): row-major n x aux_cols from the RAP challenges
+            if (!air.aux_fn) { sp_set_error("air_prove: aux_kind 2 needs aux_fn"); return SP_E_INVALID_ARG; }
+            std::vector<uint8_t> rap_bytes(std::max<size_t>(1, rap.size()) * 32), aux_rows((size_t)n * air.aux_cols * 32);
+            if (!rap.empty()) SP_TRY(sp_fe_from_device(ctx->enc, reinterpret_cast<const uint8_t*>(rap.data()), rap.size(), rap_bytes.data()));
+            if (air.aux_fn(air.aux_user, rap_bytes.data(), (uint32_t)rap.size(), aux_rows.data()) != 0) { sp_set_error("air_prove: the auxiliary-trace callback failed"); return SP_E_INVALID_ARG; }
+            SP_TRY(P->commit_trace(1, aux_rows.data(), air.aux_cols, root, false));
+            roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
+            tr.append(root, 32);
+        } else if (air.aux_cols) {
             if (air.aux_kind != 1 || air.aux_cols != 1 || air.main_cols < 2 || air.n_rap < 1) {
-                sp_set_error("air_prove: unknown auxiliary-trace kind (1 = fibonacci_rap permutation column)");
+                sp_set_error("air_prove: unknown auxiliary-trace kind (1 = fibonacci_rap permutation column, 2 = caller-supplied)");
                 return SP_E_UNSUPPORTED;
             }
             // fibonacci_rap.rs:69-93: z_0 = 1, z_i = z_(i-1) (a_(i-1) + gamma) / (b_(i-1) + gamma)

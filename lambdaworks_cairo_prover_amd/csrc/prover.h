@@ -13,13 +13,15 @@ namespace sp {
 struct ProofOptionsHost { uint8_t blowup_factor; uint64_t fri_number_of_queries; uint64_t coset_offset; uint8_t grinding_factor; };
 
 // Host form of sp_air_desc (include/stark252_hip.h).
+struct AirOpHost { uint8_t op; uint16_t a, b; };   // as the caller wrote it: operands are indices of earlier ops
 struct AirDescHost {
     uint32_t main_cols = 0, aux_cols = 0;
     std::vector<uint32_t> offsets, degrees, exemptions;
     uint32_t num_transition_exemptions = 1, degree_bound_factor = 1;
-    std::vector<AirOpDev> ops;
+    std::vector<AirOpHost> ops;
     std::vector<fe> consts;
     uint32_t n_rap = 0, aux_kind = 0;
+    sp_aux_trace_fn aux_fn = nullptr; void* aux_user = nullptr;   // aux_kind 2: build_auxiliary_trace supplied by the caller
     std::vector<BoundaryConstraint> boundary;
 };
 
@@ -86,6 +88,10 @@ class StarkProver : public sp_deletable {
         return commit_local(cols_dev, stride, ncols, Nl_, lde_order(), tree, root_out);
     }
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
+    int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
+    hipEvent_t ev_dma_[2] = {nullptr, nullptr}, ev_r2c_[2] = {nullptr, nullptr};
+    void* h_stage_[2] = {nullptr, nullptr}; size_t stage_bytes_ = 0;   // pinned staging, one column group each
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
     // order of the evaluations inside the trace / composition LDE columns this rank holds (coset-major, common.h)

@@ -10,6 +10,9 @@ namespace sp {
 constexpr int CAIRO_MAX_TRANSITIONS = 50;
 constexpr int CAIRO_MAX_BOUNDARY = 8;
 constexpr int CAIRO_MAX_BLOWUP = 32;
+// program AIRs (sp_air_desc): up to 64 transition constraints and 16 boundary constraints share the constant block below
+constexpr int COMP_MAX_BOUNDARY = 16;
+constexpr int COMP_MAX_TERMS = 64 + COMP_MAX_BOUNDARY;
 
 // out[q] = c * base^(bitrev_bits(q)) for q < count (bitrev_bits = 0: natural exponent q)
 int gen_power_table(hipStream_t st, fe* out, uint64_t count, uint32_t bitrev_bits, const fe& base, const fe& c);
@@ -33,11 +36,11 @@ struct CompositionConsts {
     fe g_last;                  // g^(n-1): root of the single transition exemption X - g^(n-1) (traits.rs:49-79)
     fe b16, b32, b48, b15, two; // constants of the instruction-decoding constraints (air.rs:883-912)
     fe zerofier[CAIRO_MAX_BLOWUP];                                          // 1/(x^n - 1) per coset (evaluator.rs:156-171)
-    fe coef[CAIRO_MAX_BLOWUP][CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY];  // alpha_k * x^(D-D_k) + beta_k per coset
-    fe bvalue[CAIRO_MAX_BOUNDARY];                                          // boundary values
-    uint32_t bcol[CAIRO_MAX_BOUNDARY];                                      // boundary columns
-    uint32_t bden[CAIRO_MAX_BOUNDARY];                                      // index of the inverse-denominator array
-    uint64_t bstep[CAIRO_MAX_BOUNDARY];                                     // boundary rows (trace check only)
+    fe coef[CAIRO_MAX_BLOWUP][COMP_MAX_TERMS];                              // alpha_k * x^(D-D_k) + beta_k per coset (transitions, then boundary)
+    fe bvalue[COMP_MAX_BOUNDARY];                                           // boundary values
+    uint32_t bcol[COMP_MAX_BOUNDARY];                                       // boundary columns
+    uint32_t bden[COMP_MAX_BOUNDARY];                                       // index of the inverse-denominator array
+    uint64_t bstep[COMP_MAX_BOUNDARY];                                      // boundary rows (trace check only)
     uint32_t n_boundary, n_transitions, main_cols, has_rc_builtin;
 };
 
@@ -53,8 +56,11 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t co
 int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev);
 
 // ---- AIRs given as a constraint program (include/stark252_hip.h sp_air_desc; reference trait src/starks/traits.rs:15-119)
-constexpr int AIR_MAX_OPS = 192, AIR_MAX_CONSTS = 48, AIR_MAX_OFFSETS = 4, AIR_MAX_EXEMPT_KINDS = 4, AIR_MAX_TRANSITIONS = 16;
-struct AirOpDev { uint8_t op, pad; uint16_t a, b, pad2; };   // 0 LOAD(row, col) 1 CONST(idx) 2 ADD 3 SUB 4 MUL 5 OUT(constraint, value)
+constexpr int AIR_MAX_OPS = 2048, AIR_MAX_LIVE = 64, AIR_MAX_CONSTS = 96, AIR_MAX_OFFSETS = 8, AIR_MAX_EXEMPT_KINDS = 4, AIR_MAX_TRANSITIONS = 64;
+// Device form of one op: the host assigns every value a slot of a small per-point value file (liveness analysis in
+// composition_air), so a long straight-line program needs AIR_MAX_LIVE values per point, not one per op.
+//   0 LOAD(a = row, b = col) -> dst   1 CONST(a = idx) -> dst   2 ADD / 3 SUB / 4 MUL (a, b = slots) -> dst   5 OUT(a = constraint, b = slot)
+struct AirOpDev { uint8_t op, pad; uint16_t a, b, dst; };
 struct AirProgram {
     uint32_t n_ops, n_offsets, offsets[AIR_MAX_OFFSETS];
     uint32_t ex_kind[AIR_MAX_TRANSITIONS];    // per constraint: 0 = enforced on every row, else 1 + index into ex_count
@@ -99,7 +105,7 @@ struct DeepConsts {
 // inv: [rows + 1][count] = 1/(x - z g^ofs_k) for each frame row, then 1/(x - z^2).
 // `count` points, point q = element (q << shift) of every column (columns at col_stride).
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
-                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order);
+                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order, uint32_t frame_rows = 2);
 
 // fold_polynomial + FriLayer::new (reference src/starks/fri/fri_functions.rs:4-27, fri_commitment.rs:30-47) in evaluation
 // form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.

@@ -378,6 +378,7 @@ int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32
 // ---------------------------------------------------------------------------------------------- DEEP composition
 // Point q of the launch is element (q << shift) of every column (shift > 0: one coset of the LDE domain only);
 // inv holds the three inverse arrays with `count` entries each, out[q] the value.
+template <int MAXR>
 __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, const fe* __restrict__ h1, const fe* __restrict__ h2, uint64_t count,
                                                    uint64_t col_stride, uint32_t shift, const DeepConsts* __restrict__ K,
                                                    const fe* __restrict__ inv, fe* __restrict__ out, LdeOrder ord) {
@@ -385,25 +386,27 @@ __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, c
     if (q >= count) return;
     const uint64_t i = ord.at(q << shift);   // coset-major columns: the one coset of the n-point evaluation is contiguous
     const uint32_t C = K->cols, R = K->rows;
-    fe a[AIR_MAX_OFFSETS];
+    fe a[MAXR];
 #pragma unroll
-    for (int k = 0; k < AIR_MAX_OFFSETS; ++k) a[k] = fe_zero();
+    for (int k = 0; k < MAXR; ++k) a[k] = fe_zero();
     for (uint32_t j = 0; j < C; ++j) {
         fe t = sk_ld(lde + (uint64_t)j * col_stride + i);
 #pragma unroll
-        for (int k = 0; k < AIR_MAX_OFFSETS; ++k)
+        for (int k = 0; k < MAXR; ++k)
             if ((uint32_t)k < R) a[k] = a[k] + K->gammas[k][j] * t;
     }
     fe hh = K->gamma_h1 * sk_ld(h1 + i) + K->gamma_h2 * sk_ld(h2 + i) - K->c_h;
     fe r = hh * sk_ld(inv + (uint64_t)R * count + q);
 #pragma unroll
-    for (int k = 0; k < AIR_MAX_OFFSETS; ++k)
+    for (int k = 0; k < MAXR; ++k)
         if ((uint32_t)k < R) r = r + (a[k] - K->c_t[k]) * sk_ld(inv + (uint64_t)k * count + q);
     sk_st(out + q, r);
 }
 int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, uint64_t count, uint64_t col_stride, uint32_t shift,
-                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order) {
-    hipLaunchKernelGGL(deep_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out, order);
+                     const DeepConsts* consts_dev, const fe* inv, fe* out, LdeOrder order, uint32_t frame_rows) {
+    // (the accumulators of unused frame rows would still take registers: two instantiations)
+    if (frame_rows <= 2) hipLaunchKernelGGL(deep_kernel<2>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out, order);
+    else hipLaunchKernelGGL(deep_kernel<AIR_MAX_OFFSETS>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, h1, h2, count, col_stride, shift, consts_dev, inv, out, order);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -530,7 +533,7 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
     const uint32_t iglob = CHECK ? 0u : shard_global_index((uint32_t)e, sm);
     const uint32_t c = iglob & (b - 1);
     const uint32_t T = K->n_transitions, B = K->n_boundary;
-    fe v[AIR_MAX_OPS];
+    fe v[AIR_MAX_LIVE];
     fe cons[AIR_MAX_TRANSITIONS];
     for (uint32_t k = 0; k < T; ++k) cons[k] = fe_zero();
     const uint32_t n_ops = Pg->n_ops;
@@ -547,9 +550,9 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
             case 2: r = v[o.a] + v[o.b]; break;
             case 3: r = v[o.a] - v[o.b]; break;
             case 4: r = v[o.a] * v[o.b]; break;
-            default: cons[o.a] = v[o.b]; break;
+            default: cons[o.a] = v[o.b]; continue;
         }
-        v[t] = r;
+        v[o.dst] = r;
     }
     if (CHECK) {
         bool bad = false;

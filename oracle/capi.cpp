@@ -299,8 +299,8 @@ int oracle_example_verify(int kind, const uint8_t* params, uint64_t steps, const
 struct oracle_air_boundary { uint32_t col; uint32_t pad; uint64_t step; uint8_t value[32]; };
 struct oracle_air_desc {
     uint32_t main_cols, aux_cols;
-    uint32_t n_offsets; uint32_t offsets[4];
-    uint32_t n_transitions; uint32_t degrees[16]; uint32_t exemptions[16];
+    uint32_t n_offsets; uint32_t offsets[8];
+    uint32_t n_transitions; uint32_t degrees[64]; uint32_t exemptions[64];
     uint32_t num_transition_exemptions;
     uint32_t degree_bound_factor;
     uint32_t n_ops; const AirOp* ops;
@@ -308,6 +308,7 @@ struct oracle_air_desc {
     uint32_t n_rap;
     uint32_t aux_kind;
     uint32_t n_boundary; const oracle_air_boundary* boundary;
+    int (*aux_fn)(void* user, const uint8_t* rap, uint32_t n_rap, uint8_t* aux_rows_out); void* aux_user;   // aux_kind 2
 };
 static std::unique_ptr<ProgramAir> make_program_air(const oracle_air_desc* d, size_t n, const ProofOptions& o) {
     std::unique_ptr<ProgramAir> a(new ProgramAir());
@@ -321,6 +322,7 @@ static std::unique_ptr<ProgramAir> make_program_air(const oracle_air_desc* d, si
     a->ops.assign(d->ops, d->ops + d->n_ops);
     a->consts = load_felts(d->consts, d->n_consts);
     a->n_rap = d->n_rap; a->aux_cols = d->aux_cols; a->aux_kind = d->aux_kind; a->bound_factor = d->degree_bound_factor;
+    a->aux_fn = d->aux_fn; a->aux_user = d->aux_user;
     for (uint32_t i = 0; i < d->n_boundary; ++i) a->bcs.push_back({d->boundary[i].col, (size_t)d->boundary[i].step, Fp::from_bytes_be(d->boundary[i].value)});
     return a;
 }

@@ -158,9 +158,21 @@ struct ProgramAir : Air {
     std::vector<Fp> consts;
     size_t n_rap = 0, aux_cols = 0, aux_kind = 0, bound_factor = 1;
     std::vector<BoundaryConstraint> bcs;
+    int (*aux_fn)(void* user, const uint8_t* rap, uint32_t n_rap, uint8_t* aux_rows_out) = nullptr;   // aux_kind 2: the caller's build_auxiliary_trace
+    void* aux_user = nullptr;
     std::vector<Fp> build_auxiliary_trace(const std::vector<Fp>& main, size_t mc, const std::vector<Fp>& rap) const override {
         if (aux_kind == 0) return {};
         if (aux_kind == 1) return fibonacci_rap_aux_column(main, mc, rap[0]);
+        if (aux_kind == 2) {   // canonical big-endian in and out (the oracle's only encoding)
+            if (!aux_fn) throw std::runtime_error("aux_kind 2 without a callback");
+            const size_t n = main.size() / mc;
+            std::vector<uint8_t> rb(std::max<size_t>(1, rap.size()) * 32), rows(n * aux_cols * 32);
+            for (size_t i = 0; i < rap.size(); ++i) rap[i].to_bytes_be(&rb[32 * i]);
+            if (aux_fn(aux_user, rb.data(), (uint32_t)rap.size(), rows.data()) != 0) throw std::runtime_error("auxiliary-trace callback failed");
+            std::vector<Fp> out(n * aux_cols);
+            for (size_t i = 0; i < out.size(); ++i) out[i] = Fp::from_bytes_be(&rows[32 * i]);
+            return out;
+        }
         throw std::runtime_error("unknown aux kind");
     }
     std::vector<Fp> build_rap_challenges(Transcript& t) const override {
