@@ -229,6 +229,9 @@ void sp_free(void* p);
  * 2: whole LDE domain, deg H < 2n, 3: whole domain, deg H >= 2n - a constraint-violating trace), out[1] = FRI layers kept
  * sharded, out[2] = groups the LDE is sharded over, out[3] = 1 when the trace interpolation was split by column. */
 int sp_last_proof_info(sp_ctx* ctx, uint32_t out[4]);
+/* Device memory the prover of this context holds (trace, coefficients, LDE, trees, FRI layers, staging), in bytes: linear in
+ * the trace length for a given column count, blowup factor and world size. */
+int sp_prover_device_bytes(sp_ctx* ctx, uint64_t* bytes_out);
 int sp_last_round_ms(sp_ctx* ctx, float out[5]);
 
 /* ---- AIRs other than Cairo ------------------------------------------------------------------ */

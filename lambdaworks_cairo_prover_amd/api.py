@@ -158,6 +158,11 @@ class Context:
         check(self._lib.sp_last_proof_info(self._h, out))
         return {"composition_path": out[0], "fri_sharded_layers": out[1], "groups": out[2], "interpolation_sharded": out[3]}
 
+    def prover_device_bytes(self):
+        out = ctypes.c_uint64()
+        check(self._lib.sp_prover_device_bytes(self._h, ctypes.byref(out)))
+        return out.value
+
     def last_round_ms(self):
         ms = (ctypes.c_float * 5)()
         check(self._lib.sp_last_round_ms(self._h, ms))

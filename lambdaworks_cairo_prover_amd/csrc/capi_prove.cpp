@@ -180,6 +180,12 @@ int sp_last_proof_info(sp_ctx* c, uint32_t out[4]) {
     return SP_OK;
 }
 
+int sp_prover_device_bytes(sp_ctx* c, uint64_t* bytes_out) {
+    if (!c || !bytes_out) return SP_E_INVALID_ARG;
+    *bytes_out = c->prover_device_bytes;
+    return SP_OK;
+}
+
 int sp_last_round_ms(sp_ctx* c, float out[5]) {
     if (!c || !out) return SP_E_INVALID_ARG;
     std::memcpy(out, c->round_ms, sizeof(float) * 5);

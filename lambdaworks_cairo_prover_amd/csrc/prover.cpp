@@ -39,6 +39,7 @@ void StarkProver::free_all() {
     stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
+    alloc_bytes_ = 0;
 }
 
 int StarkProver::alloc(void** p, size_t bytes) {
@@ -48,6 +49,8 @@ int StarkProver::alloc(void** p, size_t bytes) {
         return SP_E_ALLOC;
     }
     allocs_.push_back(*p);
+    alloc_bytes_ += bytes;
+    c_->prover_device_bytes = alloc_bytes_;
     return SP_OK;
 }
 
@@ -278,7 +281,16 @@ static void host_gather_columns(const uint8_t* src, uint64_t n, size_t row_bytes
 // hides behind the transforms of the main segment instead of preceding them.
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    const uint32_t K = (cols + 7) / 8, gc = (cols + K - 1) / K;
+    // column groups: two small ones first (the transforms start after ~2 ms instead of waiting for a full group), then groups
+    // of up to eight columns, the rest split evenly
+    std::vector<uint32_t> gsize;
+    {
+        uint32_t left = cols;
+        for (uint32_t first : {std::max(1u, cols / 16), std::max(2u, cols / 8)}) if (left > first + 8) { gsize.push_back(first); left -= first; }
+        const uint32_t K = (left + 7) / 8;
+        for (uint32_t k = 0; k < K; ++k) { uint32_t w = (left + (K - k) - 1) / (K - k); gsize.push_back(w); left -= w; }
+    }
+    const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
     if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
     if (!copy_stream_) {
@@ -295,8 +307,9 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    for (uint32_t g = 0; g < K; ++g) {
-        const uint32_t c0 = g * gc, w = std::min(gc, cols - c0), slot = g & 1u;
+    uint32_t c0 = 0;
+    for (uint32_t g = 0; g < gsize.size(); c0 += gsize[g], ++g) {
+        const uint32_t w = gsize[g], slot = g & 1u;
         if (g >= 2) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));                  // the pinned slot has crossed PCIe
         host_gather_columns(rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
         if (g >= 2) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been consumed

@@ -125,6 +125,7 @@ class StarkProver : public sp_deletable {
     bool has_rc_ = false;
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
     std::vector<void*> allocs_;
+    uint64_t alloc_bytes_ = 0;              // device memory held by this prover (sp_prover_device_bytes)
     fe *d_coeffs_ = nullptr, *d_lde_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr;
     fe* d_trace_ = nullptr;  // [C][n] the trace itself, natural order (kept for the constraint check of round 2)
     fe *d_h12s_ = nullptr, *d_h12_ = nullptr, *d_scratch_ = nullptr;  // scratch: 4N elements

@@ -2,9 +2,21 @@
 """HBM traffic per NTT from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/<name>.json, the file bench.py reads for roofline.traffic.
 usage: pmc_traffic.py <fetch_results.db> <write_results.db> <log_n> <out.json>"""
+import hashlib
 import json
+import os
 import sqlite3
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ntt_source_sha16():
+    """Same digest as bench.py: the traffic figure is only valid for the kernel sources it was measured on."""
+    h = hashlib.sha256()
+    for f in ("ntt.hip", "ntt.h", "fp.h"):
+        h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def per_kernel(path, counter):
@@ -28,7 +40,11 @@ def main():
         "launches_per_ntt": launches,
         "fetch_size_kb_per_ntt": fetch_kb,
         "write_size_kb_per_ntt": write_kb,
-        "correction": "FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; WRITE_SIZE as reported",
+        "ntt_source_sha16": ntt_source_sha16(),
+        "correction": "FETCH_SIZE x 2, WRITE_SIZE x 1: calibrated on known byte counts in the access patterns of the passes "
+                      "(tools/fetch_calibration.hip, profiles/r02_fetch_calibration.txt: contiguous and 128/256-byte-row reads of 1 GiB "
+                      "report 0.5 GiB, writes report 1:1).  The figure includes the twiddle fetches (32-byte gathers, mostly served by "
+                      "L2 / the 256 MiB infinity cache, which FETCH_SIZE counts).",
         "traffic_bytes_per_ntt": (2 * fetch_kb + write_kb) * 1024,
         "per_kernel_fetch_kb_avg": {k: t / c for k, (c, t) in passes.items()},
     }

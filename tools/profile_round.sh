@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python3 $R/bench.py --proof 0 --no-cpu-baseline --steps 20 --warmup 3"
+B="python3 $R/bench.py --proof 0 --no-cpu-baseline --steps 20 --warmup 3"   # (bench.py warms itself for 300 ms before the timed steps)
 # kernel trace of the DEFAULT bench command (200 timed steps: settled clocks, the durations bench.py itself reports)
 rocprofv3 --kernel-trace --stats -d $O/ntt_kt -o ntt -- python3 $R/bench.py --proof 0 --no-cpu-baseline > $O/ntt_kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $O/ntt_pf -o f -- $B > $O/ntt_pf.log 2>&1
