@@ -84,7 +84,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     ready_ = false; stage_ = 0;
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
-    d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
+    d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_small_ = nullptr; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
     world_ = (uint32_t)c_->world; wrank_ = (uint32_t)c_->rank;
@@ -96,6 +96,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     h_ = fe_from_u64(opt.coset_offset);
     if (fe_is_zero(h_)) return SP_E_INVALID_ARG;
     hinv_ = fe_inv(h_);
+    half_ = fe_inv(fe_from_u64(2)); binv_ = fe_inv(fe_from_u64(1ull << lb));
     g_ = host_primitive_root((int)logn_);
     SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
     SP_TRY(alloc((void**)&d_trace_, sizeof(fe) * n_ * C_));
@@ -798,7 +799,25 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     std::vector<fe> ys;
     for (uint32_t k = 0; k < R; ++k) ys.push_back(fe_mul(fe_mul(z, fe_pow_u64(g_, offsets_[k])), hinv_));
     std::vector<fe> tr;
-    SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, scratch_elems(), tr));
+    if (G_ > 1 && C_ >= G_) {
+        // the polynomials are independent: role s evaluates the cpr columns from min(s cpr, C - cpr) on, the R values per column
+        // are all-gathered (a few KB) - 1/G of the Horner-equivalent work per rank instead of all of it on every rank
+        const uint32_t cpr = (C_ + G_ - 1) / G_;
+        auto first_col = [&](uint32_t role) { return std::min(role * cpr, C_ - cpr); };
+        std::vector<fe> mine;
+        SP_TRY(eval_bitrev(c_, d_coeffs_ + (uint64_t)first_col(rank_) * n_, n_, cpr, logn_, ys, d_scratch_, scratch_elems(), mine));
+        const size_t blk = (size_t)cpr * R;
+        if (!d_small_) SP_TRY(alloc((void**)&d_small_, sizeof(fe) * (1 + (size_t)world_) * 64 * AIR_MAX_OFFSETS));
+        SP_HIP_CHECK(hipMemcpyAsync(d_small_, mine.data(), blk * sizeof(fe), hipMemcpyHostToDevice, c_->stream));
+        SP_TRY(all_gather(d_small_, d_small_ + 64 * AIR_MAX_OFFSETS, blk * sizeof(fe)));
+        std::vector<fe> all(blk * world_);
+        SP_HIP_CHECK(hipMemcpy(all.data(), d_small_ + 64 * AIR_MAX_OFFSETS, all.size() * sizeof(fe), hipMemcpyDeviceToHost));
+        tr.resize((size_t)C_ * R);
+        for (uint32_t role = 0; role < G_; ++role)
+            std::copy(all.begin() + (size_t)role * blk, all.begin() + (size_t)(role + 1) * blk, tr.begin() + (size_t)first_col(role) * R);
+    } else {
+        SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, scratch_elems(), tr));
+    }
     trace_ood.resize((size_t)R * C_);
     for (uint32_t j = 0; j < C_; ++j)
         for (uint32_t k = 0; k < R; ++k) trace_ood[(size_t)k * C_ + j] = tr[(size_t)j * R + k];
@@ -886,7 +905,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     }
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;
-    fri_offset_ = h_;
+    fri_offset_ = h_; fri_offset_inv_ = hinv_;
     int flag = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
     SP_TRY(commit_local(d_fri_evals_[0], 0, 1, fri_trees_[0].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[0], root0_out));   // synchronises
@@ -903,8 +922,8 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
     SP_TRY(c_->ntt->roots((int)logN_, &roots));
     const uint32_t k = fri_layer_ - 1;  // layer being folded
     const uint64_t M = N_ >> k;
-    fe half = fe_inv(fe_from_u64(2));
-    fe cst = fe_mul(fe_mul(zeta, half), fe_inv(fri_offset_));
+    const fe half = half_;                                           // (field inversions cost ~15 us on the host: none per layer)
+    fe cst = fe_mul(fe_mul(zeta, half), fri_offset_inv_);
     // In evaluation form the fold is local to a rank: the partner i + M/2 of index i has the same residue mod G (§8(e) item 4)
     if (fri_sharded(k)) {
         const uint64_t Ml = M >> logG_;
@@ -918,7 +937,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
     } else {
         SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half, cst));
     }
-    fri_offset_ = fe_sqr(fri_offset_);
+    fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_);
     if (k + 1 < logn_) {
         SP_TRY(commit_local(d_fri_evals_[k + 1], 0, 1, fri_trees_[k + 1].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[k + 1], root_out));
         fri_layer_ += 1;
@@ -933,7 +952,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
         fe sum = fe_zero();
         for (auto& e : ev) sum = fe_add(sum, e);
-        *last_value = fe_mul(sum, fe_inv(fe_from_u64(bb)));
+        *last_value = fe_mul(sum, binv_);
         *is_last = 1;
         stage_ = 7;
     }

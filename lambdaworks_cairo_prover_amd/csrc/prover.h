@@ -115,6 +115,7 @@ class StarkProver : public sp_deletable {
     fe* d_gather_ = nullptr; uint64_t gather_cap_ = 0;   // all-gather landing zone, grown on demand
     fe* d_cstage_ = nullptr; uint32_t cpr_max_ = 0;       // [world][cpr_max][n] coefficient all-gather (column-sharded interpolation)
     digest32* d_roots_ = nullptr;                          // [world] subtree roots
+    fe* d_small_ = nullptr;                                // out-of-domain values of this rank's columns and their all-gather
     fe* d_fullN_ = nullptr;                                // [N] whole-domain scratch when FRI layer 0 is sharded (exceptional paths)
     int ensure_gather(uint64_t elems);
     int full_domain_buffer(fe** out);
@@ -137,7 +138,8 @@ class StarkProver : public sp_deletable {
     uint32_t fri_rep_ = 0;                  // first replicated layer (0: the whole FRI is replicated)
     bool fri_sharded(uint32_t k) const { return k < fri_rep_; }
     uint32_t fri_layer_ = 0;                // number of committed layers so far
-    fe fri_offset_;                         // h^(2^layer)
+    fe fri_offset_, fri_offset_inv_;        // h^(2^layer) and its inverse
+    fe half_, binv_;                        // 1/2, 1/blowup
     CompositionConsts* d_comp_consts_ = nullptr;
     AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;

@@ -3,8 +3,7 @@ ranks share the one GPU of the test box: n = 2^21 rows x 52 columns (configs[4] 
 sharded proof must equal the single-rank proof byte for byte and pass the library's verifier; the device memory each rank
 holds is measured and extrapolated to n = 2^24 (it is linear in n) against the 288 GB of an MI355X.
 
-Heavy (several minutes: every collective is staged through host memory and gloo here): runs only when SP_HEAVY_TESTS=1 or
-when at least 200 GB of device memory are free."""
+About 40 s (every collective is staged through host memory and gloo here); needs ~200 GB of free device memory."""
 import hashlib
 import os
 import socket
@@ -54,8 +53,8 @@ def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib):
     import torch
     from lambdaworks_cairo_prover_amd import api
     free, total = torch.cuda.mem_get_info(0)
-    if os.environ.get("SP_HEAVY_TESTS") != "1" and free < 200e9:
-        pytest.skip("needs ~200 GB of free device memory (or SP_HEAVY_TESTS=1)")
+    if free < 200e9:
+        pytest.skip("needs ~200 GB of free device memory")
     run = api.CairoRun.fibonacci(FIB_INDEX)
     assert run.n_rows == 1 << 21
     with api.Context(device=0) as ctx:                      # single rank: the reference bytes, then free its 80 GB
