@@ -282,14 +282,17 @@ static void host_gather_columns(const uint8_t* src, uint64_t n, size_t row_bytes
 // hides behind the transforms of the main segment instead of preceding them.
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    // column groups: two small ones first (the transforms start after ~2 ms instead of waiting for a full group), then groups
-    // of up to eight columns, the rest split evenly
+    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.66 ms per column of 2^20 rows) and everything
+    // behind it still has to be transformed (~0.8 ms per column): the finish time is max_g [upload(0..g) + transform(g..)], i.e.
+    // a group may grow only as fast as the columns before it have bought time - small groups first, growing by about a fifth
+    // of what is already on the device, eight columns at most.
     std::vector<uint32_t> gsize;
-    {
-        uint32_t left = cols;
-        for (uint32_t first : {std::max(1u, cols / 16), std::max(2u, cols / 8)}) if (left > first + 8) { gsize.push_back(first); left -= first; }
-        const uint32_t K = (left + 7) / 8;
-        for (uint32_t k = 0; k < K; ++k) { uint32_t w = (left + (K - k) - 1) / (K - k); gsize.push_back(w); left -= w; }
+    for (uint32_t done = 0; done < cols;) {
+        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(2, done / 5 + 2));
+        if (cols - done - w < 2) w = cols - done;     // no one-column tail
+        w = std::min(w, cols - done);
+        gsize.push_back(w);
+        done += w;
     }
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
