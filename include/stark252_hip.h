@@ -85,6 +85,9 @@ int sp_set_alltoall(sp_ctx* ctx, sp_alltoall_fn fn);
 /* Collective traffic of this context since creation: out = {world, all-gather calls, bytes contributed to all-gathers,
  * all-to-all calls, bytes sent in all-to-alls, bytes received in all collectives}. */
 int sp_comm_stats(sp_ctx* ctx, uint64_t out[6]);
+/* Checks the installed transport (RCCL or hooks): one all-gather and, if installed, one all-to-all of rank-stamped blocks of
+ * bytes_per_block bytes (a multiple of 8); every rank must call it.  0 = both deliver the layout documented above. */
+int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
 /* Tuning knobs of the sharded prover (defaults in parentheses):
  *   SP_OPT_FRI_SHARD_MIN_LOG (16)  FRI layers with at least 2^value leaves keep their evaluations and trees sharded; smaller
  *                                  layers are all-gathered once and continue replicated (fri/mod.rs:20-72 is sequential in the layers);

@@ -402,6 +402,10 @@ def _ctx_set_collective(self, world, rank, hook, alltoall=True):
         check(self._lib.sp_set_alltoall(self._h, hook.a2a_cfn))
 
 
+def _ctx_comm_selftest(self, bytes_per_block=1 << 20):
+    check(self._lib.sp_comm_selftest(self._h, ctypes.c_uint64(bytes_per_block)))
+
+
 def _ctx_comm_stats(self):
     out = (ctypes.c_uint64 * 6)()
     check(self._lib.sp_comm_stats(self._h, out))
@@ -432,6 +436,7 @@ def _ctx_init_rccl(self, group=None):
 Context.set_collective = _ctx_set_collective
 Context.init_rccl = _ctx_init_rccl
 Context.comm_stats = _ctx_comm_stats
+Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION"]

@@ -153,6 +153,46 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     return sp_set_alltoall(c, rccl_alltoall);
 }
 
+// Exercises the installed transport: every rank contributes rank-stamped blocks to an all-gather and (when an all-to-all hook
+// exists) to an all-to-all, and checks what comes back.  0 = both primitives deliver the documented layout.
+int sp_comm_selftest(sp_ctx* c, uint64_t bytes_per_block) {
+    if (!c || bytes_per_block == 0 || bytes_per_block % 8) return SP_E_INVALID_ARG;
+    if (c->world > 1 && !c->allgather) { sp_set_error("sp_comm_selftest: no collective installed"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    const uint64_t W = (uint64_t)c->world, words = bytes_per_block / 8;
+    DevBuf send, recv;
+    SP_TRY(send.alloc(W * bytes_per_block));
+    SP_TRY(recv.alloc(W * bytes_per_block));
+    std::vector<uint64_t> h(W * words), back(W * words);
+    auto stamp = [&](uint64_t from, uint64_t to, uint64_t k) { return (from << 48) ^ (to << 32) ^ (k * 0x9e3779b97f4a7c15ull); };
+    // all-gather: this rank's block, recv[s] = block of rank s
+    for (uint64_t k = 0; k < words; ++k) h[k] = stamp((uint64_t)c->rank, 0xffff, k);
+    SP_HIP_CHECK(hipMemcpy(send.p, h.data(), bytes_per_block, hipMemcpyHostToDevice));
+    SP_HIP_CHECK(hipMemset(recv.p, 0, W * bytes_per_block));
+    if (c->allgather) {
+        if (c->allgather(c->allgather_user, send.p, recv.p, bytes_per_block) != 0) { sp_set_error("sp_comm_selftest: all-gather hook failed"); return SP_E_HIP; }
+    } else {
+        SP_HIP_CHECK(hipMemcpy(recv.p, send.p, bytes_per_block, hipMemcpyDeviceToDevice));
+    }
+    SP_HIP_CHECK(hipMemcpy(back.data(), recv.p, W * bytes_per_block, hipMemcpyDeviceToHost));
+    for (uint64_t s2 = 0; s2 < W; ++s2)
+        for (uint64_t k = 0; k < words; ++k)
+            if (back[s2 * words + k] != stamp(s2, 0xffff, k)) { sp_set_error("sp_comm_selftest: all-gather delivered a wrong block"); return SP_E_HIP; }
+    // all-to-all: block d goes to rank d, recv[s] = the block rank s addressed to this rank
+    if (c->alltoall) {
+        for (uint64_t d = 0; d < W; ++d)
+            for (uint64_t k = 0; k < words; ++k) h[d * words + k] = stamp((uint64_t)c->rank, d, k);
+        SP_HIP_CHECK(hipMemcpy(send.p, h.data(), W * bytes_per_block, hipMemcpyHostToDevice));
+        SP_HIP_CHECK(hipMemset(recv.p, 0, W * bytes_per_block));
+        if (c->alltoall(c->allgather_user, send.p, recv.p, bytes_per_block) != 0) { sp_set_error("sp_comm_selftest: all-to-all hook failed"); return SP_E_HIP; }
+        SP_HIP_CHECK(hipMemcpy(back.data(), recv.p, W * bytes_per_block, hipMemcpyDeviceToHost));
+        for (uint64_t s2 = 0; s2 < W; ++s2)
+            for (uint64_t k = 0; k < words; ++k)
+                if (back[s2 * words + k] != stamp(s2, (uint64_t)c->rank, k)) { sp_set_error("sp_comm_selftest: all-to-all delivered a wrong block"); return SP_E_HIP; }
+    }
+    return SP_OK;
+}
+
 int sp_sync(sp_ctx* c) {
     if (!c) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c->device));
