@@ -57,6 +57,7 @@ def _worker(rank, world, port, case, options, knobs, q):
         trace, pub, keep = _inputs(case)
         ctx = api.Context(device=0)
         ctx.set_collective(world, rank, api.StagedAllGather(), alltoall=knobs.get("alltoall", True))
+        ctx.comm_selftest(4096)
         if "fri_min_log" in knobs:
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
@@ -137,6 +138,7 @@ def _rccl_worker(rank, world, port, fib_index, options, q):
         ctx = api.Context(device=rank)
         ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, 8)
         ctx.init_rccl()                       # ncclAllGather / grouped ncclSend+ncclRecv on the context stream
+        ctx.comm_selftest(1 << 20)
         proof = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
         q.put((rank, proof, ctx.comm_stats()))
         ctx.close()
@@ -172,3 +174,44 @@ def test_rccl_on_distinct_devices(oracle, hip_ctx, hip_lib):
     for r, proof, stats in got:
         assert proof == want, (r, proof[:300])
         assert stats["world"] == world and stats["alltoall_calls"] >= 3
+
+
+def _rccl_single_worker(port, q):
+    import sys
+    import torch
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    from lambdaworks_cairo_prover_amd import api
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        ctx = api.Context(device=0)
+        ctx.init_rccl()
+        ctx.comm_selftest(1 << 20)
+        ctx.comm_selftest(8)
+        run = api.CairoRun.fibonacci(100)
+        proof = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(4, 3, 3, 1))
+        q.put(("ok", proof))
+        ctx.close()
+    except Exception:
+        import traceback
+        q.put(("fail", traceback.format_exc().encode()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_rccl_transport_single_rank(oracle):
+    """The library's RCCL communicator on the one GPU of the test box (world 1): communicator set-up, ncclAllGather and the
+    grouped ncclSend / ncclRecv all-to-all run and deliver the documented layout (sp_comm_selftest)."""
+    from lambdaworks_cairo_prover_amd import api
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_single_worker, args=(_free_port(), q))
+    p.start()
+    status, proof = q.get(timeout=600)
+    p.join(timeout=60)
+    assert status == "ok", proof[:2000]
+    run = api.CairoRun.fibonacci(100)
+    assert proof == oracle.cairo_prove(run.main_trace(), run.public_inputs_c, (4, 3, 3, 1))

@@ -12,6 +12,13 @@ opt = api.ProofOptions(b, q, 3, g)
 for it in range(2):
     t0 = time.time(); proof = ctx.cairo_prove(tr, run.public_inputs_c, opt); t1 = time.time()
     print(f"prove[{it}]: wall {1e3*(t1-t0):.1f} ms, device rounds {['%.1f' % x for x in ctx.last_round_ms()]} ms, proof {len(proof)} bytes", flush=True)
+import torch
+dev = torch.from_numpy(tr).cuda(); torch.cuda.synchronize()
+for it in range(6):
+    t0 = time.time(); p2 = ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt); t1 = time.time()
+    t2 = time.time(); p3 = ctx.cairo_prove(tr, run.public_inputs_c, opt); t3 = time.time()
+    if it >= 3:
+        print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms   from host buffer {1e3*(t3-t2):.1f} ms   (same bytes: {p2 == p3 == proof})", flush=True)
 if len(sys.argv) > 5:
     import oracle_lib as O
     t0 = time.time(); ok = O.cairo_verify(proof, run.public_inputs_c, (b, q, 3, g)); print("oracle verify:", ok, f"{time.time()-t0:.1f}s")
