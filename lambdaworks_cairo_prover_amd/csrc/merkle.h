@@ -21,9 +21,6 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
                             LdeOrder order = LdeOrder{0, 0, 0});
 // Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves);
-// Sharded reduction (several ranks): this rank's contiguous 1/2^logG of every level down to the level with 2^logG nodes;
-// the caller all-gathers that level and finishes with merkle_reduce(st, nodes, 2^logG).
-int merkle_reduce_subtree(hipStream_t st, digest32* nodes, uint64_t n_leaves, uint32_t logG, uint32_t rank);
 // Gather authentication paths: for each of `q` leaf positions, `depth` sibling digests bottom-up (lambdaworks
 // get_proof_by_pos) into out[q][depth].
 int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out);

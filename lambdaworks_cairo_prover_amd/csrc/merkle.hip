@@ -82,9 +82,8 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
 //   write A; read the columns x-1 and x+1 (ten words) -> D[x];  t = rotl(A ^ D[x], rho[x][y]);  write t at pi(x, y);
 //   read B[x][y], B[x+1][y], B[x+2][y] -> chi; iota on lane 0.
 // Two permutations per wave (lanes 0-24 and 32-56).  ~2.5x lower latency, ~8x more lane-instructions per permutation:
-// used only below MK_LANES_MAX_NODES nodes; levels of <= 32 nodes are fused into one launch (MK_LANES_FUSED).
+// used only below MK_LANES_MAX_NODES nodes, several levels per launch (node_hash_lanes_kernel).
 constexpr uint32_t MK_LANES_MAX_NODES = 4096;
-constexpr uint32_t MK_LANES_FUSED = 32;   // slots of the fused launch (1024 threads)
 __device__ __constant__ const uint8_t SP_KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
 __device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t n) { return (v << n) | (v >> ((64u - n) & 63u)); }
@@ -121,18 +120,22 @@ __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool 
     return a;
 }
 
-// nodes[first + i] for i < count; with fused = true (one work-group, count <= its slots) continues with count/2, ... 1.
-__global__ void __launch_bounds__(1024) node_hash_lanes_kernel(digest32* nodes, uint64_t first, uint32_t count, int fused) {
-    __shared__ uint64_t lds[MK_LANES_FUSED * 50];
-    const uint32_t slots = blockDim.x >> 5;
+// Block b reduces `levels` consecutive tree levels of its own nodes: nodes 8b .. 8b+7 of the level with `count` nodes, then
+// 4b .. 4b+3 of the level above, and so on (8 = slots per block).  A small level is latency-bound - one dependent Keccak-f per
+// level plus a launch boundary - so several levels per launch cost their Keccak latencies only; the slots that fall idle on
+// the way up were not needed anyway.  levels = 1: a plain level.  The last launch of a tree (count <= slots) runs to the root.
+__global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, uint32_t count, uint32_t levels) {
+    __shared__ uint64_t lds[8 * 50];
+    const uint32_t slots = blockDim.x >> 5;   // 8
     const uint32_t slot = threadIdx.x >> 5, l = threadIdx.x & 31u;
     const bool lane_active = l < 25u;
     uint64_t* buf = lds + slot * 50;
     uint64_t* words = reinterpret_cast<uint64_t*>(nodes);
-    for (;;) {
-        const uint32_t i = blockIdx.x * slots + slot;
-        if (i < count) {   // uniform per slot (32 lanes), slots never straddle a wave
-            const uint64_t p = first + i;
+    uint32_t mine = slots;                    // slots of this block that still have a node on the current level
+    for (uint32_t lev = 0;; ++lev) {
+        const uint32_t i = blockIdx.x * mine + slot;
+        if (slot < mine && i < count) {   // uniform per slot (32 lanes), slots never straddle a wave
+            const uint64_t p = (uint64_t)(count - 1) + i;
             uint64_t a = 0;
             if (l < 8u) a = words[(2 * p + 1) * 4 + l];          // left digest then right digest: 8 consecutive words
             else if (l == 8u) a = 0x01ULL;                       // original Keccak padding of a 64-byte message
@@ -140,11 +143,11 @@ __global__ void __launch_bounds__(1024) node_hash_lanes_kernel(digest32* nodes, 
             a = keccak_f_lanes(a, l, lane_active, buf);
             if (l < 4u) words[p * 4 + l] = a;
         }
-        if (!fused || count == 1) break;
+        if (lev + 1 >= levels || count == 1 || mine == 1) break;
         __threadfence();
         __syncthreads();
         count >>= 1;
-        first = count - 1;
+        mine >>= 1;
     }
 }
 
@@ -175,39 +178,19 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
 }
 
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
-    for (uint64_t count = n_leaves >> 1; count >= 1; count >>= 1) {
-        uint64_t first = count - 1;
-        if (count > MK_LANES_MAX_NODES) {
-            unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
-            hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, first, count);
-        } else if (count > MK_LANES_FUSED) {
-            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, st, nodes, first, (uint32_t)count, 0);
-        } else {   // the remaining levels count, count/2, ... 1 in one launch
-            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3(1), dim3(32 * MK_LANES_FUSED), 0, st, nodes, first, (uint32_t)count, 1);
-            SP_HIP_CHECK(hipGetLastError());
-            break;
-        }
+    uint64_t count = n_leaves >> 1;
+    for (; count > MK_LANES_MAX_NODES; count >>= 1) {
+        unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
+        hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, count - 1, count);
         SP_HIP_CHECK(hipGetLastError());
     }
-    return SP_OK;
-}
-
-// Coset-sharded commitments: every rank holds all leaf digests but reduces only its contiguous 1/G of each level
-// (the subtree over leaves [rank N/G, (rank+1) N/G)), down to the level with G nodes.  The caller all-gathers that level
-// (one digest per rank) and finishes with merkle_reduce(nodes, G).  Nodes outside the rank's subtree are left unwritten.
-int merkle_reduce_subtree(hipStream_t st, digest32* nodes, uint64_t n_leaves, uint32_t logG, uint32_t rank) {
-    const uint64_t G = 1ull << logG;
-    if (n_leaves < 2 * G) { sp_set_error("merkle: fewer than two leaves per rank"); return SP_E_INVALID_ARG; }
-    for (uint64_t count = n_leaves >> 1; count >= G; count >>= 1) {
-        const uint64_t mine = count >> logG;
-        const uint64_t first = (count - 1) + (uint64_t)rank * mine;
-        if (mine > MK_LANES_MAX_NODES) {
-            unsigned blocks = (unsigned)((mine + MK_THREADS - 1) / MK_THREADS);
-            hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, first, mine);
-        } else {
-            hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((mine + 7) / 8)), dim3(256), 0, st, nodes, first, (uint32_t)mine, 0);
-        }
+    // the upper levels, four per launch (8 -> 4 -> 2 -> 1 nodes per block)
+    while (count >= 1) {
+        const uint32_t levels = count >= 8 ? 4u : (count >= 4 ? 3u : (count >= 2 ? 2u : 1u));
+        hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, st, nodes, (uint32_t)count, levels);
         SP_HIP_CHECK(hipGetLastError());
+        if (count >> levels == 0) break;
+        count >>= levels;
     }
     return SP_OK;
 }
