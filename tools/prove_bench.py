@@ -3,6 +3,8 @@
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import torch
+torch.cuda.init()   # (torch's bundled HIP runtime has to initialise before the library's)
 from lambdaworks_cairo_prover_amd import api
 idx, b, q, g = (int(x) for x in sys.argv[1:5])
 t0 = time.time(); run = api.CairoRun.fibonacci(idx); tr = run.main_trace(); t1 = time.time()
@@ -12,7 +14,6 @@ opt = api.ProofOptions(b, q, 3, g)
 for it in range(2):
     t0 = time.time(); proof = ctx.cairo_prove(tr, run.public_inputs_c, opt); t1 = time.time()
     print(f"prove[{it}]: wall {1e3*(t1-t0):.1f} ms, device rounds {['%.1f' % x for x in ctx.last_round_ms()]} ms, proof {len(proof)} bytes", flush=True)
-import torch
 dev = torch.from_numpy(tr).cuda(); torch.cuda.synchronize()
 for it in range(6):
     t0 = time.time(); p2 = ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt); t1 = time.time()
