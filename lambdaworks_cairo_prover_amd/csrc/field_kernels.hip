@@ -40,8 +40,56 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(fe* data, fe* scratc
     }
 }
 
+// Two-level form for large arrays.  One thread per chunk of BI_CHUNK elements {t, t + T, ...} (T = chunks) keeps the running
+// prefix products of its chunk and hands its chunk product to a second batch inversion over the T products; the chunk
+// inverse then unwinds the chunk.  Compared with one level of 64-element chunks: four times as many threads in flight (the
+// kernel is a chain of dependent loads and products per thread) and 1/16 of the Fermat inversions (250 squarings each).
+// The prefixes of positions 0 and 1 of a chunk are 1 and the element itself, so scratch[0 .. T) holds the chunk products and
+// scratch[T .. 2T) is the scratch of the second level: no memory beyond the caller's n elements.
+constexpr uint32_t BI_CHUNK = 16;
+__global__ void __launch_bounds__(256) batch_inverse_prefix_kernel(const fe* data, fe* scratch, uint64_t T) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    fe acc = fk_ld(data + t);
+#pragma unroll 1
+    for (uint32_t k = 1; k < BI_CHUNK; ++k) {
+        if (k >= 2) fk_st(scratch + t + k * T, acc);
+        acc = fe_mul(acc, fk_ld(data + t + k * T));
+    }
+    fk_st(scratch + t, acc);   // chunk product
+}
+__global__ void __launch_bounds__(256) batch_inverse_unwind_kernel(fe* data, const fe* scratch, uint64_t T) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    fe inv = fk_ld(scratch + t);   // inverse of the chunk product
+#pragma unroll 1
+    for (uint32_t k = BI_CHUNK; k-- > 2;) {
+        const uint64_t i = t + k * T;
+        fe a = fk_ld(data + i);
+        fk_st(data + i, fe_mul(inv, fk_ld(scratch + i)));
+        inv = fe_mul(inv, a);
+    }
+    fe a1 = fk_ld(data + t + T), a0 = fk_ld(data + t);
+    fk_st(data + t + T, fe_mul(inv, a0));
+    fk_st(data + t, fe_mul(inv, a1));
+}
+
 int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_flag_dev) {
     if (n == 0) return SP_OK;
+    if (n >= (1ull << 16) && n % BI_CHUNK == 0) {
+        const uint64_t T = n / BI_CHUNK;
+        const unsigned blocks = (unsigned)((T + 255) / 256);
+        hipLaunchKernelGGL(batch_inverse_prefix_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, T);
+        SP_HIP_CHECK(hipGetLastError());
+        // a zero element makes its chunk product zero: the second level raises the flag
+        uint64_t threads2 = (T + 63) / 64;
+        unsigned blocks2 = (unsigned)((threads2 + 255) / 256);
+        hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks2), dim3(256), 0, st, scratch, scratch + T, T, zero_flag_dev);
+        SP_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(batch_inverse_unwind_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, T);
+        SP_HIP_CHECK(hipGetLastError());
+        return SP_OK;
+    }
     // chunk of ~64 elements per thread amortises the Fermat inversion (~300 mulmods) to < 5 mulmods/element
     uint64_t threads = (n + 63) / 64;
     unsigned blocks = (unsigned)((threads + 255) / 256);

@@ -82,11 +82,17 @@ def test_merkle_matches_oracle(hip_ctx, oracle, n, width):
 
 def test_batch_inverse(hip_ctx, oracle):
     rng = random.Random(5)
-    for n in (1, 2, 63, 64, 65, 5000):
+    for n in (1, 2, 63, 64, 65, 5000, 1 << 16, (1 << 16) + 16, (1 << 16) + 5, 3 << 16):   # >= 2^16 and a multiple of 16: two-level form
         x = api.felts_to_bytes([rng.randrange(1, P) for _ in range(n)])
         assert np.array_equal(hip_ctx.batch_inverse(x), oracle.batch_inverse(x))
     with pytest.raises(api.SpError):
         hip_ctx.batch_inverse(api.felts_to_bytes([5, 0, 7]))
+    big = [rng.randrange(1, P) for _ in range(1 << 16)]
+    for zero_at in (0, 1, 17, (1 << 16) - 1):
+        y = list(big)
+        y[zero_at] = 0
+        with pytest.raises(api.SpError):
+            hip_ctx.batch_inverse(api.felts_to_bytes(y))
 
 
 class _HipBuffer:
