@@ -504,13 +504,23 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
     }
     if (rem > 0) {
         int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
-        for (int i = 0; i < np; ++i) {
-            int take = (rem + (np - i) - 1) / (np - i);
+        std::vector<int> takes;
+        for (int i = 0, left = rem; i < np; ++i) { int take = (left + (np - i) - 1) / (np - i); takes.push_back(take); left -= take; }
+#ifndef SP_NTT_EVEN_SPLIT
+#define SP_NTT_EVEN_SPLIT 0
+#endif
+        // a pass with an odd number of stages runs one of them as a single radix-2 stage - a whole LDS round trip for one stage
+        // instead of two: trade stages between two odd passes where the tile allows it (14 = 8 + 6 instead of 7 + 7)
+        if (SP_NTT_EVEN_SPLIT)
+            for (size_t i = 0; i < takes.size(); ++i)
+                for (size_t j = i + 1; j < takes.size(); ++j)
+                    if ((takes[i] & 1) && (takes[j] & 1) && takes[i] + 1 <= NTT_MAX_STRIDED_LOG && takes[j] >= 3) { takes[i] += 1; takes[j] -= 1; }
+        for (int take : takes) {
             // adjacent elements per row: at least 4 (128 B), more for short passes so that a tile never has fewer
             // than 2^min_tile_log elements (a 2^5-row pass with 4 columns would leave half the work-group idle)
             int g = std::min(std::max(NTT_STRIDED_G_LOG, min_tile_log - take), s);
             out.push_back({s, take, g});
-            s += take; rem -= take;
+            s += take;
         }
     }
     return out;

@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <functional>
 #include <memory>
 
 namespace sp {
@@ -24,11 +27,14 @@ static bool timing_enabled() { static int v = -1; if (v < 0) v = std::getenv("SP
     do { if (timing_enabled()) { (void)hipStreamSynchronize(ctx->stream); double _t = wall_ms(); \
          std::fprintf(stderr, "[sp_timing] %-28s %9.2f ms\n", label, _t - _tp); _tp = _t; } } while (0)
 
+void host_pool_delete(HostPool* p);
+
 StarkProver::~StarkProver() {
     free_all();
     for (auto& e : ev_dma_) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    if (pool_) host_pool_delete(pool_);
 }
 
 void StarkProver::free_all() {
@@ -261,19 +267,62 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     return commit_segment_resident(segment, cols, root_out);
 }
 
-// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace, split over a few threads
-static void host_gather_columns(const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
-    const unsigned T = (unsigned)std::min<uint64_t>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency())), std::max<uint64_t>(1, n >> 12));
-    auto work = [&](uint64_t r0, uint64_t r1) {
+// A few parked host threads for the column gathers of the upload pipeline (creating them per group would put ~5 ms of
+// pthread_create on the critical path of a proof).
+class HostPool {
+  public:
+    explicit HostPool(unsigned workers) {
+        for (unsigned w = 0; w < workers; ++w) threads_.emplace_back([this, w] { loop(w); });
+    }
+    ~HostPool() {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+    }
+    unsigned size() const { return (unsigned)threads_.size() + 1; }
+    // runs job(part, parts) for part = 0 .. parts-1 (parts = workers + 1; the caller takes part 0) and waits for all of them
+    void run(const std::function<void(unsigned, unsigned)>& job) {
+        { std::lock_guard<std::mutex> lk(m_); job_ = &job; pending_ = (unsigned)threads_.size(); ++gen_; }
+        cv_.notify_all();
+        job(0, size());
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [this] { return pending_ == 0; });
+        job_ = nullptr;
+    }
+  private:
+    void loop(unsigned w) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned, unsigned)>* job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return gen_ != seen; });
+                seen = gen_;
+                if (stop_) return;
+                job = job_;
+            }
+            (*job)(w + 1, size());
+            { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+        }
+    }
+    std::vector<std::thread> threads_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned, unsigned)>* job_ = nullptr;
+    unsigned pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+void host_pool_delete(HostPool* p) { delete p; }
+
+// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace, split over the pool
+static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
+    pool.run([&](unsigned part, unsigned parts) {
+        const uint64_t per = (n + parts - 1) / parts, r0 = std::min<uint64_t>(n, part * per), r1 = std::min<uint64_t>(n, r0 + per);
         const uint8_t* s = src + r0 * row_bytes + off;
         uint8_t* d = dst + r0 * width;
         for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width) std::memcpy(d, s, width);
-    };
-    std::vector<std::thread> th;
-    const uint64_t per = (n + T - 1) / T;
-    for (unsigned t = 1; t < T; ++t) th.emplace_back(work, std::min<uint64_t>(n, t * per), std::min<uint64_t>(n, (t + 1) * per));
-    work(0, std::min<uint64_t>(n, per));
-    for (auto& x : th) x.join();
+    });
 }
 
 // interpolate_and_commit (reference prover.rs:126-159) from a HOST buffer, in column groups: while group g is interpolated and
@@ -297,6 +346,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
     if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    if (!pool_) pool_ = new HostPool(std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u));
     if (!copy_stream_) {
         SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
@@ -315,7 +365,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     for (uint32_t g = 0; g < gsize.size(); c0 += gsize[g], ++g) {
         const uint32_t w = gsize[g], slot = g & 1u;
         if (g >= 2) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));                  // the pinned slot has crossed PCIe
-        host_gather_columns(rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
+        host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
         if (g >= 2) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been consumed
         SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)n_ * w * 32, hipMemcpyHostToDevice, copy_stream_));
         SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));

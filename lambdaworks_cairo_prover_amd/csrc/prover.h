@@ -33,6 +33,8 @@ struct Openings {
     std::vector<digest32> fri_paths, fri_paths_sym;              // [q][sum_k (depth0-k)]
 };
 
+class HostPool;   // prover.cpp: parked host threads for the upload pipeline
+
 class StarkProver : public sp_deletable {
   public:
     StarkProver(sp_ctx* ctx) : c_(ctx) {}
@@ -92,6 +94,7 @@ class StarkProver : public sp_deletable {
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
     hipEvent_t ev_dma_[2] = {nullptr, nullptr}, ev_r2c_[2] = {nullptr, nullptr};
     void* h_stage_[2] = {nullptr, nullptr}; size_t stage_bytes_ = 0;   // pinned staging, one column group each
+    HostPool* pool_ = nullptr;
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
     // order of the evaluations inside the trace / composition LDE columns this rank holds (coset-major, common.h)
