@@ -507,7 +507,7 @@ static std::vector<PassGeom> geometry(int k, int first_stride_log, int first_con
         std::vector<int> takes;
         for (int i = 0, left = rem; i < np; ++i) { int take = (left + (np - i) - 1) / (np - i); takes.push_back(take); left -= take; }
 #ifndef SP_NTT_EVEN_SPLIT
-#define SP_NTT_EVEN_SPLIT 0
+#define SP_NTT_EVEN_SPLIT 1
 #endif
         // a pass with an odd number of stages runs one of them as a single radix-2 stage - a whole LDS round trip for one stage
         // instead of two: trade stages between two odd passes where the tile allows it (14 = 8 + 6 instead of 7 + 7)
