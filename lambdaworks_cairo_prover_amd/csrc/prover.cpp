@@ -334,10 +334,10 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // Column groups.  Group g can be transformed once it has crossed PCIe (~0.66 ms per column of 2^20 rows) and everything
     // behind it still has to be transformed (~0.8 ms per column): the finish time is max_g [upload(0..g) + transform(g..)], i.e.
     // a group may grow only as fast as the columns before it have bought time - small groups first, growing by about a fifth
-    // of what is already on the device, eight columns at most.
+    // of what is already on the device (1, 1, 1, 2, 2, 3, 4, 5, 7, 8 for 34 columns), eight columns at most.
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(2, done / 5 + 2));
+        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(1, done / 3 + 1));
         if (cols - done - w < 2) w = cols - done;     // no one-column tail
         w = std::min(w, cols - done);
         gsize.push_back(w);
@@ -366,12 +366,14 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         const uint32_t w = gsize[g], slot = g & 1u;
         if (g >= 2) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));                  // the pinned slot has crossed PCIe
         host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
-        if (g >= 2) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been consumed
+        // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the group has been
+        // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the upload
+        // stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
         SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)n_ * w * 32, hipMemcpyHostToDevice, copy_stream_));
         SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_dma_[slot], 0));
-        SP_TRY(rows_to_columns(c_->stream, c_->enc, landing[slot], n_, w, trace + (uint64_t)c0 * n_, n_));
-        SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], c_->stream));
+        SP_TRY(rows_to_columns(copy_stream_, c_->enc, landing[slot], n_, w, trace + (uint64_t)c0 * n_, n_));
+        SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], copy_stream_));
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_r2c_[slot], 0));
         // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
         SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
