@@ -321,7 +321,12 @@ static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, 
         const uint64_t per = (n + parts - 1) / parts, r0 = std::min<uint64_t>(n, part * per), r1 = std::min<uint64_t>(n, r0 + per);
         const uint8_t* s = src + r0 * row_bytes + off;
         uint8_t* d = dst + r0 * width;
-        for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width) std::memcpy(d, s, width);
+        // 16-byte non-temporal stores into the pinned buffer: no read-for-ownership traffic next to the DMA that is draining
+        // the other slot (the destination is 32-byte aligned; the source only needs byte alignment)
+        typedef long long v2di __attribute__((vector_size(16)));
+        typedef long long v2di_u __attribute__((vector_size(16), aligned(1)));
+        for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width)
+            for (size_t k = 0; k < width; k += 16) __builtin_nontemporal_store(*reinterpret_cast<const v2di_u*>(s + k), reinterpret_cast<v2di*>(d + k));
     });
 }
 
@@ -346,7 +351,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
     if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
-    if (!pool_) pool_ = new HostPool(std::min(15u, std::max(1u, std::thread::hardware_concurrency()) - 1u));
+    if (!pool_) pool_ = new HostPool(std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u));   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
     if (!copy_stream_) {
         SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
