@@ -321,12 +321,7 @@ static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, 
         const uint64_t per = (n + parts - 1) / parts, r0 = std::min<uint64_t>(n, part * per), r1 = std::min<uint64_t>(n, r0 + per);
         const uint8_t* s = src + r0 * row_bytes + off;
         uint8_t* d = dst + r0 * width;
-        // 16-byte non-temporal stores into the pinned buffer: no read-for-ownership traffic next to the DMA that is draining
-        // the other slot (the destination is 32-byte aligned; the source only needs byte alignment)
-        typedef long long v2di __attribute__((vector_size(16)));
-        typedef long long v2di_u __attribute__((vector_size(16), aligned(1)));
-        for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width)
-            for (size_t k = 0; k < width; k += 16) __builtin_nontemporal_store(*reinterpret_cast<const v2di_u*>(s + k), reinterpret_cast<v2di*>(d + k));
+        for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width) std::memcpy(d, s, width);
     });
 }
 
