@@ -413,7 +413,7 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION = 1, 2
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS = 1, 2, 3
 
 
 def _ctx_set_option(self, key, value):
@@ -439,4 +439,4 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION"]
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS"]

@@ -94,6 +94,10 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             c->opt_fri_shard_min_log = (uint32_t)value;
             break;
         case SP_OPT_SHARD_INTERPOLATION: c->opt_shard_interpolation = value != 0; break;
+        case SP_OPT_UPLOAD_THREADS:
+            if (value < 1 || value > 64) return SP_E_INVALID_ARG;
+            c->opt_upload_threads = (uint32_t)value;
+            break;
         default: sp_set_error("sp_set_option: unknown key"); return SP_E_INVALID_ARG;
     }
     delete c->prover_state_deleter_holder;   // the options shape the prover's buffers: start from a fresh one

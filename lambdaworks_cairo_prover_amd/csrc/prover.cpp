@@ -346,7 +346,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
     if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
-    if (!pool_) pool_ = new HostPool(std::min(7u, std::max(1u, std::thread::hardware_concurrency()) - 1u));   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
+    if (!pool_) pool_ = new HostPool(std::min(c_->opt_upload_threads, std::max(1u, std::thread::hardware_concurrency())) - 1u);   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
     if (!copy_stream_) {
         SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < 2; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
