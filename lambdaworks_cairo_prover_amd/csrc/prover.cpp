@@ -345,11 +345,11 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     }
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
-    if (2 * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    if (UPLOAD_SLOTS * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
     if (!pool_) pool_ = new HostPool(std::min(c_->opt_upload_threads, std::max(1u, std::thread::hardware_concurrency())) - 1u);   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
     if (!copy_stream_) {
         SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
+        for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
     }
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -357,14 +357,15 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
         stage_bytes_ = chunk;
     }
-    uint8_t* landing[2] = {reinterpret_cast<uint8_t*>(d_scratch_), reinterpret_cast<uint8_t*>(d_scratch_) + chunk};
+    uint8_t* landing[UPLOAD_SLOTS];
+    for (int i = 0; i < UPLOAD_SLOTS; ++i) landing[i] = reinterpret_cast<uint8_t*>(d_scratch_) + (size_t)i * chunk;
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     uint32_t c0 = 0;
     for (uint32_t g = 0; g < gsize.size(); c0 += gsize[g], ++g) {
-        const uint32_t w = gsize[g], slot = g & 1u;
-        if (g >= 2) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));                  // the pinned slot has crossed PCIe
+        const uint32_t w = gsize[g], slot = g % UPLOAD_SLOTS;
+        if (g >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));       // the pinned slot has crossed PCIe
         host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
         // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the group has been
         // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the upload

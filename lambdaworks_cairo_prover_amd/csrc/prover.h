@@ -92,8 +92,9 @@ class StarkProver : public sp_deletable {
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
-    hipEvent_t ev_dma_[2] = {nullptr, nullptr}, ev_r2c_[2] = {nullptr, nullptr};
-    void* h_stage_[2] = {nullptr, nullptr}; size_t stage_bytes_ = 0;   // pinned staging, one column group each
+    static constexpr int UPLOAD_SLOTS = 3;                    // the gather may run two groups ahead of the DMA
+    hipEvent_t ev_dma_[UPLOAD_SLOTS] = {}, ev_r2c_[UPLOAD_SLOTS] = {};
+    void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging, one column group each
     HostPool* pool_ = nullptr;
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
