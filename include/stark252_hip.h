@@ -93,7 +93,7 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  layers are all-gathered once and continue replicated (fri/mod.rs:20-72 is sequential in the layers);
  *   SP_OPT_SHARD_INTERPOLATION (1) 1: the size-n inverse transforms of a trace segment are split by column over the ranks and the
  *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns.
- *   SP_OPT_UPLOAD_THREADS (16)     host threads that gather the column groups of a row-major host trace into pinned memory
+ *   SP_OPT_UPLOAD_THREADS (24)     host threads that gather the column groups of a row-major host trace into pinned memory
  *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB). */
 enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);

@@ -31,6 +31,6 @@ struct sp_ctx {
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
     bool opt_shard_interpolation = true;
-    uint32_t opt_upload_threads = 16;
+    uint32_t opt_upload_threads = 24;
     sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

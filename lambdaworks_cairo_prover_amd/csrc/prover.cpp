@@ -253,7 +253,8 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         return SP_E_STATE;
     }
     SP_HIP_CHECK(hipSetDevice(c_->device));
-    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20)) return commit_trace_pipelined(segment, rows_host, cols, root_out);
+    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20) && (uint64_t)UPLOAD_SLOTS * 9 * n_ <= scratch_elems())
+        return commit_trace_pipelined(segment, rows_host, cols, root_out);   // (landing slots of up to nine columns each live in the scratch area)
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
