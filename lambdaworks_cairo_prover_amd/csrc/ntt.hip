@@ -306,13 +306,18 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_kernel(NttPassArgs a) {
                            wb = lds_ld(Twl, Twh, ((2 * half - 1u + i) << g) + gl); wc = lds_ld(Twl, Twh, ((3 * half - 1u + i) << g) + gl); }
                 } else {   // pass-local table w_R^e
                     if (j > 1) wa = lds_ld(Twl, Twh, i << (r - j)); else has_wa = false;   // stage 1: w = 1, inputs < 2p
-                    wb = lds_ld(Twl, Twh, i << (r - j - 1)); wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
+                    if (j > 1) wb = lds_ld(Twl, Twh, i << (r - j - 1));                    // stages 1, 2: i = 0, so w_4^0 = 1 as well
+                    wc = lds_ld(Twl, Twh, (i + half) << (r - j - 1));
                 }
                 fe x0 = lds_ld(Llo, Lhi, l0), x1 = lds_ld(Llo, Lhi, l1), x2 = lds_ld(Llo, Lhi, l2), x3 = lds_ld(Llo, Lhi, l3);
                 if (has_wa) { x1 = fe_mul_lazy(x1, wa); x3 = fe_mul_lazy(x3, wa); }
                 fe a0 = fe_add_raw(x0, x1), a1 = fe_sub_add_2p(x0, x1), a2 = fe_add_raw(x2, x3), a3 = fe_sub_add_2p(x2, x3);
-                a2 = fe_mul_lazy(a2, wb); a3 = fe_mul_lazy(a3, wc);
-                const fe y0 = fe_add_raw(a0, a2), y2 = fe_sub_add_2p(a0, a2), y1 = fe_add_raw(a1, a3), y3 = fe_sub_add_2p(a1, a3);
+                a3 = fe_mul_lazy(a3, wc);
+                fe y0, y2;
+                if (has_wa) { a2 = fe_mul_lazy(a2, wb); y0 = fe_add_raw(a0, a2); y2 = fe_sub_add_2p(a0, a2); }
+                else { y0 = fe_add_raw(a0, a2); y2 = fe_sub_add_kp(a0, a2, 4u); }   // a2 = x2 + x3 < 4p unmultiplied: bias 4p, outputs < 8p
+                                                                                    // (2p above the usual bound: 20p after ten stages, still < 32p)
+                const fe y1 = fe_add_raw(a1, a3), y3 = fe_sub_add_2p(a1, a3);
                 if (j + 1 == r && a.radix4 == 1) {
                     if (SP_NTT_PRIO & 2) __builtin_amdgcn_s_setprio(3);
                     // last pair of the pass: straight to global memory (no LDS write, barrier and re-read)
