@@ -90,7 +90,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     ready_ = false; stage_ = 0;
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
-    d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_small_ = nullptr; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
+    d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_small_ = nullptr; d_deepx_ = nullptr; deepx_cap_ = 0; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
     world_ = (uint32_t)c_->world; wrank_ = (uint32_t)c_->rank;
@@ -181,6 +181,14 @@ int StarkProver::ensure_gather(uint64_t elems) {
     if (elems <= gather_cap_) return SP_OK;
     SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
     gather_cap_ = elems;
+    return SP_OK;
+}
+
+// DEEP inverses beyond the shared scratch (many frame rows on a small blowup): one buffer, grown on demand, kept across proofs
+int StarkProver::ensure_deep_scratch(uint64_t elems) {
+    if (elems <= deepx_cap_) return SP_OK;
+    SP_TRY(alloc((void**)&d_deepx_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
+    deepx_cap_ = elems;
     return SP_OK;
 }
 
@@ -929,9 +937,8 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         fe* inv_scratch = d_scratch_ + (uint64_t)npts * n_;    // [npts n]
         fe* p0n = d_scratch_ + 2ull * npts * n_;               // [n]
         if ((2ull * npts + 1) * n_ > scratch_elems()) {   // many frame rows on a small blowup: the inverses outgrow the shared scratch
-            void* big = nullptr;
-            SP_TRY(alloc(&big, sizeof(fe) * (2ull * npts + 1) * n_));   // stays until the next reshaping setup()
-            inv = static_cast<fe*>(big); inv_scratch = inv + (uint64_t)npts * n_; p0n = inv + 2ull * npts * n_;
+            SP_TRY(ensure_deep_scratch((2ull * npts + 1) * n_));
+            inv = d_deepx_; inv_scratch = inv + (uint64_t)npts * n_; p0n = inv + 2ull * npts * n_;
         }
         SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
         SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
@@ -945,9 +952,8 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         // deg H >= 2n (constraint-violating trace): the quotient form on every LDE point this rank holds
         fe* inv = d_scratch_;
         if (2ull * npts * Nl_ > scratch_elems()) {   // more than two frame rows: the inverses outgrow the shared scratch
-            void* big = nullptr;
-            SP_TRY(alloc(&big, sizeof(fe) * 2ull * npts * Nl_));   // stays until the next reshaping setup()
-            inv = static_cast<fe*>(big);
+            SP_TRY(ensure_deep_scratch(2ull * npts * Nl_));
+            inv = d_deepx_;
         }
         fe* inv_scratch = inv + (uint64_t)npts * Nl_;
         SP_TRY(coset_minus_points(c_->stream, inv, Nl_, logN_, roots, h_, pts, npts, shard_map()));

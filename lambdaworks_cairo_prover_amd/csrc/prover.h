@@ -122,6 +122,8 @@ class StarkProver : public sp_deletable {
     fe* d_small_ = nullptr;                                // out-of-domain values of this rank's columns and their all-gather
     fe* d_fullN_ = nullptr;                                // [N] whole-domain scratch when FRI layer 0 is sharded (exceptional paths)
     int ensure_gather(uint64_t elems);
+    int ensure_deep_scratch(uint64_t elems);
+    fe* d_deepx_ = nullptr; uint64_t deepx_cap_ = 0;   // DEEP inverses when they outgrow the shared scratch
     int full_domain_buffer(fe** out);
     int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
     // recv[s] = the block rank s addressed to this role: send = [G][bytes], recv = [G][bytes]
