@@ -163,6 +163,12 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         SP_TRY(gen_power_table(c_->stream, d_post_comp_, n_, logn_, base, minv));
         SP_TRY(gen_power_table(c_->stream, d_post_comp_ + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
         SP_TRY(gen_power_table(c_->stream, d_post_deep_, n_, logn_, u, fe_inv(fe_from_u64(n_))));
+        d_post_comp0_ = nullptr;
+        if (G_ > 1 && logG_ == logb_) {   // one coset per rank: the composition pair (0, b/2) is interpolated with c0 = 0 everywhere
+            SP_TRY(alloc((void**)&d_post_comp0_, sizeof(fe) * 2 * n_));
+            SP_TRY(gen_power_table(c_->stream, d_post_comp0_, n_, logn_, hinv_, minv));
+            SP_TRY(gen_power_table(c_->stream, d_post_comp0_ + n_, n_, logn_, hinv_, fe_mul(minv, hinv_)));
+        }
     }
     ready_ = true;
     stage_ = 1;
@@ -689,12 +695,16 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     // back to the whole domain and the general split, so the bytes are identical for every input.
     int flag = 0;
     bool sub_coset = allow_sub_coset && logb_ >= logG_ + 1;  // this rank holds both cosets c0 = rank and c0 + b/2 (always on one GPU)
-    if (sub_coset) {
+    // one coset per rank (G = b): the 2n points of the cosets 0 and b/2 live on two ranks - every rank evaluates its own coset, the
+    // evaluations are all-gathered and the pair (0, b/2) is interpolated everywhere
+    bool pair_path = allow_sub_coset && !sub_coset && G_ > 1 && logb_ == logG_ && d_post_comp0_;
+    if (sub_coset || pair_path) {
         if (prog_dev) SP_TRY(air_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, prog_dev, c_->d_flag));
         else SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // (also: K is a stack object)
-        sub_coset = flag == 0;
+        sub_coset = sub_coset && flag == 0;
+        pair_path = pair_path && flag == 0;
         SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     } else {
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
@@ -722,6 +732,25 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, d_post_comp_));   // (tables: setup())
         SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        h_full_ = false;
+        SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+    } else if (pair_path) {
+        fe* binv = d_scratch_;                  // [ndist][n]
+        fe* inv_scratch = d_scratch_ + 3 * Nl_;  // [3 n]
+        if (nd) {
+            SP_TRY(coset_minus_points(c_->stream, binv, Nl_, logN_, roots, h_, points.data(), nd, shard_map()));
+            SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * Nl_, c_->d_flag));
+        }
+        SP_TRY(evaluate(Nl_, 0, binv, d_local_));                   // H on this rank's coset
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
+        SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(fe)));    // (synchronises: flag is valid)
+        if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        const uint32_t other = G_ >> 1;                              // the rank that holds coset b/2
+        if (other != 1) SP_HIP_CHECK(hipMemcpyAsync(d_gather_ + n_, d_gather_ + (uint64_t)other * n_, n_ * sizeof(fe), hipMemcpyDeviceToDevice, c_->stream));
+        fe* comp2 = d_h12s_;                                         // H(h w_2n^i): even i from coset 0, odd i from coset b/2
+        SP_TRY(interleave_shards(c_->stream, d_gather_, comp2, n_, ShardMap{1, 1, 0}));
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, 2 * n_, d_post_comp0_));   // post factors of c0 = 0
         h_full_ = false;
         SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else {
@@ -766,7 +795,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, N_, d_h12_, Nl_, 2, lde_order(), logG_, rank_));
         }
     }
-    c_->proof_info[0] = sub_coset ? 1u : (h_full_ ? 3u : 2u);
+    c_->proof_info[0] = (sub_coset || pair_path) ? 1u : (h_full_ ? 3u : 2u);
     c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && d_cstage_) ? 1u : 0u;
     SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
     stage_ = 4;

@@ -157,6 +157,7 @@ class StarkProver : public sp_deletable {
     fe* d_hfull_ = nullptr; bool h_full_ = false;  // general (degree >= 2n) composition polynomial: N/2 coefficients per half
     fe* d_hnat_ = nullptr;    // natural-order staging of the same (exceptional path)
     fe* d_post_comp_ = nullptr; fe* d_post_deep_ = nullptr;   // shape-only post-factor tables (setup)
+    fe* d_post_comp0_ = nullptr;                               // the same for c0 = 0 (one coset per rank)
     fe z_; fe h1_z2_, h2_z2_;
     std::vector<fe> trace_ood_;
     std::vector<uint32_t> offsets_{0, 1};   // transition offsets of the AIR (frame rows); Cairo: {0, 1}

@@ -65,6 +65,7 @@ def _worker(rank, world, port, case, options, knobs, q):
         proof = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
         proof2 = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))  # buffer reuse path
         stats = ctx.comm_stats()
+        stats["composition_path"] = ctx.last_proof_info()["composition_path"]
         q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE", stats))
         ctx.close()
     except Exception:
@@ -119,6 +120,9 @@ def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_
         proof, stats = results[r]
         assert proof == want, (r, proof[:300])
         assert stats["world"] == world and stats["allgather_calls"] > 0
+        # valid traces take the 2n-point composition (also with one coset per rank: cosets 0 and b/2 come from two ranks),
+        # constraint-violating ones the whole domain with the general split
+        assert stats["composition_path"] == (1 if case["kind"] == "fib" else 3)
         if knobs.get("alltoall", True) and world <= options[0]:
             assert stats["alltoall_calls"] >= 3          # main, aux and composition commitments at least
 
