@@ -50,9 +50,12 @@ def _worker(rank, world, port, q):
 
 
 def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib):
-    import torch
+    import ctypes
     from lambdaworks_cairo_prover_amd import api
-    free, total = torch.cuda.mem_get_info(0)
+    hip = ctypes.CDLL("libamdhip64.so")          # the runtime the library itself uses (no second HIP runtime in this process)
+    free, total = ctypes.c_size_t(), ctypes.c_size_t()
+    assert hip.hipSetDevice(0) == 0 and hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    free = free.value
     if free < 200e9:
         pytest.skip("needs ~200 GB of free device memory")
     run = api.CairoRun.fibonacci(FIB_INDEX)
