@@ -1,5 +1,5 @@
 // Host-side pieces of the Cairo AIR that sit between the device rounds (reference src/cairo/air.rs):
-// CairoAIR::new (:587-658), build_auxiliary_trace (:660-729, helpers :475-572), boundary_constraints (:777-849).
+// CairoAIR::new (:587-658), boundary_constraints (:777-849).  (build_auxiliary_trace runs on the device: aux_kernels.hip.)
 #pragma once
 #include "cairo_host.h"
 #include "../../include/stark252_hip.h"
@@ -17,10 +17,6 @@ struct CairoAirInfo {
 };
 
 CairoAirInfo cairo_air_info(const PublicInputs& pub);
-
-// Row-major n x 18 auxiliary trace from the row-major n x main_cols main trace and the three RAP challenges
-// (alpha_memory, z_memory, z_range_check).
-std::vector<fe> build_auxiliary_trace(const fe* main_trace, uint64_t n, uint32_t main_cols, const PublicInputs& pub, const fe rap[3]);
 
 std::vector<BoundaryConstraint> boundary_constraints(const PublicInputs& pub, const fe rap[3], uint64_t trace_length, bool has_rc_builtin);
 

@@ -86,8 +86,6 @@ class NttEngine {
     // dst[i] = src[i] * base^i * c  (natural index), c nullable. Used by the coset variants of sp_ntt.
     int scale_by_powers(fe* data, uint64_t n, uint32_t batch, uint64_t stride, const fe& base, const fe* c);
 
-    // number of butterfly passes launched by the last call and their kernel time (hipEvent), for bench.py
-    float last_ms = 0.f;
     hipStream_t stream() const { return stream_; }
 
   private:
@@ -100,6 +98,5 @@ class NttEngine {
 
 // host helpers
 fe host_primitive_root(int k);          // w of order 2^k (lambdaworks get_primitive_root_of_unity)
-std::vector<int> ntt_plan(int k, int first_stride_log);  // pass sizes r_1, r_2, ... (sum = k - first_stride_log)
 
 }  // namespace sp

@@ -388,28 +388,6 @@ fe host_primitive_root(int k) {
     return w;
 }
 
-std::vector<int> ntt_plan(int k, int first_stride_log) {
-    // passes cover stages first_stride_log+1 .. k ; a pass at stride 0 may be NTT_MAX_CONTIG_LOG long, the others
-    // at most NTT_MAX_STRIDED_LOG; the strided remainder is split evenly.
-    std::vector<int> plan;
-    int rem = k - first_stride_log;
-    if (rem <= 0) return plan;
-    if (first_stride_log == 0) {
-        int r1 = std::min(rem, NTT_MAX_CONTIG_LOG);
-        plan.push_back(r1);
-        rem -= r1;
-    }
-    if (rem > 0) {
-        int np = (rem + NTT_MAX_STRIDED_LOG - 1) / NTT_MAX_STRIDED_LOG;
-        for (int i = 0; i < np; ++i) {
-            int take = (rem + (np - i) - 1) / (np - i);
-            plan.push_back(take);
-            rem -= take;
-        }
-    }
-    return plan;
-}
-
 NttEngine::~NttEngine() {
     for (auto& kv : roots_) (void)hipFree(kv.second);
     for (auto& kv : inv_small_) (void)hipFree(kv.second);

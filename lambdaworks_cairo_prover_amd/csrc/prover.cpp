@@ -127,7 +127,6 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     SP_TRY(alloc((void**)&d_comp_consts_, sizeof(CompositionConsts)));
     SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
     SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
-    SP_TRY(alloc((void**)&d_positions_, sizeof(uint64_t) * 4096));
     d_memcols_ = d_trace_ + 19 * n_;  // pc .. off_op1 columns of the main trace (input of the Cairo auxiliary trace)
     // FRI: layers of at least 2^opt_fri_shard_min_log leaves (and at least 2 G^2, so that every rank owns whole blocks of the
     // digest exchange) stay sharded; from layer fri_rep_ on every rank holds the whole layer.  The last, uncommitted fold

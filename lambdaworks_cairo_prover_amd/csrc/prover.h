@@ -150,7 +150,6 @@ class StarkProver : public sp_deletable {
     AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
-    uint64_t* d_positions_ = nullptr;
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
     AuxWorkspace auxws_{};
