@@ -219,3 +219,50 @@ def test_rccl_transport_single_rank(oracle):
     assert status == "ok", proof[:2000]
     run = api.CairoRun.fibonacci(100)
     assert proof == oracle.cairo_prove(run.main_trace(), run.public_inputs_c, (4, 3, 3, 1))
+
+
+def _air_worker(rank, world, port, n, options, q):
+    import sys
+    import torch.distributed as dist
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.dirname(here))
+    sys.path.insert(0, here)
+    import wide_air
+    from lambdaworks_cairo_prover_amd import api
+    from test_wide_air import to_bytes
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ctx = api.Context(device=0)
+        ctx.set_collective(world, rank, api.StagedAllGather())
+        ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, 5)
+        desc, keep = wide_air.build(n).build()
+        proof = ctx.air_prove(desc, to_bytes(wide_air.main_trace(n)), api.ProofOptions(*options))
+        q.put((rank, proof))
+        ctx.close()
+    except Exception:
+        import traceback
+        q.put((rank, ("fail: " + traceback.format_exc()).encode()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n,options", [(2, 64, (4, 3, 3, 1)), (4, 256, (4, 4, 3, 2)), (2, 128, (8, 3, 3, 1))])
+def test_sharded_program_air(world, n, options, oracle):
+    """sp_air_prove on several ranks (five frame rows, caller-built auxiliary trace): the oracle's bytes."""
+    import oracle_lib as O
+    import wide_air
+    from test_wide_air import to_bytes
+    desc, keep = wide_air.build(n).build()
+    want = O.program_air_prove(desc, to_bytes(wide_air.main_trace(n)), options)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_air_worker, args=(r, world, port, n, options, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    for r in range(world):
+        assert got[r] == want, (r, got[r][:400])
