@@ -365,6 +365,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
         for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
     }
+    SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
         stage_bytes_ = 0;
