@@ -22,6 +22,15 @@ void sp_set_error(const std::string& s);
         if (_r != SP_OK) return _r; \
     } while (0)
 
+// Waits for a stream by polling it: the proof's Fiat-Shamir round trips (root down, challenge up) are latency, and a blocking
+// hipStreamSynchronize costs ~20 us of wake-up each.  Only for waits that are short by construction (the proof path).
+static inline hipError_t sp_stream_wait_polling(hipStream_t st) {
+    for (;;) {
+        const hipError_t e = hipStreamQuery(st);
+        if (e != hipErrorNotReady) return e;
+    }
+}
+
 static inline int sp_log2_exact(uint64_t n) {
     if (n == 0 || (n & (n - 1))) return -1;
     int k = 0;

@@ -83,13 +83,17 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
 //   read B[x][y], B[x+1][y], B[x+2][y] -> chi; iota on lane 0.
 // Two permutations per wave (lanes 0-24 and 32-56).  ~2.5x lower latency, ~8x more lane-instructions per permutation:
 // used only below MK_LANES_MAX_NODES nodes, several levels per launch (node_hash_lanes_kernel).
-constexpr uint32_t MK_LANES_MAX_NODES = 4096;
+#ifndef SP_MK_LANES_MAX_NODES
+#define SP_MK_LANES_MAX_NODES 4096
+#endif
+constexpr uint32_t MK_LANES_MAX_NODES = SP_MK_LANES_MAX_NODES;
 __device__ __constant__ const uint8_t SP_KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
 __device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t n) { return (v << n) | (v >> ((64u - n) & 63u)); }
 
-// one permutation slot = 32 consecutive lanes (25 active); buf = 50 words of LDS owned by the slot
-__device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool active, uint64_t* buf) {
+// one permutation slot = 32 consecutive lanes (25 active); buf = 50 words of LDS owned by the slot; rc = the 24 round
+// constants in LDS (a scalar load per round would sit in the dependent chain)
+__device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool active, uint64_t* buf, const uint64_t* rc) {
     const uint32_t x = l % 5u, y = l / 5u;
     uint64_t* A = buf;
     uint64_t* B = buf + 25;
@@ -113,7 +117,7 @@ __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool 
         if (active) {
             const uint64_t b0 = B[l], b1 = B[xp + 5u * y], b2 = B[xpp + 5u * y];
             a = b0 ^ (~b1 & b2);
-            if (l == 0) a ^= SP_KECCAK_RC_DEV[r];
+            if (l == 0) a ^= rc[r];
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -123,28 +127,40 @@ __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool 
 // Block b reduces `levels` consecutive tree levels of its own nodes: nodes 8b .. 8b+7 of the level with `count` nodes, then
 // 4b .. 4b+3 of the level above, and so on (8 = slots per block).  A small level is latency-bound - one dependent Keccak-f per
 // level plus a launch boundary - so several levels per launch cost their Keccak latencies only; the slots that fall idle on
-// the way up were not needed anyway.  levels = 1: a plain level.  The last launch of a tree (count <= slots) runs to the root.
+// the way up were not needed anyway.  The digests of a level reach the next one through LDS (the copy in the node array is
+// written on the side: nobody in this launch reads it).  levels = 1: a plain level.  The last launch of a tree runs to the root.
 __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, uint32_t count, uint32_t levels) {
     __shared__ uint64_t lds[8 * 50];
+    __shared__ uint64_t hand[2][8 * 4];
+    __shared__ uint64_t rc[24];
     const uint32_t slots = blockDim.x >> 5;   // 8
     const uint32_t slot = threadIdx.x >> 5, l = threadIdx.x & 31u;
     const bool lane_active = l < 25u;
     uint64_t* buf = lds + slot * 50;
     uint64_t* words = reinterpret_cast<uint64_t*>(nodes);
+    if (threadIdx.x < 24) rc[threadIdx.x] = SP_KECCAK_RC_DEV[threadIdx.x];
+    __syncthreads();
     uint32_t mine = slots;                    // slots of this block that still have a node on the current level
     for (uint32_t lev = 0;; ++lev) {
         const uint32_t i = blockIdx.x * mine + slot;
         if (slot < mine && i < count) {   // uniform per slot (32 lanes), slots never straddle a wave
             const uint64_t p = (uint64_t)(count - 1) + i;
             uint64_t a = 0;
-            if (l < 8u) a = words[(2 * p + 1) * 4 + l];          // left digest then right digest: 8 consecutive words
+#ifdef SP_MK_GLOBAL_HANDOFF   // A/B: the round-2 form (children re-read from the node array behind a device-scope fence)
+            if (l < 8u) a = words[(2 * p + 1) * 4 + l];
+#else
+            if (l < 8u) a = lev == 0 ? words[(2 * p + 1) * 4 + l]                       // left digest then right digest: 8 consecutive words
+                                     : hand[(lev - 1) & 1u][(2 * slot) * 4 + l];         // = slots 2 slot, 2 slot + 1 of the level below
+#endif
             else if (l == 8u) a = 0x01ULL;                       // original Keccak padding of a 64-byte message
             else if (l == 16u) a = 0x8000000000000000ULL;
-            a = keccak_f_lanes(a, l, lane_active, buf);
-            if (l < 4u) words[p * 4 + l] = a;
+            a = keccak_f_lanes(a, l, lane_active, buf, rc);
+            if (l < 4u) { words[p * 4 + l] = a; hand[lev & 1u][slot * 4 + l] = a; }
         }
         if (lev + 1 >= levels || count == 1 || mine == 1) break;
+#ifdef SP_MK_GLOBAL_HANDOFF
         __threadfence();
+#endif
         __syncthreads();
         count >>= 1;
         mine >>= 1;

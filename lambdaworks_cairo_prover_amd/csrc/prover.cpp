@@ -35,6 +35,21 @@ StarkProver::~StarkProver() {
     for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
+    if (h_pin_) (void)hipHostFree(h_pin_);
+}
+
+int StarkProver::wait_stream() {
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
+    return SP_OK;
+}
+
+int StarkProver::readback(void* dst_host, const void* src_dev, size_t bytes) {
+    if (bytes > 4096) return SP_E_INVALID_ARG;
+    if (!h_pin_ && hipHostMalloc(&h_pin_, 4096, hipHostMallocDefault) != hipSuccess) { h_pin_ = nullptr; sp_set_error("pinned read-back slot: allocation failed"); return SP_E_ALLOC; }
+    SP_HIP_CHECK(hipMemcpyAsync(h_pin_, src_dev, bytes, hipMemcpyDeviceToHost, c_->stream));
+    SP_TRY(wait_stream());
+    memcpy(dst_host, h_pin_, bytes);
+    return SP_OK;
 }
 
 void StarkProver::free_all() {
@@ -208,7 +223,7 @@ int StarkProver::full_domain_buffer(fe** out) {
 // Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank]
 // (the first G slots are the G distinct roles).
 int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
     int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
     if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
     c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
@@ -219,7 +234,7 @@ int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes
 // hook exists (every rank is its own role then); otherwise an all-gather of the whole send array and a local selection.
 int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes) {
     if (c_->alltoall && world_ == G_) {
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         int rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes);
         if (rc != 0) { sp_set_error("all-to-all hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
         c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
@@ -254,9 +269,7 @@ int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncol
         SP_HIP_CHECK(hipMemcpyAsync(tree.top + (G_ - 1), d_roots_, G_ * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
         SP_TRY(merkle_reduce(c_->stream, tree.top, G_));
     }
-    SP_HIP_CHECK(hipMemcpyAsync(root_out, tree.top, 32, hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
-    return SP_OK;
+    return readback(root_out, tree.top, 32);
 }
 
 int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], bool rows_on_device) {
@@ -466,7 +479,7 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag));
     int flag = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // pa / pv are locals; flag
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // pa / pv are locals; flag
     if (flag) { sp_set_error("commit_aux_cairo: malformed trace (address >= 2^64, offset >= 2^16 or zero permutation denominator)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
     return commit_segment_resident(1, Ca_, root_out);
 }
@@ -633,10 +646,10 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
         std::vector<fe> er(max_ex);
         for (uint32_t j = 0; j < max_ex; ++j) er[j] = fe_pow_u64(g_, n_ - 1 - j);
         SP_HIP_CHECK(hipMemcpyAsync(d_ex_roots_, er.data(), sizeof(fe) * max_ex, hipMemcpyHostToDevice, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
     }
     SP_HIP_CHECK(hipMemcpyAsync(d_air_prog_, &prog, sizeof(prog), hipMemcpyHostToDevice, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // prog is a stack object
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // prog is a stack object
     // --- boundary data and per-coset constants
     std::vector<uint64_t> steps;
     CompositionConsts K;
@@ -702,12 +715,12 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         if (prog_dev) SP_TRY(air_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, prog_dev, c_->d_flag));
         else SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // (also: K is a stack object)
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
         sub_coset = sub_coset && flag == 0;
         pair_path = pair_path && flag == 0;
         SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     } else {
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));  // K is a stack object
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // K is a stack object
     }
     if (sub_coset) {
         const uint64_t M = 2 * n_;
@@ -730,7 +743,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // 2n c_j hp^j for j = 2k, position n + q for j = 2k + 1 (k = rev_n(q)); the post factors leave a_k h^k = c_2k h^k
         // and b_k h^k = c_(2k+1) h^k:  (2n)^-1 (h^-1 u^2)^k  and  (2n)^-1 (h^-1 u) (h^-1 u^2)^k,  u = w_N^-c0.
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, d_post_comp_));   // (tables: setup())
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
         h_full_ = false;
         SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
@@ -771,11 +784,11 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp, (int)logN_, 1, N_, nullptr));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
         SP_TRY(high_coeff_check(c_->stream, comp, N_, logb_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         h_full_ = flag != 0;
         if (!h_full_) {
             SP_TRY(split_composition(c_->stream, comp, n_, logb_, d_t2_, hinv_, d_h12s_, d_h12s_ + n_));
@@ -877,10 +890,10 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
         in = outb; in_stride = (uint64_t)points * M; in_points = points;
         which ^= 1;
     }
-    SP_HIP_CHECK(hipStreamSynchronize(c->stream));  // yp is a local vector
+    SP_HIP_CHECK(sp_stream_wait_polling(c->stream));  // yp is a local vector
     out.resize((size_t)vectors * points);
     SP_HIP_CHECK(hipMemcpyAsync(out.data(), in, out.size() * sizeof(fe), hipMemcpyDeviceToHost, c->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    SP_HIP_CHECK(sp_stream_wait_polling(c->stream));
     return SP_OK;
 }
 
@@ -945,7 +958,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
             K.c_t[k] = fe_add(K.c_t[k], fe_mul(tg[(size_t)j * R + k], trace_ood_[(size_t)k * C_ + j]));
         }
     SP_HIP_CHECK(hipMemcpyAsync(d_deep_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
     fe pts[AIR_MAX_OFFSETS + 1];                       // z g^ofs_k for every frame row, then z^2
     for (uint32_t k = 0; k < R; ++k) pts[k] = fe_mul(z_, fe_pow_u64(g_, offsets_[k]));
     pts[R] = fe_sqr(z_);
@@ -1040,8 +1053,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
         // polynomial is constant and every evaluation already equals it).
         const uint32_t bb = 1u << logb_;
         std::vector<fe> ev(bb);
-        SP_HIP_CHECK(hipMemcpyAsync(ev.data(), d_fri_evals_[k + 1], sizeof(fe) * bb, hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_TRY(readback(ev.data(), d_fri_evals_[k + 1], sizeof(fe) * bb));
         fe sum = fe_zero();
         for (auto& e : ev) sum = fe_add(sum, e);
         *last_value = fe_mul(sum, binv_);
@@ -1062,8 +1074,7 @@ int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* no
     for (uint64_t start = 0;; start += batch) {
         for (uint32_t u = 0; u < 4; ++u) SP_TRY(grind_range(c_->stream, challenge, factor, start + u * sub, sub, d_nonce_));
         unsigned long long r = 0;
-        SP_HIP_CHECK(hipMemcpyAsync(&r, d_nonce_, sizeof(r), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipStreamSynchronize(c_->stream));
+        SP_TRY(readback(&r, d_nonce_, sizeof(r)));
         if (r != ~0ULL) { *nonce_out = r; return SP_OK; }
         if (start > (1ULL << 40)) { sp_set_error("grind: nonce not found"); return SP_E_UNSUPPORTED; }
     }
@@ -1151,7 +1162,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     } else {
         SP_HIP_CHECK(hipMemcpyAsync(host.data(), blk, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
     }
-    SP_HIP_CHECK(hipStreamSynchronize(st));   // (hidx is a local)
+    SP_HIP_CHECK(sp_stream_wait_polling(st));   // (hidx is a local)
     auto slot = [&](uint32_t owner) -> const fe* { return host.data() + (G_ > 1 ? (size_t)owner * items : 0); };
     auto take_values = [&](const ValJob& v, size_t s, fe* dst) {
         const uint32_t owner = v.sharded ? (uint32_t)(v.idx[s] & (G_ - 1)) : rank_;

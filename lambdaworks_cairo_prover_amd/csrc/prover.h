@@ -79,6 +79,10 @@ class StarkProver : public sp_deletable {
     // subtree roots; root = top[0].
     struct TreeBuf { digest32* sub = nullptr; digest32* top = nullptr; uint64_t sub_leaves = 0; };
     void free_all();
+    // small device -> host read-back on the compute stream through a pinned slot, waiting by polling the stream (a blocking
+    // synchronisation costs ~20 us of wake-up per Fiat-Shamir round trip; a proof has ~35 of them)
+    int readback(void* dst_host, const void* src_dev, size_t bytes);
+    int wait_stream();
     int alloc(void** p, size_t bytes);
     int alloc_tree(TreeBuf& t, uint64_t leaves_total, bool sharded);
     int setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
@@ -150,6 +154,7 @@ class StarkProver : public sp_deletable {
     AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
+    void* h_pin_ = nullptr;   // 4 KB of pinned host memory for readback()
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
     AuxWorkspace auxws_{};
