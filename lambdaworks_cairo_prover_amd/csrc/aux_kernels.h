@@ -19,6 +19,10 @@ struct AuxWorkspace {
     fe* block_tot;            // prefix-product block totals (>= 4n / 2048 + 1, two levels)
     fe *pm_addr, *pm_val;     // public memory (capacity pm_cap)
     void* sort_tmp; size_t sort_tmp_bytes;
+    // the range-check half runs on its own stream beside the memory half: its own keys, sort workspace and block totals
+    uint16_t* rc_keys;        // 3n
+    void* sort_tmp_rc;
+    fe* block_tot_rc;
     uint64_t n; uint64_t pm_cap;
 };
 
@@ -32,8 +36,11 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
 // aux_cols_out: 18 natural-order columns at stride n (sorted offsets 0-2, sorted addresses 3-6, sorted values 7-10,
 // memory permutation 11-14, range-check permutation 15-17).  *flag_dev is set on malformed input (address >= 2^64,
 // offset >= 2^16, zero denominator).
+// side / ev_fork / ev_join: when side is not null the range-check half (sort of the offsets, its table of inverses, its prefix
+// product) is queued there - two chains of dependent latencies (a batch inversion each) side by side instead of in a row.
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                           uint64_t pm, const fe rap[3], fe* aux_cols_out, int* flag_dev);
+                           uint64_t pm, const fe rap[3], fe* aux_cols_out, int* flag_dev, hipStream_t side = nullptr,
+                           hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 
 // In-place inclusive prefix product of M elements (block_tot: workspace of >= M/2048 + 2 elements).
 int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot);

@@ -198,7 +198,9 @@ size_t aux_workspace_bytes(uint64_t n, uint64_t pm_cap, size_t* sort_tmp_bytes) 
     b += 2 * align_up(sizeof(fe) * 65536);
     b += align_up(sizeof(fe) * (4 * n / PP_BLOCK + 8));
     b += 2 * align_up(sizeof(fe) * (pm_cap + 1));
-    b += align_up(tmp);
+    b += 2 * align_up(tmp);
+    b += align_up(sizeof(uint16_t) * 3 * n);
+    b += align_up(sizeof(fe) * (4 * n / PP_BLOCK + 8));
     return b;
 }
 
@@ -217,15 +219,24 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
     w.block_tot = (fe*)take(sizeof(fe) * (4 * n / PP_BLOCK + 8));
     w.pm_addr = (fe*)take(sizeof(fe) * (pm_cap + 1)); w.pm_val = (fe*)take(sizeof(fe) * (pm_cap + 1));
     w.sort_tmp = take(sort_tmp_bytes); w.sort_tmp_bytes = sort_tmp_bytes;
+    w.sort_tmp_rc = take(sort_tmp_bytes);
+    w.rc_keys = (uint16_t*)take(sizeof(uint16_t) * 3 * n);
+    w.block_tot_rc = (fe*)take(sizeof(fe) * (4 * n / PP_BLOCK + 8));
     w.n = n; w.pm_cap = pm_cap;
 }
 
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                           uint64_t pm, const fe rap[3], fe* out, int* flag) {
+                           uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
     if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
     AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
     const uint64_t M = 4 * n, M3 = 3 * n;
     auto blocks = [](uint64_t x) { return dim3((unsigned)((x + 255) / 256)); };
+    const bool fork = side && ev_fork && ev_join;
+    hipStream_t rs = fork ? side : st;            // stream of the range-check half
+    if (fork) {
+        SP_HIP_CHECK(hipEventRecord(ev_fork, st));   // the trace columns and the cleared flag are behind this point
+        SP_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
+    }
     if (pm) {
         SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
         SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
@@ -241,14 +252,17 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
     SP_TRY(prefix_product(st, w.num, M, w.block_tot));
     // range check: counting sort of the 3n 16-bit offsets, permutation column
     const fe* off_cols = mem_cols + 8 * n;
-    uint16_t* rc_keys = reinterpret_cast<uint16_t*>(w.keys_in);  // the 4n u64 key buffer is free again here
-    hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, off_cols, n, rc_keys, flag);
+    hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_keys, flag);
     size_t tmp2 = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp, tmp2, rc_keys, w.rc_sorted, (size_t)M3, 0, 16, st));
-    hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, st, w.rc_den, K);
-    SP_TRY(batch_inverse(st, w.rc_den, w.rc_den_scratch, 65536, flag));
-    hipLaunchKernelGGL(rc_terms_kernel, blocks(M3), dim3(256), 0, st, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);
-    SP_TRY(prefix_product(st, w.rc_terms, M3, w.block_tot));
+    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, rs));
+    hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, rs, w.rc_den, K);
+    SP_TRY(batch_inverse(rs, w.rc_den, w.rc_den_scratch, 65536, flag));
+    hipLaunchKernelGGL(rc_terms_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);
+    SP_TRY(prefix_product(rs, w.rc_terms, M3, w.block_tot_rc));
+    if (fork) {
+        SP_HIP_CHECK(hipEventRecord(ev_join, side));
+        SP_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
+    }
     hipLaunchKernelGGL(aux_interleave_kernel, blocks(n), dim3(256), 0, st, n, w.rc_sorted, w.a_s, w.v_s, w.num, w.rc_terms, out);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;

@@ -36,6 +36,15 @@ StarkProver::~StarkProver() {
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
+    for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_}) if (e) (void)hipEventDestroy(e);
+    if (side_stream_) (void)hipStreamDestroy(side_stream_);
+}
+
+int StarkProver::ensure_side() {
+    if (!side_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
+    for (hipEvent_t* e : {&ev_side_fork_, &ev_side_deep_, &ev_side_bnd_, &ev_side_aux_})
+        if (!*e) SP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    return SP_OK;
 }
 
 int StarkProver::wait_stream() {
@@ -56,6 +65,8 @@ void StarkProver::free_all() {
     (void)hipSetDevice(c_->device);
     (void)hipStreamSynchronize(c_->stream);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    if (side_stream_) (void)hipStreamSynchronize(side_stream_);
+    d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
@@ -99,6 +110,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
+        bpre_valid_ = false; deep_pref_ = false;
         return SP_OK;
     }
     free_all();
@@ -205,6 +217,60 @@ int StarkProver::ensure_gather(uint64_t elems) {
 }
 
 // DEEP inverses beyond the shared scratch (many frame rows on a small blowup): one buffer, grown on demand, kept across proofs
+// DEEP denominators of round 4 on the side stream while round 3 evaluates the polynomials at z (same arrays, same batch
+// inversion as deep_fri_begin's inline path; valid-trace form only: one coset of n points).
+int StarkProver::prefetch_deep_inverses() {
+    deep_pref_ = false;
+    if (h_full_) return SP_OK;
+    const uint32_t R = (uint32_t)offsets_.size(), npts = R + 1;
+    SP_TRY(ensure_side());
+    SP_TRY(ensure_deep_scratch((2ull * npts + 1) * n_));
+    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 2 * sizeof(int)));
+    fe pts[AIR_MAX_OFFSETS + 1];
+    for (uint32_t k = 0; k < R; ++k) pts[k] = fe_mul(z_, fe_pow_u64(g_, offsets_[k]));
+    pts[R] = fe_sqr(z_);
+    const fe* roots_n = nullptr;
+    SP_TRY(c_->ntt->roots((int)logn_, &roots_n));
+    const fe hp = fe_mul(h_, fe_pow_u64(host_primitive_root((int)logN_), rank_));
+    SP_HIP_CHECK(hipEventRecord(ev_side_fork_, c_->stream));          // (the buffer's previous readers are behind this point)
+    SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
+    SP_HIP_CHECK(hipMemsetAsync(d_flag_side_, 0, sizeof(int), side_stream_));
+    SP_TRY(coset_minus_points(side_stream_, d_deepx_, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
+    SP_TRY(batch_inverse(side_stream_, d_deepx_, d_deepx_ + (uint64_t)npts * n_, (uint64_t)npts * n_, d_flag_side_));
+    SP_HIP_CHECK(hipEventRecord(ev_side_deep_, side_stream_));
+    deep_pref_ = true;
+    return SP_OK;
+}
+
+// Boundary denominators of round 2 for a constraint-satisfying trace (the 2n points of this rank's coset pair), computed on
+// the side stream while round 1 runs.  composition_core uses them when it takes that path with the same boundary points.
+int StarkProver::prefetch_boundary_inverses(const std::vector<uint64_t>& steps_in) {
+    bpre_valid_ = false;
+    if (!ready_ || logb_ < logG_ + 1) return SP_OK;
+    std::vector<uint64_t> steps;
+    for (uint64_t s : steps_in) if (std::find(steps.begin(), steps.end(), s) == steps.end()) steps.push_back(s);
+    if (steps.empty() || steps.size() > 3) return SP_OK;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    SP_TRY(ensure_side());
+    const uint64_t M = 2 * n_;
+    if (bpre_cap_ < 6 * M) { SP_TRY(alloc((void**)&d_bpre_, sizeof(fe) * 6 * M)); bpre_cap_ = 6 * M; }
+    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 2 * sizeof(int)));
+    bpre_points_.clear();
+    for (uint64_t s : steps) bpre_points_.push_back(fe_pow_u64(g_, s));
+    const fe* roots_m = nullptr;
+    SP_TRY(c_->ntt->roots((int)logn_ + 1, &roots_m));
+    const fe hp = fe_mul(h_, fe_pow_u64(host_primitive_root((int)logN_), rank_));
+    const uint32_t nd = (uint32_t)bpre_points_.size();
+    SP_HIP_CHECK(hipEventRecord(ev_side_fork_, c_->stream));
+    SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
+    SP_HIP_CHECK(hipMemsetAsync(d_flag_side_ + 1, 0, sizeof(int), side_stream_));
+    SP_TRY(coset_minus_points(side_stream_, d_bpre_, M, logn_ + 1, roots_m, hp, bpre_points_.data(), nd, ShardMap{0, 0, 0}));
+    SP_TRY(batch_inverse(side_stream_, d_bpre_, d_bpre_ + 3 * M, (uint64_t)nd * M, d_flag_side_ + 1));
+    SP_HIP_CHECK(hipEventRecord(ev_side_bnd_, side_stream_));
+    bpre_valid_ = true;
+    return SP_OK;
+}
+
 int StarkProver::ensure_deep_scratch(uint64_t elems) {
     if (elems <= deepx_cap_) return SP_OK;
     SP_TRY(alloc((void**)&d_deepx_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
@@ -476,7 +542,9 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
         }
     }
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag));
+    SP_TRY(ensure_side());
+    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag,
+                                  side_stream_, ev_side_fork_, ev_side_aux_));
     int flag = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
     SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // pa / pv are locals; flag
@@ -732,10 +800,17 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         const fe hp = fe_mul(h_, fe_pow_u64(wN, rank_));
         fe* binv = d_scratch_;                    // [ndist][2n]
         fe* inv_scratch = d_scratch_ + 3 * M;     // [3 * 2n]
-        if (nd) {
+        bool pref = bpre_valid_ && nd == bpre_points_.size();
+        for (uint32_t j = 0; pref && j < nd; ++j) pref = fe_eq(points[j], bpre_points_[j]);
+        if (nd && pref) {                         // computed beside round 1 (prefetch_boundary_inverses)
+            binv = d_bpre_;
+            SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_bnd_, 0));
+        } else if (nd) {
             SP_TRY(coset_minus_points(c_->stream, binv, M, logn_ + 1, roots_m, hp, points.data(), nd, ShardMap{0, 0, 0}));
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * M, c_->d_flag));
         }
+        int flag_pref = 0;
+        if (nd && pref) SP_HIP_CHECK(hipMemcpyAsync(&flag_pref, d_flag_side_ + 1, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         fe* comp2 = d_h12s_;                      // [2n] evaluations H(h w_2n^i), then [H1s | H2s]
         SP_TRY(evaluate(M, logb_ - logG_ - 1, binv, comp2));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
@@ -744,7 +819,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // and b_k h^k = c_(2k+1) h^k:  (2n)^-1 (h^-1 u^2)^k  and  (2n)^-1 (h^-1 u) (h^-1 u^2)^k,  u = w_N^-c0.
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, d_post_comp_));   // (tables: setup())
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
-        if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        if (flag | flag_pref) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
         h_full_ = false;
         SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else if (pair_path) {
@@ -808,6 +883,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(natural_to_coset_major(c_->stream, d_hnat_, N_, d_h12_, Nl_, 2, lde_order(), logG_, rank_));
         }
     }
+    bpre_valid_ = false;
     c_->proof_info[0] = (sub_coset || pair_path) ? 1u : (h_full_ ? 3u : 2u);
     c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && d_cstage_) ? 1u : 0u;
     SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
@@ -901,6 +977,7 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     if (stage_ != 4) { sp_set_error("ood: composition polynomial not committed"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     z_ = z;
+    SP_TRY(prefetch_deep_inverses());   // round 4's denominators depend on z only: side stream, beside the evaluations below
     // stored coefficients are c_k h^k, so evaluate at y / h (reference prover.rs:301-304, frame.rs:67-83)
     const uint32_t R = (uint32_t)offsets_.size();   // frame rows: z g^ofs for every transition offset (frame.rs:67-83)
     std::vector<fe> ys;
@@ -964,6 +1041,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     pts[R] = fe_sqr(z_);
     const uint32_t npts = R + 1;
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    bool used_pref = false;
     if (!h_full_) {
         // deg p0 <= n - 2 (every term is a quotient of a polynomial of degree < n by a linear factor), so p0 is fixed by
         // its values on ONE coset of n points: evaluate the quotient form there only (coset c0 = first coset this rank
@@ -982,8 +1060,14 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
             SP_TRY(ensure_deep_scratch((2ull * npts + 1) * n_));
             inv = d_deepx_; inv_scratch = inv + (uint64_t)npts * n_; p0n = inv + 2ull * npts * n_;
         }
-        SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
-        SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
+        if (deep_pref_ && d_deepx_ && deepx_cap_ >= (2ull * npts + 1) * n_) {   // computed beside round 3 (prefetch_deep_inverses)
+            inv = d_deepx_; p0n = inv + 2ull * npts * n_;
+            SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_deep_, 0));
+            used_pref = true;
+        } else {
+            SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
+            SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
+        }
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order(), R));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, d_post_deep_));   // n^-1 w_N^(-c0 j): setup()
@@ -1011,9 +1095,12 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     // FRI layer 0 (reference fri/mod.rs:27-33)
     fri_layer_ = 0;
     fri_offset_ = h_; fri_offset_inv_ = hinv_;
-    int flag = 0;
+    int flag = 0, flag_pref = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    if (used_pref) SP_HIP_CHECK(hipMemcpyAsync(&flag_pref, d_flag_side_, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    deep_pref_ = false;
     SP_TRY(commit_local(d_fri_evals_[0], 0, 1, fri_trees_[0].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[0], root0_out));   // synchronises
+    flag |= flag_pref;
     if (flag) { sp_set_error("deep composition: z lies on the LDE coset"); return SP_E_ZERO_INVERSE; }
     fri_layer_ = 1;
     stage_ = 6;
@@ -1338,6 +1425,8 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         uint8_t root[32];
         // ---- round 1 (reference prover.rs:187-224)
         SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+        if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
+            SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
         SP_TRY(P->commit_trace(0, main_trace, cols, root, trace_on_device));
         uint8_t main_root[32]; std::memcpy(main_root, root, 32);
         SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");

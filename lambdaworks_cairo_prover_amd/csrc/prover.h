@@ -155,6 +155,23 @@ class StarkProver : public sp_deletable {
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
     void* h_pin_ = nullptr;   // 4 KB of pinned host memory for readback()
+    // Side stream: latency-bound work that does not wait for the next challenge runs beside the compute stream instead of in
+    // its way - a batch inversion is one chain of ~260 dependent field products (~0.3 ms whatever the size).
+    //   * boundary denominators 1 / (x - g^step) of round 2 (shape and public inputs only): during round 1;
+    //   * DEEP denominators 1 / (x - z g^k), 1 / (x - z^2) of round 4 (known once z is sampled): during round 3;
+    //   * the range-check half of the Cairo auxiliary trace beside its memory half.
+    hipStream_t side_stream_ = nullptr;
+    hipEvent_t ev_side_fork_ = nullptr, ev_side_deep_ = nullptr, ev_side_bnd_ = nullptr, ev_side_aux_ = nullptr;
+    int* d_flag_side_ = nullptr;            // [2] zero-inverse flags of the two prefetches
+    int ensure_side();
+    int prefetch_deep_inverses();           // from ood(): z_ is set
+    bool deep_pref_ = false;
+    fe* d_bpre_ = nullptr; uint64_t bpre_cap_ = 0;   // [3][2n] boundary inverses + [3][2n] scratch
+    std::vector<fe> bpre_points_; bool bpre_valid_ = false;
+  public:
+    // round 2's boundary denominators ahead of time (whole-proof entry points call it before round 1; optional)
+    int prefetch_boundary_inverses(const std::vector<uint64_t>& steps);
+  private:
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
     AuxWorkspace auxws_{};

@@ -17,6 +17,9 @@ for it in range(2):
 dev = torch.from_numpy(tr).cuda(); torch.cuda.synchronize()
 for it in range(6):
     t0 = time.time(); p2 = ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt); t1 = time.time()
+    if os.environ.get("SP_BENCH_RESIDENT_ONLY"):   # (kernel traces of the resident path alone)
+        print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms, device rounds {['%.1f' % x for x in ctx.last_round_ms()]} ms", flush=True)
+        continue
     t2 = time.time(); p3 = ctx.cairo_prove(tr, run.public_inputs_c, opt); t3 = time.time()
     if it >= 3:
         print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms   from host buffer {1e3*(t3-t2):.1f} ms   (same bytes: {p2 == p3 == proof})", flush=True)
