@@ -1224,9 +1224,23 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
             hidx[t.ipos + s] = t.idx[s] & (t.t->sub_leaves - 1);
             if (t.du) hidx[t.iown + s] = t.idx[s] / t.t->sub_leaves;
         }
+    // one job table for every array (values, lower and upper tree parts), uploaded with the indices: one copy, one launch
+    std::vector<GatherJob> jobs;
+    uint32_t max_items = 0;
+    auto add_job = [&](const void* base, uint64_t stride_or_leaves, size_t idx_off, size_t out_off, size_t count, uint32_t width, uint32_t kind) {
+        if (count == 0 || width == 0) return;
+        jobs.push_back(GatherJob{base, stride_or_leaves, (uint64_t)idx_off, (uint64_t)out_off, (uint32_t)count, width, kind, 0u});
+        max_items = std::max<uint32_t>(max_items, (uint32_t)count * width);
+    };
+    for (auto& v : vj) add_job(v.base, v.stride, v.ipos, v.off, v.idx.size(), v.ncols, 0);
+    for (auto& t : tj) {
+        add_job(t.t->sub, t.t->sub_leaves, t.ipos, t.lower_off, t.idx.size(), t.dl, 1);
+        if (t.du) add_job(t.t->top, G_, t.iown, t.upper_off, t.idx.size(), t.du, 1);
+    }
     const size_t idx_bytes = (nidx * sizeof(uint64_t) + 255) & ~size_t(255);
+    const size_t job_bytes = (jobs.size() * sizeof(GatherJob) + 255) & ~size_t(255);
     const size_t blk_bytes = items * 32;
-    const size_t need = idx_bytes + blk_bytes * (G_ > 1 ? 1 + (size_t)world_ : 1);
+    const size_t need = idx_bytes + job_bytes + blk_bytes * (G_ > 1 ? 1 + (size_t)world_ : 1);
     struct Tmp { void* p = nullptr; ~Tmp() { if (p) (void)hipFree(p); } } tmp;   // many queries on a tiny domain: own staging buffer
     uint8_t* base = reinterpret_cast<uint8_t*>(d_scratch_);
     if (need > scratch_elems() * sizeof(fe)) {
@@ -1234,14 +1248,14 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
         base = static_cast<uint8_t*>(tmp.p);
     }
     uint64_t* d_idx = reinterpret_cast<uint64_t*>(base);
-    fe* blk = reinterpret_cast<fe*>(base + idx_bytes);
+    GatherJob* d_jobs = reinterpret_cast<GatherJob*>(base + idx_bytes);
+    fe* blk = reinterpret_cast<fe*>(base + idx_bytes + job_bytes);
     fe* all_dev = blk + items;
-    SP_HIP_CHECK(hipMemcpyAsync(d_idx, hidx.data(), nidx * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-    for (auto& v : vj) SP_TRY(gather_rows(st, v.base, v.stride, v.ncols, d_idx + v.ipos, (uint32_t)v.idx.size(), blk + v.off));
-    for (auto& t : tj) {
-        SP_TRY(merkle_gather_paths(st, t.t->sub, t.t->sub_leaves, d_idx + t.ipos, (uint32_t)t.idx.size(), reinterpret_cast<digest32*>(blk + t.lower_off)));
-        if (t.du) SP_TRY(merkle_gather_paths(st, t.t->top, G_, d_idx + t.iown, (uint32_t)t.idx.size(), reinterpret_cast<digest32*>(blk + t.upper_off)));
-    }
+    std::vector<uint8_t> up(idx_bytes + job_bytes, 0);
+    std::memcpy(up.data(), hidx.data(), nidx * sizeof(uint64_t));
+    std::memcpy(up.data() + idx_bytes, jobs.data(), jobs.size() * sizeof(GatherJob));
+    SP_HIP_CHECK(hipMemcpyAsync(base, up.data(), up.size(), hipMemcpyHostToDevice, st));
+    SP_TRY(gather_jobs(st, d_jobs, (uint32_t)jobs.size(), max_items, d_idx, blk));
     std::vector<fe> host(items * (G_ > 1 ? world_ : 1));
     if (G_ > 1) {
         SP_TRY(all_gather(blk, all_dev, blk_bytes));

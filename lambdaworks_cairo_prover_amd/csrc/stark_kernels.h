@@ -124,5 +124,11 @@ int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uin
 int natural_to_coset_major(hipStream_t st, const fe* src, uint64_t src_stride, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order,
                            uint32_t shard_log = 0, uint32_t shard_rank = 0);
 int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out);
+// Every gather of the query phase in ONE launch (fri/mod.rs:74-127, prover.rs:484-529 open ~45 arrays; a launch per array is
+// ~0.4 ms of submission latency per proof).  A job copies 32-byte items into the staging block:
+//   kind 0: rows   - item (r, j) = base[j * stride + idx[r]]           (count rows x width columns)
+//   kind 1: paths  - item (r, l) = sibling on level l of leaf idx[r]    (count leaves x width levels, lambdaworks node order)
+struct GatherJob { const void* base; uint64_t stride_or_leaves; uint64_t idx_off; uint64_t out_off; uint32_t count, width, kind, pad; };
+int gather_jobs(hipStream_t st, const GatherJob* jobs_dev, uint32_t njobs, uint32_t max_items, const uint64_t* idx_dev, fe* out);
 
 }  // namespace sp

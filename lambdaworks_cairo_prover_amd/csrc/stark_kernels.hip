@@ -479,6 +479,28 @@ int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32
     return SP_OK;
 }
 
+__global__ void __launch_bounds__(128) gather_jobs_kernel(const GatherJob* jobs, const uint64_t* idx, fe* out) {
+    const GatherJob jb = jobs[blockIdx.y];
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= jb.count * jb.width) return;
+    const uint32_t r = t / jb.width, j = t % jb.width;
+    const uint64_t at = idx[jb.idx_off + r];
+    if (jb.kind == 0) {
+        sk_st(out + jb.out_off + t, sk_ld(static_cast<const fe*>(jb.base) + (uint64_t)j * jb.stride_or_leaves + at));
+    } else {
+        uint64_t p = at + jb.stride_or_leaves - 1;
+        for (uint32_t k = 0; k < j; ++k) p = (p - 1) >> 1;
+        const uint64_t sib = (p & 1) ? p + 1 : p - 1;
+        sk_st(out + jb.out_off + t, sk_ld(static_cast<const fe*>(jb.base) + sib));
+    }
+}
+int gather_jobs(hipStream_t st, const GatherJob* jobs_dev, uint32_t njobs, uint32_t max_items, const uint64_t* idx_dev, fe* out) {
+    if (njobs == 0 || max_items == 0) return SP_OK;
+    hipLaunchKernelGGL(gather_jobs_kernel, dim3((max_items + 127) / 128, njobs), dim3(128), 0, st, jobs_dev, idx_dev, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 // dst column v [coset-major, the `len` evaluations this rank holds] = src column v [natural order, whole domain]: local
 // natural index l is the global index (l << shard_log) | shard_rank  (exceptional paths only)
 __global__ void __launch_bounds__(256) natural_to_coset_major_kernel(const fe* src, uint64_t src_stride, fe* dst, uint64_t len, LdeOrder ord,

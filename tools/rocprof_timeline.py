@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel timeline of the LAST proof in a rocprofv3 kernel trace (rocpd SQLite): start offset, duration, gap to the previous
 kernel, grid size, name.  A proof starts at its first aux_prepare_kernel... no: at the first kernel after the previous proof's
-last gather_paths_kernel.  usage: rocprof_timeline.py <kernel_trace.db> [which_proof_from_the_end=1]"""
+gather_jobs_kernel.  usage: rocprof_timeline.py <kernel_trace.db> [which_proof_from_the_end=1]"""
 import sqlite3
 import sys
 
@@ -10,7 +10,7 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rows = list(db.execute("select name,start,end,grid_x from kernels order by start"))
-    ends = [i for i, r in enumerate(rows) if "gather_paths_kernel" in r[0] and (i + 1 == len(rows) or "gather_paths_kernel" not in rows[i + 1][0])]
+    ends = [i for i, r in enumerate(rows) if "gather_jobs_kernel" in r[0]]
     if len(ends) < back + 1:
         print("not enough proofs in the trace")
         return
