@@ -19,8 +19,17 @@ int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint
 // Same, but the n_leaves digests go to a plain array (coset-sharded commitment: leaves are exchanged before the tree is built).
 int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out,
                             LdeOrder order = LdeOrder{0, 0, 0});
+// The Fiat-Shamir step that follows a FRI layer's commitment (fri/mod.rs:45-50: append the root, sample zeta), done by the
+// launch that produces the root so that the layers of the commit phase follow each other without a host round trip.
+// DefaultTranscript after a challenge holds the 32 reversed digest bytes r; append(root) makes it r || root, one 64-byte
+// Keccak block - the same shape as a node hash with "left" = r.  With d = Keccak256(r || root):  new state = reverse(d),
+// zeta = the 251 low bits of d read little-endian (transcript.rs:13-43).  All pointers are device memory:
+//   state[4]: r as four little-endian words (in/out);  mul_in: a Montgomery constant;  cst_out = zeta * mul_in (Montgomery);
+//   root_copy[4]: the root, for the host's own transcript afterwards.
+struct FriChallenge { uint64_t* state; const fe* mul_in; fe* cst_out; uint64_t* root_copy; };
 // Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
-int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves);
+// ch (nullable, n_leaves >= 2): see FriChallenge.
+int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch = nullptr);
 // Gather authentication paths: for each of `q` leaf positions, `depth` sibling digests bottom-up (lambdaworks
 // get_proof_by_pos) into out[q][depth].
 int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out);

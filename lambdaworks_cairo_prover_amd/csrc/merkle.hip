@@ -129,7 +129,7 @@ __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool 
 // level plus a launch boundary - so several levels per launch cost their Keccak latencies only; the slots that fall idle on
 // the way up were not needed anyway.  The digests of a level reach the next one through LDS (the copy in the node array is
 // written on the side: nobody in this launch reads it).  levels = 1: a plain level.  The last launch of a tree runs to the root.
-__global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, uint32_t count, uint32_t levels) {
+__global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, uint32_t count, uint32_t levels, FriChallenge ch) {
     __shared__ uint64_t lds[8 * 50];
     __shared__ uint64_t hand[2][8 * 4];
     __shared__ uint64_t rc[24];
@@ -157,7 +157,34 @@ __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, u
             a = keccak_f_lanes(a, l, lane_active, buf, rc);
             if (l < 4u) { words[p * 4 + l] = a; hand[lev & 1u][slot * 4 + l] = a; }
         }
-        if (lev + 1 >= levels || count == 1 || mine == 1) break;
+        if (lev + 1 >= levels || count == 1 || mine == 1) {
+            // the launch that reaches the root also takes the transcript step of the FRI commit phase (merkle.h, FriChallenge)
+            if (ch.state != nullptr && count == 1 && blockIdx.x == 0) {
+                __syncthreads();                        // hand[lev & 1][0..3] = the root
+                if (slot == 0) {
+                    uint64_t a = 0;
+                    if (l < 4u) a = ch.state[l];
+                    else if (l < 8u) a = hand[lev & 1u][l - 4u];
+                    else if (l == 8u) a = 0x01ULL;
+                    else if (l == 16u) a = 0x8000000000000000ULL;
+                    a = keccak_f_lanes(a, l, lane_active, buf, rc);
+                    uint64_t* d = hand[(lev + 1u) & 1u];
+                    if (l < 4u) { d[l] = a; ch.root_copy[l] = hand[lev & 1u][l]; }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    if (l < 4u) ch.state[l] = sp_bswap64(d[3u - l]);          // reverse(d) as little-endian words
+                    if (l == 0u) {
+                        fe z;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { z.v[2 * k] = (uint32_t)d[k]; z.v[2 * k + 1] = (uint32_t)(d[k] >> 32); }
+                        z.v[7] &= 0x07ffffffu;                                // 251 bits (transcript.rs:24-43): below p
+                        const fe c = fe_mul(fe_to_mont(z), *ch.mul_in);
+                        *ch.cst_out = c;
+                    }
+                }
+            }
+            break;
+        }
 #ifdef SP_MK_GLOBAL_HANDOFF
         __threadfence();
 #endif
@@ -193,7 +220,8 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
     return SP_OK;
 }
 
-int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
+int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch) {
+    if (ch && n_leaves < 2) return SP_E_INVALID_ARG;
     uint64_t count = n_leaves >> 1;
     for (; count > MK_LANES_MAX_NODES; count >>= 1) {
         unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
@@ -203,9 +231,11 @@ int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves) {
     // the upper levels, four per launch (8 -> 4 -> 2 -> 1 nodes per block)
     while (count >= 1) {
         const uint32_t levels = count >= 8 ? 4u : (count >= 4 ? 3u : (count >= 2 ? 2u : 1u));
-        hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, st, nodes, (uint32_t)count, levels);
+        const bool last = (count >> levels) == 0;
+        hipLaunchKernelGGL(node_hash_lanes_kernel, dim3((unsigned)((count + 7) / 8)), dim3(256), 0, st, nodes, (uint32_t)count, levels,
+                           (last && ch) ? *ch : FriChallenge{nullptr, nullptr, nullptr, nullptr});
         SP_HIP_CHECK(hipGetLastError());
-        if (count >> levels == 0) break;
+        if (last) break;
         count >>= levels;
     }
     return SP_OK;

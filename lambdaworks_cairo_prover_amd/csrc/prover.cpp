@@ -67,6 +67,7 @@ void StarkProver::free_all() {
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
+    d_fri_chain_ = nullptr; fri_chain_layers_ = 0;
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
@@ -1150,6 +1151,55 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
     return SP_OK;
 }
 
+int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value) {
+    if (!fri_chain_available() || fri_layer_ != 1) { sp_set_error("fri_commit_chain: layer 0 not committed, or a sharded prover"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    const fe* roots = nullptr;
+    SP_TRY(c_->ntt->roots((int)logN_, &roots));
+    const uint32_t L = logn_;
+    if (!d_fri_chain_ || fri_chain_layers_ < L) {
+        SP_TRY(alloc((void**)&d_fri_chain_, 32 + (size_t)L * 96));
+        fri_chain_layers_ = L;
+    }
+    uint64_t* d_state = reinterpret_cast<uint64_t*>(d_fri_chain_);
+    fe* d_cmul = reinterpret_cast<fe*>(d_fri_chain_ + 32);
+    fe* d_cst = d_cmul + L;
+    uint64_t* d_roots = reinterpret_cast<uint64_t*>(d_cst + L);
+    // constants half / offset_k of every layer (offset_k = h^(2^k)) and the transcript state, in one upload
+    std::vector<uint8_t> up(32 + (size_t)L * 32);
+    std::memcpy(up.data(), state32, 32);
+    fe oi = fri_offset_inv_;
+    for (uint32_t k = 0; k < L; ++k) { const fe c = fe_mul(half_, oi); std::memcpy(up.data() + 32 + (size_t)k * 32, &c, 32); oi = fe_sqr(oi); }
+    SP_HIP_CHECK(hipMemcpyAsync(d_fri_chain_, up.data(), up.size(), hipMemcpyHostToDevice, c_->stream));
+    const fe cst0 = fe_mul(fe_mul(zeta0, half_), fri_offset_inv_);
+    for (uint32_t k = 0; k < L; ++k) {            // fold layer k into layer k + 1 and commit it
+        const uint64_t M = N_ >> k;
+        SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, k == 0 ? nullptr : d_cst + k));
+        if (k + 1 < L) {
+            TreeBuf& t = fri_trees_[k + 1];
+            SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}));
+            const FriChallenge ch{d_state, d_cmul + (k + 1), d_cst + (k + 1), d_roots + 4 * (size_t)(k + 1)};
+            SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch));
+        }
+    }
+    for (uint32_t k = 0; k < L; ++k) { fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_); }
+    // roots of layers 1 .. L-1 and the b evaluations of the last fold (fri/mod.rs:58-67, see fri_fold_commit)
+    roots_out.assign(L - 1, std::array<uint8_t, 32>{});
+    if (L > 1) {
+        if ((size_t)(L - 1) * 32 > 4096) return SP_E_UNSUPPORTED;
+        SP_TRY(readback(roots_out.data(), d_roots + 4, (size_t)(L - 1) * 32));
+    }
+    const uint32_t bb = 1u << logb_;
+    std::vector<fe> ev(bb);
+    SP_TRY(readback(ev.data(), d_fri_evals_[L], sizeof(fe) * bb));
+    fe sum = fe_zero();
+    for (auto& e : ev) sum = fe_add(sum, e);
+    *last_value = fe_mul(sum, binv_);
+    fri_layer_ = L;
+    stage_ = 7;
+    return SP_OK;
+}
+
 int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out) {
     SP_HIP_CHECK(hipSetDevice(c_->device));
     // expected number of trials 2^factor: ranges of about that size, four queued per host round trip (a range that starts
@@ -1485,6 +1535,16 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         fri_roots.emplace_back(root, root + 32);
         tr.append(root, 32);
         fe last_value;
+        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
+            const fe zeta0 = tr.to_field();
+            std::vector<std::array<uint8_t, 32>> rest;
+            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
+            for (auto& r : rest) {
+                fri_roots.emplace_back(r.begin(), r.end());
+                tr.append(r.data(), 32);
+                (void)tr.to_field();      // zeta_k: the device sampled the same value
+            }
+        } else
         for (;;) {
             fe zeta = tr.to_field();
             int is_last = 0;
@@ -1614,6 +1674,16 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         fri_roots.emplace_back(root, root + 32);
         tr.append(root, 32);
         fe last_value;
+        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
+            const fe zeta0 = tr.to_field();
+            std::vector<std::array<uint8_t, 32>> rest;
+            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
+            for (auto& r : rest) {
+                fri_roots.emplace_back(r.begin(), r.end());
+                tr.append(r.data(), 32);
+                (void)tr.to_field();      // zeta_k: the device sampled the same value
+            }
+        } else
         for (;;) {
             fe zeta = tr.to_field();
             int is_last = 0;

@@ -6,6 +6,7 @@
 #include "cairo_air_host.h"
 #include "aux_kernels.h"
 #include <vector>
+#include <array>
 #include <algorithm>
 
 namespace sp {
@@ -59,6 +60,12 @@ class StarkProver : public sp_deletable {
     // round 4
     int deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::vector<fe>& trace_gammas /*[j*2+k]*/, uint8_t root0_out[32]);
     int fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_value, int* is_last);
+    // The whole commit phase after layer 0 without a host round trip per layer (one GPU): the launch that produces a layer's
+    // root also takes the transcript step (append root, sample zeta - merkle.h FriChallenge) and leaves zeta's fold constant
+    // in device memory for the next layer.  state32 = the transcript buffer after zeta_0 was sampled (32 bytes); roots_out =
+    // the roots of layers 1 .. L-1, which the caller feeds to its own transcript afterwards.
+    bool fri_chain_available() const { return G_ == 1 && stage_ == 6 && logn_ >= 2; }
+    int fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value);
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
     int open(const std::vector<uint64_t>& iotas, Openings& out);
 
@@ -154,6 +161,7 @@ class StarkProver : public sp_deletable {
     AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
+    uint8_t* d_fri_chain_ = nullptr; uint32_t fri_chain_layers_ = 0;   // [state 32 B][L x constants][L x zeta constants][L x roots]
     void* h_pin_ = nullptr;   // 4 KB of pinned host memory for readback()
     // Side stream: latency-bound work that does not wait for the next challenge runs beside the compute stream instead of in
     // its way - a batch inversion is one chain of ~260 dependent field products (~0.3 ms whatever the size).

@@ -112,7 +112,7 @@ int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, 
 // roots_N: half table of w_N; M = N >> layer. c = zeta / (2 * offset).
 // Sharded layer: M = the elements this rank holds, local index l = global index (l << shard_log) | shard_rank.
 int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
-             uint32_t shard_log = 0, uint32_t shard_rank = 0);
+             uint32_t shard_log = 0, uint32_t shard_rank = 0, const fe* c_dev = nullptr);   // c_dev (device, nullable) replaces c
 
 // generate_nonce_with_grinding (reference src/starks/grinding.rs:17-48): smallest nonce in [start, start+count) whose
 // Keccak256(challenge || nonce_le)[0..8] (BE) has >= factor trailing zeros; *result_dev = min(*result_dev, nonce).

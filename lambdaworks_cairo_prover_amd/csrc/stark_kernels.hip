@@ -416,9 +416,10 @@ struct FriArgs { fe half, c; };
 // Sharded layers: this rank holds the elements with global index i = (local << shard_log) | shard_rank; the partner
 // i + M/2 has the same residue, so the fold is local and only the twiddle exponent needs the global index.
 __global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, uint64_t Mh, uint32_t logN, uint32_t layer, const fe* roots, FriArgs a,
-                                                       uint32_t shard_log, uint32_t shard_rank) {
+                                                       uint32_t shard_log, uint32_t shard_rank, const fe* c_dev) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Mh) return;
+    if (c_dev) a.c = sk_ld(c_dev);   // zeta * half / offset left in device memory by the previous layer's root launch (merkle.h, FriChallenge)
     fe x = sk_ld(cur + i), y = sk_ld(cur + Mh + i);
     uint32_t Nm = (1u << logN) - 1;
     const uint32_t ig = ((uint32_t)i << shard_log) | shard_rank;
@@ -427,10 +428,10 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, 
     sk_st(next + i, a.half * (x + y) + a.c * (w * (x - y)));
 }
 int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
-             uint32_t shard_log, uint32_t shard_rank) {
+             uint32_t shard_log, uint32_t shard_rank, const fe* c_dev) {
     uint64_t Mh = M >> 1;   // M = elements this rank holds
     FriArgs a; a.half = half; a.c = c;
-    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a, shard_log, shard_rank);
+    hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a, shard_log, shard_rank, c_dev);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
