@@ -89,36 +89,49 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
 constexpr uint32_t MK_LANES_MAX_NODES = SP_MK_LANES_MAX_NODES;
 __device__ __constant__ const uint8_t SP_KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
-__device__ __forceinline__ uint64_t rotl64_var(uint64_t v, uint32_t n) { return (v << n) | (v >> ((64u - n) & 63u)); }
+// rotation by a per-lane amount with 32-bit funnel shifts (two 64-bit variable shifts and an or are three slow VALU ops):
+// swap = n >= 32 exchanges the halves, sh = (32 - n % 32) % 32 is the v_alignbit amount, keep = n % 32 == 0 leaves them as they are
+struct LaneRot { uint32_t sh; bool swap, keep; };
+__device__ __forceinline__ uint64_t rotl64_lane(uint64_t v, const LaneRot r) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    const uint32_t a = r.swap ? hi : lo, b = r.swap ? lo : hi;                   // {b, a} = v rotated by 0 or 32
+    const uint32_t rh = __builtin_amdgcn_alignbit(b, a, r.sh), rl = __builtin_amdgcn_alignbit(a, b, r.sh);
+    lo = r.keep ? a : rl; hi = r.keep ? b : rh;
+    return ((uint64_t)hi << 32) | lo;
+}
 
-// one permutation slot = 32 consecutive lanes (25 active); buf = 50 words of LDS owned by the slot; rc = the 24 round
-// constants in LDS (a scalar load per round would sit in the dependent chain)
+// one permutation slot = 32 consecutive lanes (25 active); buf = 64 words of LDS owned by the slot (A[32], B[32]: the seven
+// spare lanes run the same instructions on entries nobody reads, so a round is straight-line code); rc = the 24 round
+// constants in LDS (a scalar load per round would sit in the dependent chain; every lane reads the constant together with
+// its other operands and lane 0 alone uses it).
+// A slot is half a wave and the LDS serves the instructions of one wave in order: the reads of an exchange see the writes
+// issued before them without a wait in between (no fence: it would drain the queue, one more LDS round trip per exchange).
 __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool active, uint64_t* buf, const uint64_t* rc) {
-    const uint32_t x = l % 5u, y = l / 5u;
+    const uint32_t x = l % 5u, y = active ? l / 5u : 0u;
     uint64_t* A = buf;
-    uint64_t* B = buf + 25;
+    uint64_t* B = buf + 32;
     const uint32_t xm = (x + 4u) % 5u, xp = (x + 1u) % 5u, xpp = (x + 2u) % 5u;
     const uint32_t rho = active ? SP_KECCAK_RHO[l] : 0u;
-    const uint32_t dst = y + 5u * ((2u * x + 3u * y) % 5u);   // pi: B[y][2x + 3y] = rotl(A[x][y], rho[x][y])
+    const LaneRot rot{(32u - (rho & 31u)) & 31u, rho >= 32u, (rho & 31u) == 0u};
+    const uint32_t dst = active ? y + 5u * ((2u * x + 3u * y) % 5u) : l;   // pi: B[y][2x + 3y] = rotl(A[x][y], rho[x][y])
+    const uint64_t iota_mask = l == 0u ? ~0ULL : 0ULL;
+    const uint64_t* Am = A + xm;
+    const uint64_t* Ap = A + xp;
+    const uint64_t* B1 = B + xp + 5u * y;
+    const uint64_t* B2 = B + xpp + 5u * y;
 #pragma unroll 1
     for (int r = 0; r < 24; ++r) {
-        if (active) A[l] = a;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        A[l] = a;
         __builtin_amdgcn_wave_barrier();
-        uint64_t cm = 0, cp = 0;
-        if (active) {
+        const uint64_t rcv = rc[r] & iota_mask;
+        uint64_t m[5], q[5];
 #pragma unroll
-            for (uint32_t k = 0; k < 5; ++k) { cm ^= A[xm + 5u * k]; cp ^= A[xp + 5u * k]; }
-            const uint64_t t = rotl64_var(a ^ cm ^ rotl64_var(cp, 1), rho);
-            B[dst] = t;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (uint32_t k = 0; k < 5; ++k) { m[k] = Am[5u * k]; q[k] = Ap[5u * k]; }
+        const uint64_t cm = m[0] ^ m[1] ^ m[2] ^ m[3] ^ m[4], cp = q[0] ^ q[1] ^ q[2] ^ q[3] ^ q[4];
+        B[dst] = rotl64_lane(a ^ cm ^ sp_rotl64(cp, 1), rot);
         __builtin_amdgcn_wave_barrier();
-        if (active) {
-            const uint64_t b0 = B[l], b1 = B[xp + 5u * y], b2 = B[xpp + 5u * y];
-            a = b0 ^ (~b1 & b2);
-            if (l == 0) a ^= rc[r];
-        }
+        const uint64_t b0 = B[l], b1 = *B1, b2 = *B2;
+        a = sp_chi(b0, b1, b2) ^ rcv;
         __builtin_amdgcn_wave_barrier();
     }
     return a;
@@ -130,13 +143,13 @@ __device__ __forceinline__ uint64_t keccak_f_lanes(uint64_t a, uint32_t l, bool 
 // the way up were not needed anyway.  The digests of a level reach the next one through LDS (the copy in the node array is
 // written on the side: nobody in this launch reads it).  levels = 1: a plain level.  The last launch of a tree runs to the root.
 __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, uint32_t count, uint32_t levels, FriChallenge ch) {
-    __shared__ uint64_t lds[8 * 50];
+    __shared__ uint64_t lds[8 * 64];
     __shared__ uint64_t hand[2][8 * 4];
     __shared__ uint64_t rc[24];
     const uint32_t slots = blockDim.x >> 5;   // 8
     const uint32_t slot = threadIdx.x >> 5, l = threadIdx.x & 31u;
     const bool lane_active = l < 25u;
-    uint64_t* buf = lds + slot * 50;
+    uint64_t* buf = lds + slot * 64;
     uint64_t* words = reinterpret_cast<uint64_t*>(nodes);
     if (threadIdx.x < 24) rc[threadIdx.x] = SP_KECCAK_RC_DEV[threadIdx.x];
     __syncthreads();
