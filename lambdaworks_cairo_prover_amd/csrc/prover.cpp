@@ -934,33 +934,26 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
         }
         return SP_OK;
     }
-    // all power tables first (yp[level][p][t] = y_level^rev_l(t), y_(level+1) = y_level^(2^l)), one upload, no host
-    // synchronisation between the levels
+    // power tables yp[level][p][t] = y_level^rev_l(t), y_(level+1) = y_level^(2^l): the table of a level goes up right before its
+    // kernel, so the host computes the next level's table (~25 us) while the device runs this one; no synchronisation between levels
     std::vector<fe> yp(tab_elems, fe_zero());
+    std::vector<fe> pw(256);
     for (size_t lev = 0; lev < ls.size(); ++lev) {
         const uint32_t l = ls[lev], Tn = 1u << l;
         for (uint32_t p = 0; p < points; ++p) {
-            std::vector<fe> pw(Tn);
             pw[0] = fe_one();
             for (uint32_t e = 1; e < Tn; ++e) pw[e] = fe_mul(pw[e - 1], ycur[p]);
+            fe* dstp = &yp[lev * points * 256 + (size_t)p * Tn];   // compacted: the kernel indexes yp[p * T + t]
             for (uint32_t t = 0; t < Tn; ++t) {  // yp[t] = y^rev_l(t)
                 uint32_t r = 0;
                 for (uint32_t bit = 0; bit < l; ++bit) if ((t >> bit) & 1) r |= 1u << (l - 1 - bit);
-                yp[(lev * points + p) * 256 + t] = pw[r];
+                dstp[t] = pw[r];
             }
             fe y2 = ycur[p];
             for (uint32_t s = 0; s < l; ++s) y2 = fe_sqr(y2);
             ycur[p] = y2;
         }
-    }
-    SP_HIP_CHECK(hipMemcpyAsync(yp_dev, yp.data(), yp.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
-    // one compacted table per level: the kernel indexes yp[p * T + t]
-    for (size_t lev = 0; lev < ls.size(); ++lev) {
-        const uint32_t l = ls[lev], Tn = 1u << l;
-        if (Tn != 256)
-            for (uint32_t p = 1; p < points; ++p)
-                SP_HIP_CHECK(hipMemcpyAsync(yp_dev + lev * points * 256 + (size_t)p * Tn, yp_dev + (lev * points + p) * 256, sizeof(fe) * Tn,
-                                            hipMemcpyDeviceToDevice, c->stream));
+        SP_HIP_CHECK(hipMemcpyAsync(yp_dev + lev * points * 256, &yp[lev * points * 256], sizeof(fe) * points * Tn, hipMemcpyHostToDevice, c->stream));
         fe* outb = bufs[which];
         SP_TRY(fold_eval_level(c->stream, in, in_stride, in_points, M, l, yp_dev + lev * points * 256, points, vectors, outb));
         M >>= l;
