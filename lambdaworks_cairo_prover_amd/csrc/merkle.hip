@@ -159,12 +159,8 @@ __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, u
         if (slot < mine && i < count) {   // uniform per slot (32 lanes), slots never straddle a wave
             const uint64_t p = (uint64_t)(count - 1) + i;
             uint64_t a = 0;
-#ifdef SP_MK_GLOBAL_HANDOFF   // A/B: the round-2 form (children re-read from the node array behind a device-scope fence)
-            if (l < 8u) a = words[(2 * p + 1) * 4 + l];
-#else
             if (l < 8u) a = lev == 0 ? words[(2 * p + 1) * 4 + l]                       // left digest then right digest: 8 consecutive words
                                      : hand[(lev - 1) & 1u][(2 * slot) * 4 + l];         // = slots 2 slot, 2 slot + 1 of the level below
-#endif
             else if (l == 8u) a = 0x01ULL;                       // original Keccak padding of a 64-byte message
             else if (l == 16u) a = 0x8000000000000000ULL;
             a = keccak_f_lanes(a, l, lane_active, buf, rc);
@@ -198,9 +194,6 @@ __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, u
             }
             break;
         }
-#ifdef SP_MK_GLOBAL_HANDOFF
-        __threadfence();
-#endif
         __syncthreads();
         count >>= 1;
         mine >>= 1;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of compile-time Merkle variants on the GPU box (scratch copies of the tree, like sweep_ntt_variants.sh).
-# usage: tools/sweep_merkle_lanes.sh "<flags of variant 1>" ...   (an empty string = the default build)
+# usage: tools/sweep_merkle_lanes.sh "<flags of variant 1>" ...   (an empty string = the default build; e.g. -DSP_MK_LANES_MAX_NODES=8192)
 set -euo pipefail
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 export TMPDIR=/tmp
