@@ -30,8 +30,5 @@ struct FriChallenge { uint64_t* state; const fe* mul_in; fe* cst_out; uint64_t* 
 // Reduce the inner levels: nodes[i] = Keccak256(nodes[2i+1] || nodes[2i+2]) for i = n_leaves-2 .. 0.
 // ch (nullable, n_leaves >= 2): see FriChallenge.
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch = nullptr);
-// Gather authentication paths: for each of `q` leaf positions, `depth` sibling digests bottom-up (lambdaworks
-// get_proof_by_pos) into out[q][depth].
-int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out);
 
 }  // namespace sp

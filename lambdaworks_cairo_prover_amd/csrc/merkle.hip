@@ -200,16 +200,6 @@ __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, u
     }
 }
 
-__global__ void gather_paths_kernel(const digest32* nodes, uint64_t n_leaves, uint32_t depth, const uint64_t* positions, uint32_t q, digest32* out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= q * depth) return;
-    uint32_t qi = t / depth, lvl = t % depth;
-    uint64_t p = positions[qi] + n_leaves - 1;
-    for (uint32_t k = 0; k < lvl; ++k) p = (p - 1) >> 1;
-    uint64_t sib = (p & 1) ? p + 1 : p - 1;
-    out[(uint64_t)qi * depth + lvl] = nodes[sib];
-}
-
 int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes, LdeOrder order) {
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || ncols == 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
@@ -244,16 +234,6 @@ int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriC
         if (last) break;
         count >>= levels;
     }
-    return SP_OK;
-}
-
-int merkle_gather_paths(hipStream_t st, const digest32* nodes, uint64_t n_leaves, const uint64_t* positions_dev, uint32_t q, digest32* out) {
-    int depth = sp_log2_exact(n_leaves);
-    if (depth < 0) return SP_E_INVALID_ARG;
-    if (depth == 0 || q == 0) return SP_OK;
-    unsigned total = q * (unsigned)depth;
-    hipLaunchKernelGGL(gather_paths_kernel, dim3((total + 127) / 128), dim3(128), 0, st, nodes, n_leaves, (uint32_t)depth, positions_dev, q, out);
-    SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
 

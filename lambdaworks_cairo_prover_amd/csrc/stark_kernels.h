@@ -118,12 +118,11 @@ int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN,
 // Keccak256(challenge || nonce_le)[0..8] (BE) has >= factor trailing zeros; *result_dev = min(*result_dev, nonce).
 int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uint64_t start, uint64_t count, unsigned long long* result_dev);
 
-// out[r*cols + j] = cols_base[j*col_stride + rows[r]]
+
 // dst column v (coset-major order, the `len` evaluations this rank holds) = src column v (natural order of the whole domain,
 // columns at src_stride); local natural index l is the global index (l << shard_log) | shard_rank
 int natural_to_coset_major(hipStream_t st, const fe* src, uint64_t src_stride, fe* dst, uint64_t len, uint32_t ncols, LdeOrder order,
                            uint32_t shard_log = 0, uint32_t shard_rank = 0);
-int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out);
 // Every gather of the query phase in ONE launch (fri/mod.rs:74-127, prover.rs:484-529 open ~45 arrays; a launch per array is
 // ~0.4 ms of submission latency per proof).  A job copies 32-byte items into the staging block:
 //   kind 0: rows   - item (r, j) = base[j * stride + idx[r]]           (count rows x width columns)

@@ -466,20 +466,6 @@ int grind_range(hipStream_t st, const uint8_t challenge[32], uint8_t factor, uin
 }
 
 // ---------------------------------------------------------------------------------------------- gathers
-__global__ void gather_rows_kernel(const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows, uint32_t nrows, fe* out) {
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nrows * ncols) return;
-    uint32_t r = t / ncols, j = t % ncols;
-    sk_st(out + t, sk_ld(cols_base + (uint64_t)j * col_stride + rows[r]));
-}
-int gather_rows(hipStream_t st, const fe* cols_base, uint64_t col_stride, uint32_t ncols, const uint64_t* rows_dev, uint32_t nrows, fe* out) {
-    uint32_t total = nrows * ncols;
-    if (total == 0) return SP_OK;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((total + 127) / 128), dim3(128), 0, st, cols_base, col_stride, ncols, rows_dev, nrows, out);
-    SP_HIP_CHECK(hipGetLastError());
-    return SP_OK;
-}
-
 __global__ void __launch_bounds__(128) gather_jobs_kernel(const GatherJob* jobs, const uint64_t* idx, fe* out) {
     const GatherJob jb = jobs[blockIdx.y];
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
