@@ -53,7 +53,7 @@ int StarkProver::wait_stream() {
 }
 
 int StarkProver::readback(void* dst_host, const void* src_dev, size_t bytes) {
-    if (bytes > 4096) return SP_E_INVALID_ARG;
+    if (bytes > 4096) { sp_set_error("readback: more than the 4 KB pinned slot"); return SP_E_INVALID_ARG; }
     if (!h_pin_ && hipHostMalloc(&h_pin_, 4096, hipHostMallocDefault) != hipSuccess) { h_pin_ = nullptr; sp_set_error("pinned read-back slot: allocation failed"); return SP_E_ALLOC; }
     SP_HIP_CHECK(hipMemcpyAsync(h_pin_, src_dev, bytes, hipMemcpyDeviceToHost, c_->stream));
     SP_TRY(wait_stream());
@@ -67,7 +67,7 @@ void StarkProver::free_all() {
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
-    d_fri_chain_ = nullptr; fri_chain_layers_ = 0;
+    d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false;
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
@@ -111,7 +111,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
-        bpre_valid_ = false; deep_pref_ = false;
+        bpre_valid_ = false; deep_pref_ = false; check_pending_ = false;
         return SP_OK;
     }
     free_all();
@@ -561,6 +561,35 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     return commit_segment_resident(1, Ca_, root_out);
 }
 
+int StarkProver::composition_precheck(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, uint32_t n_transitions) {
+    check_pending_ = false;
+    if (stage_ != 3 && !(stage_ == 2 && Ca_ == 0)) { sp_set_error("composition_precheck: trace segments not committed"); return SP_E_STATE; }
+    const uint32_t B = (uint32_t)bcs.size();
+    if (n_transitions > CAIRO_MAX_TRANSITIONS || B > CAIRO_MAX_BOUNDARY) return SP_E_INVALID_ARG;
+    // the check only runs where composition_core would run it (2n-point paths)
+    const bool sub_coset = logb_ >= logG_ + 1, pair_path = !sub_coset && G_ > 1 && logb_ == logG_ && d_post_comp0_;
+    if (!sub_coset && !pair_path) return SP_OK;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    if (!d_comp_consts_chk_) SP_TRY(alloc((void**)&d_comp_consts_chk_, sizeof(CompositionConsts)));
+    if (!h_comp_chk_) h_comp_chk_.reset(new CompositionConsts());
+    CompositionConsts& K = *h_comp_chk_;
+    std::memset(&K, 0, sizeof(K));
+    for (uint32_t j = 0; j < B; ++j) {
+        if (bcs[j].col >= C_) return SP_E_INVALID_ARG;
+        K.bcol[j] = bcs[j].col; K.bvalue[j] = bcs[j].value; K.bstep[j] = bcs[j].step;
+    }
+    K.h = h_;
+    K.rap[0] = rap[0]; K.rap[1] = rap[1]; K.rap[2] = rap[2];
+    K.two = fe_from_u64(2);
+    K.b15 = fe_from_u64(1ULL << 15); K.b16 = fe_from_u64(1ULL << 16); K.b32 = fe_from_u64(1ULL << 32); K.b48 = fe_from_u64(1ULL << 48);
+    K.n_boundary = B; K.n_transitions = n_transitions; K.main_cols = Cm_; K.has_rc_builtin = has_rc_ ? 1 : 0;
+    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_chk_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_chk_, c_->d_flag));
+    check_pending_ = true;
+    return SP_OK;
+}
+
 int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
                              const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
                              const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint8_t root_out[32]) {
@@ -777,8 +806,10 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         return cairo_composition(c_->stream, d_lde_, count, Nl_, stride_log, logN_, logb_, roots, d_comp_consts_, binv, out, logG_, rank_);
     };
     SP_HIP_CHECK(hipSetDevice(c_->device));
+    const bool prechecked = check_pending_ && !prog_dev;   // composition_precheck queued the constraint check (and cleared the flag) already
+    check_pending_ = false;
     SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
-    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    if (!prechecked) SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     // A trace that satisfies its constraints gives deg H < 2n, and then 2n evaluations fix H.  Decide that EXACTLY by
     // checking the constraints on the trace itself (n rows, no divisions): clean -> evaluate the composition on the 2n
     // points of the cosets 0 and b/2 only; otherwise (the reference still proves such traces, with longer H1/H2) fall
@@ -790,13 +821,14 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     bool pair_path = allow_sub_coset && !sub_coset && G_ > 1 && logb_ == logG_ && d_post_comp0_;
     if (sub_coset || pair_path) {
         if (prog_dev) SP_TRY(air_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, prog_dev, c_->d_flag));
-        else SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
+        else if (!prechecked) SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
         sub_coset = sub_coset && flag == 0;
         pair_path = pair_path && flag == 0;
         SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     } else {
+        if (prechecked) SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));   // (unreachable today: same conditions)
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // K is a stack object
     }
     if (sub_coset) {
@@ -903,8 +935,10 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
 // sum_q A[q] y^rev(q) for `vectors` arrays of 2^k elements and `points` points, by repeated folding
 // (DESIGN.md "Out-of-domain evaluation"): one level maps M elements to M >> l.
 // scratch: at least 3 * 2^k elements (two ping-pong buffers and the per-level power tables).
+// after_first (nullable): host work to do once the first - long - level is queued (it runs beside that kernel).
 static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_t vectors, uint32_t k, const std::vector<fe>& ys,
-                       fe* scratch, uint64_t scratch_elems, std::vector<fe>& out /*[vectors][points]*/) {
+                       fe* scratch, uint64_t scratch_elems, std::vector<fe>& out /*[vectors][points]*/,
+                       const std::function<int()>* after_first = nullptr) {
     const uint32_t points = (uint32_t)ys.size();
     std::vector<fe> ycur = ys;
     const fe* in = arrays;
@@ -934,6 +968,7 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
     fe* yp_dev = scratch + 2 * level1;
     int which = 0;
     if (k == 0) {
+        if (after_first) SP_TRY((*after_first)());
         out.resize((size_t)vectors * points);
         for (uint32_t v = 0; v < vectors; ++v) {
             fe t;
@@ -964,6 +999,7 @@ static int eval_bitrev(sp_ctx* c, const fe* arrays, uint64_t vec_stride, uint32_
         SP_HIP_CHECK(hipMemcpyAsync(yp_dev + lev * points * 256, &yp[lev * points * 256], sizeof(fe) * points * Tn, hipMemcpyHostToDevice, c->stream));
         fe* outb = bufs[which];
         SP_TRY(fold_eval_level(c->stream, in, in_stride, in_points, M, l, yp_dev + lev * points * 256, points, vectors, outb));
+        if (lev == 0 && after_first) SP_TRY((*after_first)());
         M >>= l;
         in = outb; in_stride = (uint64_t)points * M; in_points = points;
         which ^= 1;
@@ -979,7 +1015,8 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
     if (stage_ != 4) { sp_set_error("ood: composition polynomial not committed"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     z_ = z;
-    SP_TRY(prefetch_deep_inverses());   // round 4's denominators depend on z only: side stream, beside the evaluations below
+    // round 4's denominators depend on z only: side stream, beside the evaluations below (queued once the first of them runs)
+    const std::function<int()> prefetch = [this]() { return prefetch_deep_inverses(); };
     // stored coefficients are c_k h^k, so evaluate at y / h (reference prover.rs:301-304, frame.rs:67-83)
     const uint32_t R = (uint32_t)offsets_.size();   // frame rows: z g^ofs for every transition offset (frame.rs:67-83)
     std::vector<fe> ys;
@@ -991,7 +1028,7 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
         const uint32_t cpr = (C_ + G_ - 1) / G_;
         auto first_col = [&](uint32_t role) { return std::min(role * cpr, C_ - cpr); };
         std::vector<fe> mine;
-        SP_TRY(eval_bitrev(c_, d_coeffs_ + (uint64_t)first_col(rank_) * n_, n_, cpr, logn_, ys, d_scratch_, scratch_elems(), mine));
+        SP_TRY(eval_bitrev(c_, d_coeffs_ + (uint64_t)first_col(rank_) * n_, n_, cpr, logn_, ys, d_scratch_, scratch_elems(), mine, &prefetch));
         const size_t blk = (size_t)cpr * R;
         if (!d_small_) SP_TRY(alloc((void**)&d_small_, sizeof(fe) * (1 + (size_t)world_) * 64 * AIR_MAX_OFFSETS));
         SP_HIP_CHECK(hipMemcpyAsync(d_small_, mine.data(), blk * sizeof(fe), hipMemcpyHostToDevice, c_->stream));
@@ -1002,7 +1039,7 @@ int StarkProver::ood(const fe& z, fe* h1_z2, fe* h2_z2, std::vector<fe>& trace_o
         for (uint32_t role = 0; role < G_; ++role)
             std::copy(all.begin() + (size_t)role * blk, all.begin() + (size_t)(role + 1) * blk, tr.begin() + (size_t)first_col(role) * R);
     } else {
-        SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, scratch_elems(), tr));
+        SP_TRY(eval_bitrev(c_, d_coeffs_, n_, C_, logn_, ys, d_scratch_, scratch_elems(), tr, &prefetch));
     }
     trace_ood.resize((size_t)R * C_);
     for (uint32_t j = 0; j < C_; ++j)
@@ -1505,6 +1542,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         // ---- round 2 (reference prover.rs:597-635)
         std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
         const uint32_t T = air.num_transition_constraints;
+        SP_TRY(P->composition_precheck(rap, bcs, T));   // runs while the challenges below are sampled
         std::vector<fe> b_alpha(bcs.size()), b_beta(bcs.size()), t_alpha(T), t_beta(T);
         for (auto& x : b_alpha) x = tr.to_field();
         for (auto& x : b_beta) x = tr.to_field();

@@ -6,6 +6,7 @@
 #include "cairo_air_host.h"
 #include "aux_kernels.h"
 #include <vector>
+#include <memory>
 #include <array>
 #include <algorithm>
 
@@ -51,6 +52,10 @@ class StarkProver : public sp_deletable {
     int composition(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, const std::vector<fe>& b_alpha,
                     const std::vector<fe>& b_beta, const std::vector<fe>& t_alpha, const std::vector<fe>& t_beta,
                     const std::vector<uint32_t>& degrees, const std::vector<uint32_t>& exemptions, uint8_t root_out[32]);
+    // Optional, before composition() of the Cairo AIR: the exact constraint check on the trace (what decides between the 2n-point
+    // and the whole-domain evaluation) needs the RAP challenges and the boundary constraints but none of the alpha / beta
+    // coefficients - queued here it runs while the caller samples those ~110 challenges and composition() builds its tables.
+    int composition_precheck(const fe rap[3], const std::vector<BoundaryConstraint>& bcs, uint32_t n_transitions);
     // round 2 for an AIR given as a constraint program (reference traits.rs:15-119 + evaluator.rs:38-260); rap = its RAP
     // challenges (appended to the program's constants); also sets the frame offsets used by rounds 3 and 4.
     int composition_air(const AirDescHost& air, const std::vector<fe>& rap, const std::vector<fe>& b_alpha, const std::vector<fe>& b_beta,
@@ -158,6 +163,9 @@ class StarkProver : public sp_deletable {
     fe fri_offset_, fri_offset_inv_;        // h^(2^layer) and its inverse
     fe half_, binv_;                        // 1/2, 1/blowup
     CompositionConsts* d_comp_consts_ = nullptr;
+    CompositionConsts* d_comp_consts_chk_ = nullptr;   // the constants of an early constraint check (composition_precheck)
+    std::unique_ptr<CompositionConsts> h_comp_chk_;    // its host copy (stays put until the upload has happened)
+    bool check_pending_ = false;
     AirProgram* d_air_prog_ = nullptr; fe* d_ex_roots_ = nullptr; uint32_t ex_roots_cap_ = 0;
     DeepConsts* d_deep_consts_ = nullptr;
     unsigned long long* d_nonce_ = nullptr;
