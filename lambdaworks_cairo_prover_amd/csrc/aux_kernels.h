@@ -40,7 +40,14 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
 // product) is queued there - two chains of dependent latencies (a batch inversion each) side by side instead of in a row.
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
                            uint64_t pm, const fe rap[3], fe* aux_cols_out, int* flag_dev, hipStream_t side = nullptr,
-                           hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+                           hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr, bool presorted = false);
+
+// The part of the auxiliary trace that needs no challenge, for a stream of its own while round 1 extends and hashes the main
+// trace: public-memory substitution, the stable sort of the 4n accesses by address with the gather of the sorted (address,
+// value) pairs, and the sort of the 3n offsets.  A later cairo_aux_trace_device(..., presorted = true) on the same workspace
+// starts from there.  *flag_dev is set on malformed input like there.
+int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
+                      uint64_t pm, int* flag_dev);
 
 // In-place inclusive prefix product of M elements (block_tot: workspace of >= M/2048 + 2 elements).
 int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot);

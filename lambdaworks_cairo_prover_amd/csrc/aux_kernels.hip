@@ -53,6 +53,43 @@ __global__ void __launch_bounds__(256) aux_gather_kernel(const fe* a_aux, const 
     ax_st(den + e, fe_sub(K.z, fe_add(a, fe_mul(K.alpha, v))));
 }
 
+// ---- the same two steps split at the challenges: keys / sorted pairs first (cairo_aux_presort), numerators and
+// denominators once alpha and z are known
+__global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint64_t n, const fe* pm_addr, const fe* pm_val, uint64_t pm,
+                                                       fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag) {
+    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= 4 * n) return;
+    uint64_t i = e >> 2; uint32_t k = (uint32_t)e & 3;
+    fe a, v;
+    if (e >= 4 * n - pm) {  // last |pm| accesses are replaced by the public memory (air.rs:475-494)
+        uint64_t j = e - (4 * n - pm);
+        a = ax_ld(pm_addr + j); v = ax_ld(pm_val + j);
+    } else {
+        a = ax_ld(mem_cols + (uint64_t)k * n + i);
+        v = ax_ld(mem_cols + (uint64_t)(4 + k) * n + i);
+    }
+    ax_st(a_aux + e, a); ax_st(v_aux + e, v);
+    fe raw = fe_from_mont(a);
+    if (raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 2);
+    keys[e] = (uint64_t)raw.v[0] | ((uint64_t)raw.v[1] << 32);
+    idx[e] = (uint32_t)e;
+}
+__global__ void __launch_bounds__(256) aux_gather_pairs_kernel(const fe* a_aux, const fe* v_aux, const uint32_t* idx, uint64_t M, fe* a_s, fe* v_s) {
+    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M) return;
+    uint32_t s = idx[e];
+    ax_st(a_s + e, ax_ld(a_aux + s)); ax_st(v_s + e, ax_ld(v_aux + s));
+}
+// num[e] = z - (a + alpha v) of the ORIGINAL access e (air.rs:543-550), den[e] = the same of the sorted pair e
+__global__ void __launch_bounds__(256) aux_num_den_kernel(const fe* mem_cols, uint64_t n, const fe* a_s, const fe* v_s, AuxConsts K, fe* num, fe* den) {
+    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= 4 * n) return;
+    uint64_t i = e >> 2; uint32_t k = (uint32_t)e & 3;
+    const fe a = ax_ld(mem_cols + (uint64_t)k * n + i), v = ax_ld(mem_cols + (uint64_t)(4 + k) * n + i);
+    ax_st(num + e, fe_sub(K.z, fe_add(a, fe_mul(K.alpha, v))));
+    ax_st(den + e, fe_sub(K.z, fe_add(ax_ld(a_s + e), fe_mul(K.alpha, ax_ld(v_s + e)))));
+}
+
 __global__ void __launch_bounds__(256) mul_inplace_kernel(fe* x, const fe* y, uint64_t M) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= M) return;
@@ -225,8 +262,28 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
     w.n = n; w.pm_cap = pm_cap;
 }
 
+int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
+                      uint64_t pm, int* flag) {
+    if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
+    const uint64_t M = 4 * n, M3 = 3 * n;
+    auto blocks = [](uint64_t x) { return dim3((unsigned)((x + 255) / 256)); };
+    if (pm) {
+        SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
+        SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(aux_keys_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag);
+    size_t tmp = w.sort_tmp_bytes;
+    SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, 64, st));
+    hipLaunchKernelGGL(aux_gather_pairs_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
+    hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
+    size_t tmp2 = w.sort_tmp_bytes;
+    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, st));
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                           uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join) {
+                           uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool presorted) {
     if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
     AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
     const uint64_t M = 4 * n, M3 = 3 * n;
@@ -237,24 +294,30 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
         SP_HIP_CHECK(hipEventRecord(ev_fork, st));   // the trace columns and the cleared flag are behind this point
         SP_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
     }
-    if (pm) {
-        SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
-        SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
+    if (presorted) {   // cairo_aux_presort left the sorted pairs (and the sorted offsets) in the workspace
+        hipLaunchKernelGGL(aux_num_den_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.a_s, w.v_s, K, w.num, w.den);
+    } else {
+        if (pm) {
+            SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
+            SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
+        }
+        // memory: substitute, sort (stable, by address), permutation column
+        hipLaunchKernelGGL(aux_prepare_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, K, w.a_aux, w.v_aux, w.num,
+                           w.keys_in, w.idx_in, flag);
+        size_t tmp = w.sort_tmp_bytes;
+        SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, 64, st));
+        hipLaunchKernelGGL(aux_gather_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, K, w.a_s, w.v_s, w.den);
     }
-    // memory: substitute, sort (stable, by address), permutation column
-    hipLaunchKernelGGL(aux_prepare_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, K, w.a_aux, w.v_aux, w.num,
-                       w.keys_in, w.idx_in, flag);
-    size_t tmp = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, 64, st));
-    hipLaunchKernelGGL(aux_gather_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, K, w.a_s, w.v_s, w.den);
     SP_TRY(batch_inverse(st, w.den, w.inv_scratch, M, flag));
     hipLaunchKernelGGL(mul_inplace_kernel, blocks(M), dim3(256), 0, st, w.num, w.den, M);
     SP_TRY(prefix_product(st, w.num, M, w.block_tot));
     // range check: counting sort of the 3n 16-bit offsets, permutation column
     const fe* off_cols = mem_cols + 8 * n;
-    hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_keys, flag);
-    size_t tmp2 = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, rs));
+    if (!presorted) {
+        hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_keys, flag);
+        size_t tmp2 = w.sort_tmp_bytes;
+        SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, rs));
+    }
     hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, rs, w.rc_den, K);
     SP_TRY(batch_inverse(rs, w.rc_den, w.rc_den_scratch, 65536, flag));
     hipLaunchKernelGGL(rc_terms_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);

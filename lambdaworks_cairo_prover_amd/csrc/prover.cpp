@@ -36,13 +36,13 @@ StarkProver::~StarkProver() {
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
-    for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
 }
 
 int StarkProver::ensure_side() {
     if (!side_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&ev_side_fork_, &ev_side_deep_, &ev_side_bnd_, &ev_side_aux_})
+    for (hipEvent_t* e : {&ev_side_fork_, &ev_side_deep_, &ev_side_bnd_, &ev_side_aux_, &ev_side_presort_})
         if (!*e) SP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SP_OK;
 }
@@ -67,7 +67,7 @@ void StarkProver::free_all() {
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
-    d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false;
+    d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     stage_bytes_ = 0;
     for (void* p : allocs_) (void)hipFree(p);
@@ -111,7 +111,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
-        bpre_valid_ = false; deep_pref_ = false; check_pending_ = false;
+        bpre_valid_ = false; deep_pref_ = false; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
         return SP_OK;
     }
     free_all();
@@ -226,7 +226,7 @@ int StarkProver::prefetch_deep_inverses() {
     const uint32_t R = (uint32_t)offsets_.size(), npts = R + 1;
     SP_TRY(ensure_side());
     SP_TRY(ensure_deep_scratch((2ull * npts + 1) * n_));
-    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 2 * sizeof(int)));
+    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 4 * sizeof(int)));
     fe pts[AIR_MAX_OFFSETS + 1];
     for (uint32_t k = 0; k < R; ++k) pts[k] = fe_mul(z_, fe_pow_u64(g_, offsets_[k]));
     pts[R] = fe_sqr(z_);
@@ -255,7 +255,7 @@ int StarkProver::prefetch_boundary_inverses(const std::vector<uint64_t>& steps_i
     SP_TRY(ensure_side());
     const uint64_t M = 2 * n_;
     if (bpre_cap_ < 6 * M) { SP_TRY(alloc((void**)&d_bpre_, sizeof(fe) * 6 * M)); bpre_cap_ = 6 * M; }
-    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 2 * sizeof(int)));
+    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 4 * sizeof(int)));
     bpre_points_.clear();
     for (uint64_t s : steps) bpre_points_.push_back(fe_pow_u64(g_, s));
     const fe* roots_m = nullptr;
@@ -358,6 +358,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         SP_HIP_CHECK(hipMemcpyAsync(raw, rows_host, (size_t)n_ * cols * 32, hipMemcpyHostToDevice, c_->stream));
         SP_TRY(rows_to_columns(c_->stream, c_->enc, raw, n_, cols, trace, n_));
     }
+    if (segment == 0) SP_TRY(launch_aux_presort());
     return commit_segment_resident(segment, cols, root_out);
 }
 
@@ -482,6 +483,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
         SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
     }
+    if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
     return SP_OK;
@@ -516,47 +518,81 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     return SP_OK;
 }
 
+// get_pub_memory_addrs (reference cairo/air.rs:500-517) and the matching values -> pm_addr_h_, pm_val_h_
+int StarkProver::public_memory_lists(const PublicInputs& pub) {
+    const uint64_t pm = pub.public_memory.size();
+    pm_addr_h_.clear(); pm_val_h_.clear();
+    std::vector<uint64_t> addrs;
+    if (const MemorySegment* out = pub.segment(1)) {
+        if (out->end < out->start || out->end - out->start > pm) { sp_set_error("commit_aux_cairo: output segment larger than the public memory"); return SP_E_INVALID_ARG; }
+        uint64_t output_section = out->end - out->start, program_section = pm - output_section;
+        for (uint64_t i = 1; i <= program_section; ++i) addrs.push_back(i);
+        for (uint64_t a = out->start; a < out->end; ++a) addrs.push_back(a);
+    } else {
+        for (uint64_t i = 1; i <= pm; ++i) addrs.push_back(i);
+    }
+    std::unordered_map<uint64_t, const fe*> by_addr;   // the reference keeps the public memory in a HashMap (cairo/air.rs:163-181)
+    by_addr.reserve(pub.public_memory.size() * 2);
+    for (auto& kv : pub.public_memory) by_addr.emplace(kv.first, &kv.second);   // first entry of an address wins, as the linear scan did
+    for (uint64_t a : addrs) {
+        auto it = by_addr.find(a);
+        if (it == by_addr.end()) { sp_set_error("commit_aux_cairo: public memory address missing"); return SP_E_INVALID_ARG; }
+        pm_addr_h_.push_back(fe_from_u64(a)); pm_val_h_.push_back(*it->second);
+    }
+    return SP_OK;
+}
+
+int StarkProver::ensure_aux_workspace(uint64_t pm) {
+    if (d_auxws_ && pm <= auxws_pm_cap_) return SP_OK;
+    size_t sort_tmp = 0;
+    uint64_t cap = std::max<uint64_t>(pm, 1024);
+    size_t bytes = aux_workspace_bytes(n_, cap, &sort_tmp);
+    void* base = nullptr;
+    SP_TRY(alloc(&base, bytes));  // an outgrown workspace stays in allocs_ until the next reshaping setup()
+    d_auxws_ = base; auxws_bytes_ = bytes; auxws_pm_cap_ = cap;
+    aux_workspace_carve(auxws_, base, n_, cap, sort_tmp);
+    return SP_OK;
+}
+
+// The sorts of the auxiliary trace need the main trace and the public memory but no challenge: side stream, from the moment
+// the natural-order main columns are queued on the compute stream (request_aux_presort + commit_trace(0, ..)).
+int StarkProver::launch_aux_presort() {
+    const PublicInputs* pub = presort_pub_;
+    presort_pub_ = nullptr; presorted_ = false;
+    if (!pub || Ca_ != 18 || Cm_ < 34) return SP_OK;
+    SP_TRY(public_memory_lists(*pub));
+    const uint64_t pm = pm_addr_h_.size();
+    SP_TRY(ensure_aux_workspace(pm));
+    SP_TRY(ensure_side());
+    if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 4 * sizeof(int)));
+    SP_HIP_CHECK(hipEventRecord(ev_side_fork_, c_->stream));          // the main trace columns are behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
+    SP_HIP_CHECK(hipMemsetAsync(d_flag_side_ + 2, 0, sizeof(int), side_stream_));
+    SP_TRY(cairo_aux_presort(side_stream_, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, d_flag_side_ + 2));
+    SP_HIP_CHECK(hipEventRecord(ev_side_presort_, side_stream_));
+    presorted_ = true;
+    return SP_OK;
+}
+
 int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]) {
     if (stage_ != 2 || Ca_ != 18 || Cm_ < 34) { sp_set_error("commit_aux_cairo: main segment not committed or not a Cairo layout"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
-    const uint64_t pm = pub.public_memory.size();
-    if (!d_auxws_ || pm > auxws_pm_cap_) {
-        size_t sort_tmp = 0;
-        uint64_t cap = std::max<uint64_t>(pm, 1024);
-        size_t bytes = aux_workspace_bytes(n_, cap, &sort_tmp);
-        void* base = nullptr;
-        SP_TRY(alloc(&base, bytes));  // an outgrown workspace stays in allocs_ until the next reshaping setup()
-        d_auxws_ = base; auxws_bytes_ = bytes; auxws_pm_cap_ = cap;
-        aux_workspace_carve(auxws_, base, n_, cap, sort_tmp);
-    }
-    // get_pub_memory_addrs (reference cairo/air.rs:500-517) and the matching values
-    std::vector<fe> pa, pv;
-    {
-        std::vector<uint64_t> addrs;
-        if (const MemorySegment* out = pub.segment(1)) {
-            if (out->end < out->start || out->end - out->start > pm) { sp_set_error("commit_aux_cairo: output segment larger than the public memory"); return SP_E_INVALID_ARG; }
-            uint64_t output_section = out->end - out->start, program_section = pm - output_section;
-            for (uint64_t i = 1; i <= program_section; ++i) addrs.push_back(i);
-            for (uint64_t a = out->start; a < out->end; ++a) addrs.push_back(a);
-        } else {
-            for (uint64_t i = 1; i <= pm; ++i) addrs.push_back(i);
-        }
-        std::unordered_map<uint64_t, const fe*> by_addr;   // the reference keeps the public memory in a HashMap (cairo/air.rs:163-181)
-        by_addr.reserve(pub.public_memory.size() * 2);
-        for (auto& kv : pub.public_memory) by_addr.emplace(kv.first, &kv.second);   // first entry of an address wins, as the linear scan did
-        for (uint64_t a : addrs) {
-            auto it = by_addr.find(a);
-            if (it == by_addr.end()) { sp_set_error("commit_aux_cairo: public memory address missing"); return SP_E_INVALID_ARG; }
-            pa.push_back(fe_from_u64(a)); pv.push_back(*it->second);
-        }
-    }
+    const bool pre = presorted_;
+    presorted_ = false;
+    if (!pre) SP_TRY(public_memory_lists(pub));     // (the presort built them from the same public inputs)
+    const uint64_t pm = pm_addr_h_.size();
+    if (pm != pub.public_memory.size()) { sp_set_error("commit_aux_cairo: public memory changed since the presort"); return SP_E_STATE; }
+    SP_TRY(ensure_aux_workspace(pm));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    if (pre) SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_presort_, 0));
     SP_TRY(ensure_side());
-    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pa.data(), pv.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag,
-                                  side_stream_, ev_side_fork_, ev_side_aux_));
-    int flag = 0;
+    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, rap, d_trace_ + (uint64_t)Cm_ * n_, c_->d_flag,
+                                  side_stream_, ev_side_fork_, ev_side_aux_, pre));
+    int flag = 0, flag_pre = 0;
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // pa / pv are locals; flag
+    if (pre) SP_HIP_CHECK(hipMemcpyAsync(&flag_pre, d_flag_side_ + 2, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // flags
+    if (!flag) flag = flag_pre;
     if (flag) { sp_set_error("commit_aux_cairo: malformed trace (address >= 2^64, offset >= 2^16 or zero permutation denominator)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
     return commit_segment_resident(1, Ca_, root_out);
 }
@@ -1527,6 +1563,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         uint8_t root[32];
         // ---- round 1 (reference prover.rs:187-224)
         SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+        P->request_aux_presort(pub);                    // the sorts of the auxiliary trace: beside round 1 too
         if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
             SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
         SP_TRY(P->commit_trace(0, main_trace, cols, root, trace_on_device));

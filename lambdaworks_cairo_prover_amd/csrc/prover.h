@@ -178,15 +178,24 @@ class StarkProver : public sp_deletable {
     //   * the range-check half of the Cairo auxiliary trace beside its memory half.
     hipStream_t side_stream_ = nullptr;
     hipEvent_t ev_side_fork_ = nullptr, ev_side_deep_ = nullptr, ev_side_bnd_ = nullptr, ev_side_aux_ = nullptr;
-    int* d_flag_side_ = nullptr;            // [2] zero-inverse flags of the two prefetches
+    int* d_flag_side_ = nullptr;            // [4] flags of the side-stream work: DEEP inverses, boundary inverses, presort
     int ensure_side();
     int prefetch_deep_inverses();           // from ood(): z_ is set
     bool deep_pref_ = false;
     fe* d_bpre_ = nullptr; uint64_t bpre_cap_ = 0;   // [3][2n] boundary inverses + [3][2n] scratch
     std::vector<fe> bpre_points_; bool bpre_valid_ = false;
+    // the challenge-free part of the Cairo auxiliary trace (sorts) beside round 1's transforms and hashing
+    const PublicInputs* presort_pub_ = nullptr; bool presorted_ = false;
+    hipEvent_t ev_side_presort_ = nullptr;
+    std::vector<fe> pm_addr_h_, pm_val_h_;  // get_pub_memory_addrs and the matching values (host copies behind the async uploads)
+    int public_memory_lists(const PublicInputs& pub);
+    int ensure_aux_workspace(uint64_t pm);
+    int launch_aux_presort();               // from commit_trace(0, ..) once the main trace columns are queued
   public:
     // round 2's boundary denominators ahead of time (whole-proof entry points call it before round 1; optional)
     int prefetch_boundary_inverses(const std::vector<uint64_t>& steps);
+    // optional, before commit_trace(0, ..) of a Cairo proof: sort the memory accesses and the offsets while round 1 runs
+    void request_aux_presort(const PublicInputs& pub) { presort_pub_ = &pub; }
   private:
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;
