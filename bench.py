@@ -39,11 +39,19 @@ MAD_ISSUE_NS = 2.299
 MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
 VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_ntt22_traffic.json")
+MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_merkle_traffic.json")
 
 
 def ntt_source_sha16():
     h = hashlib.sha256()
     for f in ("ntt.hip", "ntt.h", "fp.h"):
+        h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def merkle_source_sha16():
+    h = hashlib.sha256()
+    for f in ("merkle.hip", "merkle.h", "keccak.h", "fp.h"):
         h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -118,7 +126,18 @@ def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
     perms = n * ((32 * cols + 1 + 135) // 136) + (n - 1)
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     del data, nodes
-    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+    traffic, note = None, "no PMC profile committed"
+    try:   # HBM-side bytes per build from the committed PMC passes, valid only for the kernel sources they were taken from
+        tj = json.load(open(MERKLE_TRAFFIC_FILE))
+        if log_leaves == 23 and cols == 34:
+            if tj.get("merkle_source_sha16") == merkle_source_sha16():
+                traffic, note = tj["traffic_bytes_per_build"], os.path.relpath(MERKLE_TRAFFIC_FILE, ROOT)
+            else:
+                note = f"stale: {os.path.relpath(MERKLE_TRAFFIC_FILE, ROOT)} was taken from other kernel sources ({tj.get('traffic_bytes_per_build')} B)"
+    except Exception:
+        pass
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": note, "algorithmic_bytes": algo_bytes,
             "kernel": "leaf_hash_kernel + node_hash levels of one batched Merkle build", "avg_launch_ms": ms,
             "workload": f"2^{log_leaves} leaves x {cols} field elements (configs[2] main-trace commitment)",
             "keccak_f_per_s": perms / (ms * 1e-3), "valu_ceiling_keccak_f_per_s": VALU_KECCAK_CEILING,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """HBM traffic per NTT from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as
 /opt/skills/guides/MI355X_MICROARCH.md prescribes) -> profiles/<name>.json, the file bench.py reads for roofline.traffic.
-usage: pmc_traffic.py <fetch_results.db> <write_results.db> <log_n> <out.json>"""
+usage: pmc_traffic.py <fetch_results.db> <write_results.db> <log_n> <out.json> [<merkle_out.json>]"""
 import hashlib
 import json
 import os
@@ -15,6 +15,13 @@ def ntt_source_sha16():
     """Same digest as bench.py: the traffic figure is only valid for the kernel sources it was measured on."""
     h = hashlib.sha256()
     for f in ("ntt.hip", "ntt.h", "fp.h"):
+        h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def merkle_source_sha16():
+    h = hashlib.sha256()
+    for f in ("merkle.hip", "merkle.h", "keccak.h", "fp.h"):
         h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -50,6 +57,21 @@ def main():
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
+    # the Merkle leg of the same bench.py run (roofline_merkle: one batched build of 2^23 leaves x 34 elements): every build
+    # launches the leaf kernel once, so builds = launches of the leaf kernel; all hash kernels of the run belong to that leg
+    if len(sys.argv) > 5:
+        leaf = [k for k in f if "leaf_hash" in k]
+        if leaf:
+            builds_f = sum(f[k][0] for k in leaf)
+            builds_w = sum(w[k][0] for k in leaf if k in w) or builds_f
+            fetch_kb = sum(t for k, (_, t) in f.items() if "hash" in k) / builds_f
+            write_kb = sum(t for k, (_, t) in w.items() if "hash" in k) / builds_w
+            m = {"source": res["source"] + " (its Merkle leg)", "workload": "2^23 leaves x 34 field elements",
+                 "fetch_size_kb_per_build": fetch_kb, "write_size_kb_per_build": write_kb, "merkle_source_sha16": merkle_source_sha16(),
+                 "correction": "FETCH_SIZE x 2, WRITE_SIZE x 1 (profiles/r02_fetch_calibration.txt)",
+                 "traffic_bytes_per_build": (2 * fetch_kb + write_kb) * 1024}
+            json.dump(m, open(sys.argv[5], "w"), indent=1)
+            print(json.dumps(m, indent=1))
 
 
 if __name__ == "__main__":
