@@ -13,5 +13,6 @@ for FLAGS in "$@"; do
     make -s -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -Wall -Wno-unused-function --offload-arch=gfx950 $FLAGS" )
   echo "== variant [$FLAGS]"
   python3 "$V/tools/merkle_tail_bench.py" 2>&1 | tail -10
+  python3 "$V/tools/merkle_width_bench.py" 2>&1 | tail -6
   python3 "$V/tools/prove_bench.py" 149000 8 80 20 2>&1 | tail -2
 done
