@@ -228,7 +228,22 @@ int sp_cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t 
  * starts with its input in HBM; sp_cairo_prove additionally pays the PCIe copy of n*cols*32 bytes. */
 int sp_cairo_prove_dev(sp_ctx* ctx, const void* main_trace_dev, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
                        const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
+/* Same from host COLUMNS: column j of the main trace at main_trace_cols + j*col_stride*32 (col_stride in elements, 0 = n),
+ * the layout `TraceTable::cols()` produces (reference src/starks/trace.rs:23-31, the input of compute_trace_polys, :104-110).
+ * device_layout != 0: elements in the DEVICE layout (sp_fe_to_device); 0: in the context encoding.  No host-side gather: every
+ * column group is one DMA overlapped with the transforms of the group before it.  Allocate the buffer with sp_host_alloc and
+ * the DMA runs at PCIe speed; ordinary (pageable) memory works too, through the runtime's staging copy. */
+int sp_cairo_prove_columns(sp_ctx* ctx, const uint8_t* main_trace_cols, uint64_t n, uint32_t cols, uint64_t col_stride, int device_layout,
+                           const sp_cairo_public_inputs* pub, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
+/* Page-locked host memory for trace tables (hipHostMalloc): SP_E_ALLOC when the runtime cannot provide it. */
+int sp_host_alloc(uint64_t bytes, void** out);
+void sp_host_free(void* p);
 void sp_free(void* p);
+/* How the main trace of the last proof reached the device: out = {kind (0: one copy / resident, 1: row-major host buffer gathered
+ * into column groups by host threads, 2: DMA of host columns), column groups, bytes, host gather ms (sum), gather GB/s, DMA ms
+ * (sum over the groups), DMA GB/s, exposed ms (how long the compute stream waited for column groups in total), longest wait
+ * for one group ms, host wall ms of the upload loop}. */
+int sp_last_upload_stats(sp_ctx* ctx, double out[10]);
 /* Device time (ms, HIP events on the context stream) of rounds 0..4 of the last sp_cairo_prove. */
 /* What the last proof on this context did: out[0] = composition path (1: 2n-point evaluation after a clean trace check,
  * 2: whole LDE domain, deg H < 2n, 3: whole domain, deg H >= 2n - a constraint-violating trace), out[1] = FRI layers kept
@@ -307,6 +322,13 @@ int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_co
 int sp_cairo_run_main_trace(const sp_cairo_run* run, int fe_encoding, uint8_t* out);
 /* Fills `pi`; the pointers inside stay valid until sp_cairo_run_free(run). */
 int sp_cairo_run_public_inputs(const sp_cairo_run* run, sp_cairo_public_inputs* pi);
+/* The main trace as the run keeps it: column-major [cols][n_rows] in the DEVICE layout, page-locked when *pinned_out = 1 (the
+ * HIP runtime was usable when the run was built).  The pointer lives as long as the run. */
+int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_t* n_rows, uint32_t* n_cols, int* pinned_out);
+/* generate_prover_args + generate_cairo_proof (reference src/cairo/runner/run.rs:242-263, src/cairo/air.rs:1165-1171) for a run
+ * of this front-end: the run's own column-major page-locked trace goes up by DMA, column group by column group, behind the
+ * transforms of the groups before it (sp_cairo_prove_columns on sp_cairo_run_columns + sp_cairo_run_public_inputs). */
+int sp_cairo_prove_run(sp_ctx* ctx, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
 
 /* verify_cairo_proof (reference src/cairo/air.rs:1176-1182, src/starks/verifier.rs:559-657) on the host CPU: returns 1 when the
  * proof is accepted, 0 when it is rejected or malformed. Ships with the library so that proofs of shapes without a golden

@@ -139,6 +139,41 @@ class Context:
         self._lib.sp_free(out)
         return proof
 
+    def _take_proof(self, out, ln):
+        proof = ctypes.string_at(out, ln.value)
+        self._lib.sp_free(out)
+        return proof
+
+    def cairo_prove_run(self, run, options):
+        """sp_cairo_prove_run: the run's own column-major (page-locked) main trace goes up by DMA - no host-side gather."""
+        opt = options.to_c()
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_uint64()
+        check(self._lib.sp_cairo_prove_run(self._h, run._h, ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln)))
+        return self._take_proof(out, ln)
+
+    def cairo_prove_columns(self, cols_ptr, n, cols, public_inputs_c, options, col_stride=0, device_layout=False):
+        """sp_cairo_prove_columns: host COLUMNS at `cols_ptr` (int address or (cols, n, 32) uint8 array)."""
+        keep = None
+        if isinstance(cols_ptr, np.ndarray):
+            keep = np.ascontiguousarray(cols_ptr, dtype=np.uint8)
+            cols_ptr = keep.ctypes.data
+        opt = options.to_c()
+        out = ctypes.POINTER(ctypes.c_uint8)()
+        ln = ctypes.c_uint64()
+        check(self._lib.sp_cairo_prove_columns(self._h, ctypes.c_void_p(cols_ptr), ctypes.c_uint64(n), ctypes.c_uint32(cols), ctypes.c_uint64(col_stride),
+                                               int(bool(device_layout)), ctypes.byref(public_inputs_c), ctypes.byref(opt), ctypes.byref(out), ctypes.byref(ln)))
+        del keep
+        return self._take_proof(out, ln)
+
+    def last_upload_stats(self):
+        """sp_last_upload_stats of the last proof's main-trace upload."""
+        v = (ctypes.c_double * 10)()
+        check(self._lib.sp_last_upload_stats(self._h, v))
+        kinds = {0: "single copy / resident", 1: "row-major host buffer, gathered by host threads", 2: "host columns, DMA"}
+        return {"kind": kinds.get(int(v[0]), "?"), "groups": int(v[1]), "bytes": int(v[2]), "gather_ms": round(v[3], 3), "gather_gbs": round(v[4], 1),
+                "dma_ms": round(v[5], 3), "dma_gbs": round(v[6], 1), "exposed_ms": round(v[7], 3), "max_stall_ms": round(v[8], 3), "host_ms": round(v[9], 3)}
+
     def air_prove(self, desc, main_trace, options):
         """sp_air_prove: desc = lambdaworks_cairo_prover_amd.air.AirDescC (AirBuilder.build()[0]); main_trace (n, cols, 32)."""
         a = np.ascontiguousarray(main_trace, dtype=np.uint8)
@@ -259,6 +294,12 @@ class CairoRun:
         out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
         check(self._lib.sp_cairo_run_main_trace(self._h, fe_encoding, _u8p(out)))
         return out
+
+    def columns(self):
+        """(address, n_rows, n_cols, pinned) of the run's own column-major main trace in the device layout (sp_cairo_run_columns)."""
+        p, n, c, pin = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_int()
+        check(self._lib.sp_cairo_run_columns(self._h, ctypes.byref(p), ctypes.byref(n), ctypes.byref(c), ctypes.byref(pin)))
+        return p.value, n.value, c.value, bool(pin.value)
 
     def public_memory(self):
         pi = self.public_inputs_c

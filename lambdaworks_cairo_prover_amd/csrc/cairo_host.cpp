@@ -3,6 +3,10 @@
 #include <algorithm>
 #include <cstring>
 #include <stdexcept>
+#include <thread>
+#include <cstdlib>
+#include <exception>
+#include <new>
 
 namespace sp {
 
@@ -38,7 +42,7 @@ bool parse_memory_le(const uint8_t* b, size_t len, CairoMemory& out) {
         std::memcpy(&addr, b + 40 * i, 8);
         uint8_t be[32];
         for (int k = 0; k < 32; ++k) be[k] = b[40 * i + 8 + 31 - k];  // value is 32 bytes little-endian
-        out.data[addr] = fe_from_bytes_be(be);
+        out.set(addr, fe_from_bytes_be(be));
     }
     return true;
 }
@@ -95,124 +99,195 @@ const fe& mem_at(const CairoMemory& m, uint64_t a) {
 }
 }  // namespace
 
-std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub,
-                                 size_t* n_rows, size_t* n_cols) {
+void TraceColumns::release() {
+    if (data) { if (pinned) (void)hipHostFree(data); else std::free(data); }
+    data = nullptr; n_rows = n_cols = 0; pinned = false;
+}
+void TraceColumns::allocate(size_t rows, size_t cols) {
+    release();
+    const size_t bytes = std::max<size_t>(rows * cols * sizeof(fe), 64);
+    void* p = nullptr;
+    // page-locked when a device is there (the upload of a column group is then a plain DMA); SP_HOST_PINNED=0 turns it off
+    const char* env = std::getenv("SP_HOST_PINNED");
+    if (!(env && env[0] == '0') && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) pinned = true;
+    else {
+        (void)hipGetLastError();
+        p = nullptr;
+        if (posix_memalign(&p, 4096, bytes) != 0 || !p) throw std::bad_alloc();
+    }
+    data = static_cast<fe*>(p); n_rows = rows; n_cols = cols;
+}
+
+void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
+    static const unsigned max_threads = [] {
+        unsigned t = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        if (const char* e = std::getenv("SP_HOST_THREADS")) { int v = std::atoi(e); if (v >= 1) t = (unsigned)std::min(v, 256); }
+        return t;
+    }();
+    const size_t parts = std::max<size_t>(1, std::min<size_t>(max_threads, n / std::max<size_t>(min_chunk, 1)));
+    if (parts <= 1) { fn(0, n); return; }
+    const size_t per = (n + parts - 1) / parts;
+    std::vector<std::thread> ts;
+    std::vector<std::exception_ptr> errs(parts);
+    for (size_t t = 1; t < parts; ++t)
+        ts.emplace_back([&, t] { try { const size_t b = std::min(n, t * per); fn(b, std::min(n, b + per)); } catch (...) { errs[t] = std::current_exception(); } });
+    try { fn(0, std::min(n, per)); } catch (...) { errs[0] = std::current_exception(); }
+    for (auto& t : ts) t.join();
+    for (auto& e : errs) if (e) std::rethrow_exception(e);
+}
+
+// In-place Montgomery batch inversion of non-zero elements (one inversion per call)
+static void host_batch_inverse_nonzero(std::vector<fe>& v) {
+    if (v.empty()) return;
+    std::vector<fe> pre(v.size());
+    fe acc = fe_one();
+    for (size_t i = 0; i < v.size(); ++i) { pre[i] = acc; acc = fe_mul(acc, v[i]); }
+    fe inv = fe_inv(acc);
+    for (size_t i = v.size(); i-- > 0;) { const fe x = v[i]; v[i] = fe_mul(inv, pre[i]); inv = fe_mul(inv, x); }
+}
+
+void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TraceColumns& T) {
     const size_t steps = regs.size();
+    if (steps == 0) throw std::runtime_error("empty register trace");
     const MemorySegment* rc_seg = pub.segment(0);
     const size_t cols = rc_seg ? 43 : 34;
     const fe zero = fe_zero(), one = fe_one();
-    std::vector<fe> t;
-    t.reserve((steps + steps / 8 + 64) * cols);
-    t.resize(steps * cols, zero);
-    // build_cairo_execution_trace (execution_trace.rs:261-356)
-    for (size_t i = 0; i < steps; ++i) {
-        const RegisterState& r = regs[i];
-        const fe& inst = mem_at(mem, r.pc);
-        Decoded d = decode(inst);
-        fe* row = &t[i * cols];
-        for (int k = 0; k < 15; ++k) row[k] = ((d.flags >> k) & 1) ? one : zero;
-        uint64_t dst_addr = add_signed(d.dst_reg ? r.fp : r.ap, d.off_dst);
-        uint64_t op0_addr = add_signed(d.op0_reg ? r.fp : r.ap, d.off_op0);
-        fe dst = mem_at(mem, dst_addr);
-        fe op0 = mem_at(mem, op0_addr);
-        uint64_t op1_base = d.op1_src == 0 ? fe_low_u64(op0) : d.op1_src == 1 ? r.pc : d.op1_src == 2 ? r.fp : r.ap;
-        uint64_t op1_addr = add_signed(op1_base, d.off_op1);
-        fe op1 = mem_at(mem, op1_addr);
-        fe res;
-        if (d.pc_update == 4) {  // jnz: res holds dst^-1 (execution_trace.rs:382-440)
-            if (!(d.res_logic == 0 && d.opcode == 0 && d.ap_update != 1)) throw std::runtime_error("Undefined Behavior");
-            res = fe_is_zero(dst) ? dst : fe_inv(dst);
-        } else {
-            res = d.res_logic == 0 ? op1 : d.res_logic == 1 ? fe_add(op0, op1) : fe_mul(op0, op1);
+    // ---- pass A: the four memory addresses and three offsets of every step (what decides the number of rows)
+    std::vector<uint64_t> addr(4 * steps);    // [step][pc, dst, op0, op1]
+    std::vector<uint16_t> off(3 * steps);     // [step][dst, op0, op1] (biased)
+    host_parallel_for(steps, 4096, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i) {
+            const RegisterState& r = regs[i];
+            const Decoded d = decode(mem_at(mem, r.pc));
+            const uint64_t dst_addr = add_signed(d.dst_reg ? r.fp : r.ap, d.off_dst);
+            const uint64_t op0_addr = add_signed(d.op0_reg ? r.fp : r.ap, d.off_op0);
+            const uint64_t op1_base = d.op1_src == 0 ? fe_low_u64(mem_at(mem, op0_addr)) : d.op1_src == 1 ? r.pc : d.op1_src == 2 ? r.fp : r.ap;
+            addr[4 * i] = r.pc; addr[4 * i + 1] = dst_addr; addr[4 * i + 2] = op0_addr; addr[4 * i + 3] = add_signed(op1_base, d.off_op1);
+            off[3 * i] = (uint16_t)d.off_dst; off[3 * i + 1] = (uint16_t)d.off_op0; off[3 * i + 2] = (uint16_t)d.off_op1;
         }
-        // update_values (execution_trace.rs:572-592)
-        if (d.opcode == 1) { op0 = fe_from_u64(r.pc + (d.op1_src == 1 ? 2 : 1)); dst = fe_from_u64(r.fp); }
-        else if (d.opcode == 4) { res = dst; }
-        row[16] = res; row[17] = fe_from_u64(r.ap); row[18] = fe_from_u64(r.fp); row[19] = fe_from_u64(r.pc);
-        row[20] = fe_from_u64(dst_addr); row[21] = fe_from_u64(op0_addr); row[22] = fe_from_u64(op1_addr);
-        row[23] = inst; row[24] = dst; row[25] = op0; row[26] = op1;
-        row[27] = fe_from_u64(d.off_dst); row[28] = fe_from_u64(d.off_op0); row[29] = fe_from_u64(d.off_op1);
-        fe t0 = ((d.flags >> 9) & 1) ? dst : zero;
-        row[30] = t0; row[31] = fe_mul(t0, res); row[32] = fe_mul(op0, op1);
-        row[33] = (i + 1 == steps) ? zero : one;
-    }
-    if (rc_seg) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624)
-        size_t k = 0;
-        for (uint64_t a = rc_seg->start; a < rc_seg->end && k < steps; ++a, ++k) {
-            const fe& v = mem_at(mem, a);
-            fe raw = fe_from_mont(v);
-            fe* row = &t[k * cols];
-            for (int c = 0; c < 8; ++c) row[34 + c] = fe_from_u64((raw.v[c / 2] >> (16 * (c & 1))) & 0xffff);
-            row[42] = v;
-        }
-    }
-    // sorted addresses of the execution trace, before any padding (execution_trace.rs:64-67)
-    std::vector<uint64_t> addrs;
-    addrs.reserve(4 * steps);
-    for (size_t i = 0; i < steps; ++i)
-        for (int c = 19; c <= 22; ++c) addrs.push_back(fe_low_u64(t[i * cols + c]));
-    std::sort(addrs.begin(), addrs.end());
-    // get_rc_holes / fill_rc_holes (execution_trace.rs:136-185)
+    });
+    // get_rc_holes (execution_trace.rs:136-185): every value strictly between the smallest and the largest offset that no step uses
+    std::vector<uint16_t> missing;
     {
-        std::vector<uint16_t> offs;
-        offs.reserve(3 * steps);
-        for (size_t i = 0; i < steps; ++i)
-            for (int c = 27; c <= 29; ++c) offs.push_back((uint16_t)fe_low_u64(t[i * cols + c]));
-        std::sort(offs.begin(), offs.end());
-        std::vector<uint16_t> missing;
-        for (size_t i = 1; i < offs.size(); ++i)
-            if (offs[i] != offs[i - 1])
-                for (uint32_t v = (uint32_t)offs[i - 1] + 1; v < offs[i]; ++v) missing.push_back((uint16_t)v);
-        size_t pad = ((missing.size() + 2) / 3) * 3 - missing.size();
-        for (size_t i = 0; i < pad; ++i) missing.push_back(offs.back());
-        pub.range_check_min = offs.front(); pub.range_check_max = offs.back();
+        std::vector<uint8_t> seen(65536, 0);
+        for (uint16_t v : off) seen[v] = 1;
+        uint32_t lo = 0, hi = 65535;
+        while (!seen[lo]) ++lo;
+        while (!seen[hi]) --hi;
+        for (uint32_t v = lo + 1; v < hi; ++v) if (!seen[v]) missing.push_back((uint16_t)v);
+        const size_t pad = ((missing.size() + 2) / 3) * 3 - missing.size();
+        for (size_t i = 0; i < pad; ++i) missing.push_back((uint16_t)hi);
+        pub.range_check_min = (uint16_t)lo; pub.range_check_max = (uint16_t)hi;
         pub.has_rc_min = pub.has_rc_max = true;
-        for (size_t i = 0; i < missing.size(); i += 3) {
-            size_t base = t.size();
-            t.resize(base + cols, zero);
-            for (int k = 0; k < 3; ++k) t[base + 27 + k] = fe_from_u64(missing[i + k]);
-        }
     }
-    // get_memory_holes / fill_memory_holes (execution_trace.rs:195-255)
+    // get_memory_holes (execution_trace.rs:195-255): the addresses above the public memory that lie between two accessed
+    // addresses and are not accessed themselves, in increasing order
+    std::vector<uint64_t> holes;
     {
-        uint64_t codelen = pub.public_memory.size();
-        std::vector<uint64_t> holes;
-        uint64_t prev = addrs[0];
-        for (uint64_t a : addrs) {
-            uint64_t diff = a - prev;
-            if (diff != 1 && diff != 0 && a > codelen)
-                for (uint64_t h = prev + 1; h < a; ++h) if (h > codelen) holes.push_back(h);
-            prev = a;
-        }
-        if (!holes.empty()) {
-            std::vector<fe> last(t.end() - cols, t.end());
-            size_t hi = 0;
-            size_t rows = (holes.size() + 3) / 4;
-            for (size_t r = 0; r < rows; ++r) {
-                std::vector<fe> row = last;
-                for (int c = 19; c <= 22; ++c) if (hi < holes.size()) row[c] = fe_from_u64(holes[hi++]);
-                t.insert(t.end(), row.begin(), row.end());
+        const uint64_t codelen = pub.public_memory.size();
+        uint64_t lo = ~0ULL, hi = 0;
+        for (uint64_t a : addr) { lo = std::min(lo, a); hi = std::max(hi, a); }
+        if (hi - lo < (1ULL << 34)) {           // presence bitmap over [lo, hi]
+            std::vector<uint64_t> bits(((hi - lo) >> 6) + 1, 0);
+            for (uint64_t a : addr) bits[(a - lo) >> 6] |= 1ULL << ((a - lo) & 63);
+            for (uint64_t h = std::max(lo + 1, codelen + 1); h < hi; ++h)
+                if (!((bits[(h - lo) >> 6] >> ((h - lo) & 63)) & 1)) holes.push_back(h);
+        } else {                                // scattered addresses: sort (the reference's own formulation)
+            std::vector<uint64_t> sorted(addr);
+            std::sort(sorted.begin(), sorted.end());
+            uint64_t prev = sorted[0];
+            for (uint64_t a : sorted) {
+                const uint64_t diff = a - prev;
+                if (diff != 1 && diff != 0 && a > codelen)
+                    for (uint64_t h = prev + 1; h < a; ++h) if (h > codelen) holes.push_back(h);
+                prev = a;
             }
         }
     }
-    // add_pub_memory_dummy_accesses (execution_trace.rs:91-96, :112-127)
+    const size_t r_rc = steps, r_holes = r_rc + missing.size() / 3, r_dummy = r_holes + (holes.size() + 3) / 4,
+                 r_pad = r_dummy + (pub.public_memory.size() >> 2) + 1;
+    size_t n = 1;
+    while (n < r_pad) n <<= 1;
+    T.allocate(n, cols);
+    // ---- pass B: build_cairo_execution_trace (execution_trace.rs:261-356), one row per step
+    host_parallel_for(steps, 4096, [&](size_t b, size_t e) {
+        std::vector<size_t> jnz_rows;
+        std::vector<fe> jnz_dst;
+        for (size_t i = b; i < e; ++i) {
+            const RegisterState& r = regs[i];
+            const fe& inst = mem_at(mem, r.pc);
+            const Decoded d = decode(inst);
+            for (int k = 0; k < 15; ++k) T.at(i, k) = ((d.flags >> k) & 1) ? one : zero;
+            T.at(i, 15) = zero;
+            const uint64_t dst_addr = addr[4 * i + 1], op0_addr = addr[4 * i + 2], op1_addr = addr[4 * i + 3];
+            fe dst = mem_at(mem, dst_addr);
+            fe op0 = mem_at(mem, op0_addr);
+            const fe op1 = mem_at(mem, op1_addr);
+            fe res;
+            bool deferred = false;
+            if (d.pc_update == 4) {  // jnz: res holds dst^-1 (execution_trace.rs:382-440); inverted in one batch below
+                if (!(d.res_logic == 0 && d.opcode == 0 && d.ap_update != 1)) throw std::runtime_error("Undefined Behavior");
+                res = dst;
+                if (!fe_is_zero(dst)) { deferred = true; jnz_rows.push_back(i); jnz_dst.push_back(dst); }
+            } else {
+                res = d.res_logic == 0 ? op1 : d.res_logic == 1 ? fe_add(op0, op1) : fe_mul(op0, op1);
+            }
+            // update_values (execution_trace.rs:572-592)
+            if (d.opcode == 1) { op0 = fe_from_u64(r.pc + (d.op1_src == 1 ? 2 : 1)); dst = fe_from_u64(r.fp); }
+            else if (d.opcode == 4) { res = dst; }
+            T.at(i, 16) = res; T.at(i, 17) = fe_from_u64(r.ap); T.at(i, 18) = fe_from_u64(r.fp); T.at(i, 19) = fe_from_u64(r.pc);
+            T.at(i, 20) = fe_from_u64(dst_addr); T.at(i, 21) = fe_from_u64(op0_addr); T.at(i, 22) = fe_from_u64(op1_addr);
+            T.at(i, 23) = inst; T.at(i, 24) = dst; T.at(i, 25) = op0; T.at(i, 26) = op1;
+            T.at(i, 27) = fe_from_u64(d.off_dst); T.at(i, 28) = fe_from_u64(d.off_op0); T.at(i, 29) = fe_from_u64(d.off_op1);
+            const fe t0 = ((d.flags >> 9) & 1) ? dst : zero;
+            T.at(i, 30) = t0; T.at(i, 31) = deferred ? zero : fe_mul(t0, res); T.at(i, 32) = fe_mul(op0, op1);
+            T.at(i, 33) = (i + 1 == steps) ? zero : one;
+            for (size_t c = 34; c < cols; ++c) T.at(i, c) = zero;
+        }
+        host_batch_inverse_nonzero(jnz_dst);
+        for (size_t k = 0; k < jnz_rows.size(); ++k) {
+            const size_t i = jnz_rows[k];
+            T.at(i, 16) = jnz_dst[k];
+            T.at(i, 31) = fe_mul(T.at(i, 30), jnz_dst[k]);
+        }
+    });
+    if (rc_seg) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624)
+        const size_t cnt = (size_t)std::min<uint64_t>(rc_seg->end > rc_seg->start ? rc_seg->end - rc_seg->start : 0, steps);
+        host_parallel_for(cnt, 4096, [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const fe& v = mem_at(mem, rc_seg->start + k);
+                const fe raw = fe_from_mont(v);
+                for (int c = 0; c < 8; ++c) T.at(k, 34 + c) = fe_from_u64((raw.v[c / 2] >> (16 * (c & 1))) & 0xffff);
+                T.at(k, 42) = v;
+            }
+        });
+    }
+    auto get_row = [&](size_t r) { std::vector<fe> row(cols); for (size_t c = 0; c < cols; ++c) row[c] = T.at(r, c); return row; };
+    // fill_rc_holes (execution_trace.rs:136-185): zero rows that carry three missing offsets each
+    for (size_t r = r_rc; r < r_holes; ++r) {
+        for (size_t c = 0; c < cols; ++c) T.at(r, c) = zero;
+        for (int k = 0; k < 3; ++k) T.at(r, 27 + k) = fe_from_u64(missing[3 * (r - r_rc) + k]);
+    }
+    // fill_memory_holes (execution_trace.rs:195-255): copies of the last row with four holes each as addresses
+    if (r_dummy > r_holes) {
+        const std::vector<fe> last = get_row(r_holes - 1);
+        host_parallel_for(r_dummy - r_holes, 1024, [&](size_t b, size_t e) {
+            for (size_t k = b; k < e; ++k) {
+                const size_t r = r_holes + k;
+                for (size_t c = 0; c < cols; ++c) T.at(r, c) = last[c];
+                for (int c = 0; c < 4; ++c) if (4 * k + c < holes.size()) T.at(r, 19 + c) = fe_from_u64(holes[4 * k + c]);
+            }
+        });
+    }
+    // add_pub_memory_dummy_accesses (execution_trace.rs:91-96, :112-127) and pad_with_last_row (:82-84): the last row with
+    // zeroed memory columns, up to the next power of two
     {
-        std::vector<fe> last(t.end() - cols, t.end());
+        std::vector<fe> last = get_row(r_dummy - 1);
         for (int c = 19; c <= 26; ++c) last[c] = zero;
-        size_t rows = (pub.public_memory.size() >> 2) + 1;
-        for (size_t r = 0; r < rows; ++r) t.insert(t.end(), last.begin(), last.end());
+        host_parallel_for(cols, 1, [&](size_t b, size_t e) {
+            for (size_t c = b; c < e; ++c) std::fill(&T.at(r_dummy, c), &T.at(0, c) + n, last[c]);
+        });
     }
-    // pad_with_last_row to the next power of two (execution_trace.rs:82-84)
-    {
-        size_t n = t.size() / cols, p2 = 1;
-        while (p2 < n) p2 <<= 1;
-        std::vector<fe> last(t.end() - cols, t.end());
-        t.reserve(p2 * cols);
-        for (size_t r = n; r < p2; ++r) t.insert(t.end(), last.begin(), last.end());
-        *n_rows = p2;
-    }
-    *n_cols = cols;
-    return t;
 }
 
 // cairo-run's non-proof-mode layout (reference src/cairo/runner/run.rs:64-240 drives cairo-vm 0.6.0 that way): program at
@@ -233,25 +308,34 @@ void run_program_builtins(const std::vector<fe>& program, uint32_t builtins_mask
     for (size_t b = 0; b < nb; ++b) base[b] = (1ULL << 40) * (b + 1);
     uint64_t end_marker = ~0ULL >> 8;
     for (int pass = 0; pass < 2; ++pass) {
-        mem.data.clear();
+        mem.clear();
         regs.clear();
-        for (uint64_t i = 0; i < L; ++i) mem.data[i + 1] = program[i];
-        for (size_t b = 0; b < nb; ++b) mem.data[L + 1 + b] = fe_from_u64(base[b]);
-        mem.data[L + 1 + nb] = fe_from_u64(end_marker);  // return fp
-        mem.data[L + 2 + nb] = fe_from_u64(end_marker);  // return pc
+        for (uint64_t i = 0; i < L; ++i) mem.set(i + 1, program[i]);
+        for (size_t b = 0; b < nb; ++b) mem.set(L + 1 + b, fe_from_u64(base[b]));
+        mem.set(L + 1 + nb, fe_from_u64(end_marker));  // return fp
+        mem.set(L + 2 + nb, fe_from_u64(end_marker));  // return pc
+        std::vector<Decoded> dcache; std::vector<uint8_t> dcache_ok;
         uint64_t pc = entry_pc, ap = L + 3 + nb, fp = L + 3 + nb;
         const uint64_t fp0 = fp;
         bool done = false;
         while (!done) {
             if (regs.size() >= max_steps) throw std::runtime_error("step limit exceeded");
             regs.push_back(RegisterState{ap, fp, pc});
-            Decoded d = decode(mem_at(mem, pc));
+            Decoded d;
+            if (pc < dcache.size() && dcache_ok[pc]) d = dcache[pc];      // (program cells 1..L are never written: ap starts above them)
+            else {
+                d = decode(mem_at(mem, pc));
+                if (pc <= L && pc < (1u << 24)) {
+                    if (pc >= dcache.size()) { dcache.resize(pc + 1024); dcache_ok.resize(pc + 1024, 0); }
+                    dcache[pc] = d; dcache_ok[pc] = 1;
+                }
+            }
             uint64_t size = d.op1_src == 1 ? 2 : 1;
             uint64_t dst_addr = add_signed(d.dst_reg ? fp : ap, d.off_dst);
             uint64_t op0_addr = add_signed(d.op0_reg ? fp : ap, d.off_op0);
             if (d.opcode == 1) {  // call: [ap] = fp, [ap+1] = pc + size
-                mem.data[ap] = fe_from_u64(fp);
-                mem.data[ap + 1] = fe_from_u64(pc + size);
+                mem.set(ap, fe_from_u64(fp));
+                mem.set(ap + 1, fe_from_u64(pc + size));
             }
             const fe* op0p = mem.get(op0_addr);
             uint64_t op1_base;
@@ -264,16 +348,16 @@ void run_program_builtins(const std::vector<fe>& program, uint32_t builtins_mask
                 if (!dstp) {
                     if (!op1p || (d.res_logic != 0 && !op0p)) throw std::runtime_error("cannot deduce dst");
                     fe r = d.res_logic == 0 ? *op1p : d.res_logic == 1 ? fe_add(*op0p, *op1p) : fe_mul(*op0p, *op1p);
-                    mem.data[dst_addr] = r;
+                    mem.set(dst_addr, r);
                 } else if (!op1p) {
                     fe r;
                     if (d.res_logic == 0) r = *dstp;
                     else if (!op0p) throw std::runtime_error("cannot deduce op1");
                     else if (d.res_logic == 1) r = fe_sub(*dstp, *op0p);
                     else r = fe_mul(*dstp, fe_inv(*op0p));
-                    mem.data[op1_addr] = r;
+                    mem.set(op1_addr, r);
                 } else if (!op0p && d.res_logic != 0) {
-                    mem.data[op0_addr] = d.res_logic == 1 ? fe_sub(*dstp, *op1p) : fe_mul(*dstp, fe_inv(*op1p));
+                    mem.set(op0_addr, d.res_logic == 1 ? fe_sub(*dstp, *op1p) : fe_mul(*dstp, fe_inv(*op1p)));
                 }
                 dstp = mem.get(dst_addr); op0p = mem.get(op0_addr); op1p = mem.get(op1_addr);
             }

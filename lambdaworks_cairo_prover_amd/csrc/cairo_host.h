@@ -10,16 +10,60 @@
 #include <cstdint>
 #include <string>
 #include <unordered_map>
+#include <functional>
+#include <algorithm>
 #include <vector>
 
 namespace sp {
 
 struct RegisterState { uint64_t ap, fp, pc; };
 
+// Relocated Cairo memory, values in Montgomery form.  Addresses of a run are small consecutive integers (program, execution and
+// builtin segments follow each other), so cells live in a flat array that grows with the highest address written; an address far
+// beyond it (the placeholder bases of the first builtin pass, a hostile dump) goes to a hash map.
 struct CairoMemory {
-    std::unordered_map<uint64_t, fe> data;  // values in Montgomery form
-    const fe* get(uint64_t addr) const { auto it = data.find(addr); return it == data.end() ? nullptr : &it->second; }
+    static constexpr uint64_t ALWAYS_DENSE = 1ULL << 26;   // below this address a cell always lives in the flat array
+    std::vector<fe> dense;
+    std::vector<uint8_t> present;
+    std::unordered_map<uint64_t, fe> sparse;
+    const fe* get(uint64_t addr) const {
+        if (addr < dense.size() && present[addr]) return &dense[addr];
+        if (sparse.empty()) return nullptr;
+        auto it = sparse.find(addr);
+        return it == sparse.end() ? nullptr : &it->second;
+    }
+    void set(uint64_t addr, const fe& v) {
+        if (addr >= dense.size()) {
+            // the flat array follows contiguous growth (at most doubling per step); a far-away address goes to the map
+            if (addr >= ALWAYS_DENSE && addr > 2 * (uint64_t)dense.size()) { sparse[addr] = v; return; }
+            const uint64_t want = std::max<uint64_t>(std::max<uint64_t>(addr + 1, dense.size() * 2), 1024);
+            dense.resize(want);
+            present.resize(want, 0);
+        }
+        if (!sparse.empty()) sparse.erase(addr);
+        dense[addr] = v; present[addr] = 1;
+    }
+    void clear() { dense.clear(); present.clear(); sparse.clear(); }
 };
+
+// The main trace in the device's own layout: column-major [cols][n] Montgomery field elements, in page-locked host memory when
+// the HIP runtime can provide it (a column group is then one plain DMA - sp_cairo_prove_run), ordinary memory otherwise.
+struct TraceColumns {
+    fe* data = nullptr;
+    size_t n_rows = 0, n_cols = 0;
+    bool pinned = false;
+    TraceColumns() = default;
+    TraceColumns(const TraceColumns&) = delete;
+    TraceColumns& operator=(const TraceColumns&) = delete;
+    ~TraceColumns() { release(); }
+    void allocate(size_t rows, size_t cols);   // throws std::bad_alloc
+    void release();
+    fe& at(size_t row, size_t col) { return data[col * n_rows + row]; }
+    const fe& at(size_t row, size_t col) const { return data[col * n_rows + row]; }
+};
+
+// fn(begin, end) over [0, n) on up to SP_HOST_THREADS (default: the hardware threads, at most 64) host threads
+void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn);
 
 struct MemorySegment { uint8_t type; uint64_t start, end; };  // type 0 RangeCheck, 1 Output (air.rs:156-160)
 
@@ -44,10 +88,9 @@ bool parse_memory_le(const uint8_t* bytes, size_t len, CairoMemory& out);
 PublicInputs public_inputs_from_regs_and_mem(const std::vector<RegisterState>& regs, const CairoMemory& mem,
                                              size_t program_size, const std::vector<MemorySegment>& segments);
 
-// execution_trace.rs:57-87. Returns the row-major n x cols main trace (cols = 34, or 43 with the rc builtin),
-// n a power of two; sets pub.range_check_min/max. Throws std::runtime_error on undecodable instructions.
-std::vector<fe> build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub,
-                                 size_t* n_rows, size_t* n_cols);
+// execution_trace.rs:57-87. Builds the n x cols main trace (cols = 34, or 43 with the rc builtin), n a power of two, column-major
+// in `out`; sets pub.range_check_min/max. Throws std::runtime_error on undecodable instructions.
+void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TraceColumns& out);
 
 // Runs `program` (field elements, address 1..L) from pc = 1 in cairo-run's non-proof-mode layout until main returns.
 // Fills the relocated register trace and memory. Supports every hint-free, builtin-free instruction.

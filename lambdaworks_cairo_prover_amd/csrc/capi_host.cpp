@@ -13,7 +13,7 @@ struct sp_cairo_run {
     std::vector<sp::RegisterState> regs;
     sp::CairoMemory mem;
     sp::PublicInputs pub;
-    std::vector<fe> main_trace;
+    sp::TraceColumns main_trace;   // column-major, device layout (pinned when the HIP runtime provides it)
     size_t n_rows = 0, n_cols = 0;
     // flattened views handed out by sp_cairo_run_public_inputs
     std::vector<uint8_t> seg_types;
@@ -21,6 +21,10 @@ struct sp_cairo_run {
     std::vector<uint8_t> pm_bytes;
 };
 
+namespace sp {   // for capi_prove.cpp (sp_cairo_prove_run)
+const PublicInputs& cairo_run_public_inputs(const sp_cairo_run* run) { return run->pub; }
+const TraceColumns& cairo_run_columns(const sp_cairo_run* run) { return run->main_trace; }
+}
 static thread_local std::string g_last_error;
 void sp_set_error(const std::string& s) { g_last_error = s; }
 namespace sp {
@@ -79,7 +83,8 @@ int sp_fe_from_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
 
 static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out, const std::vector<sp::MemorySegment>& segments = {}) {
     r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, segments);
-    r->main_trace = sp::build_main_trace(r->regs, r->mem, r->pub, &r->n_rows, &r->n_cols);
+    sp::build_main_trace(r->regs, r->mem, r->pub, r->main_trace);
+    r->n_rows = r->main_trace.n_rows; r->n_cols = r->main_trace.n_cols;
     *out = r;
     return SP_OK;
 }
@@ -144,9 +149,45 @@ int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_co
 }
 
 int sp_cairo_run_main_trace(const sp_cairo_run* run, int enc, uint8_t* out) {
-    if (!run || !out) return SP_E_INVALID_ARG;
-    return sp_fe_from_device(enc, reinterpret_cast<const uint8_t*>(run->main_trace.data()), run->main_trace.size(), out);
+    if (!run || !out || (enc != SP_FE_CANON_BE && enc != SP_FE_MONT_LIMBS)) return SP_E_INVALID_ARG;
+    // row-major n x cols in the ABI encoding (what the reference's TraceTable holds, trace.rs:9-13) from the column-major store
+    const sp::TraceColumns& T = run->main_trace;
+    sp::host_parallel_for(T.n_rows, 1024, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i)
+            for (size_t c = 0; c < T.n_cols; ++c) {
+                uint8_t* o = out + (i * T.n_cols + c) * 32;
+                if (enc == SP_FE_CANON_BE) fe_to_bytes_be(T.at(i, c), o);
+                else { uint64_t l[4]; fe_to_lw_limbs(T.at(i, c), l); std::memcpy(o, l, 32); }
+            }
+    });
+    return SP_OK;
 }
+
+// The same trace as it is stored: column-major [cols][n_rows] field elements in the DEVICE layout (8 x u32 little-endian
+// Montgomery limbs, SP_FE_DEVICE), page-locked when *pinned comes back 1.  The pointer lives as long as the run.
+int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_t* n_rows, uint32_t* n_cols, int* pinned) {
+    if (!run || !cols_out) return SP_E_INVALID_ARG;
+    *cols_out = run->main_trace.data;
+    if (n_rows) *n_rows = run->main_trace.n_rows;
+    if (n_cols) *n_cols = (uint32_t)run->main_trace.n_cols;
+    if (pinned) *pinned = run->main_trace.pinned ? 1 : 0;
+    return SP_OK;
+}
+
+// Page-locked host memory for trace tables that will be handed to sp_cairo_prove / sp_cairo_prove_columns / sp_commit_trace:
+// a buffer from here crosses PCIe by DMA without the staging copy a pageable buffer needs.
+int sp_host_alloc(uint64_t bytes, void** out) {
+    if (!out) return SP_E_INVALID_ARG;
+    *out = nullptr;
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        *out = nullptr;
+        sp_set_error("sp_host_alloc: hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");
+        return SP_E_ALLOC;
+    }
+    return SP_OK;
+}
+void sp_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 int sp_cairo_run_public_inputs(const sp_cairo_run* crun, sp_cairo_public_inputs* pi) {
     if (!crun || !pi) return SP_E_INVALID_ARG;

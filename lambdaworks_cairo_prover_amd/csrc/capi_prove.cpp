@@ -1,8 +1,13 @@
 // C ABI: round-level prover entry points and the whole-proof call. See include/stark252_hip.h.
 #include "prover.h"
+#include "cairo_host.h"
 #include <cstdlib>
 #include <cstring>
 
+namespace sp {   // capi_host.cpp
+const PublicInputs& cairo_run_public_inputs(const sp_cairo_run* run);
+const TraceColumns& cairo_run_columns(const sp_cairo_run* run);
+}
 using namespace sp;
 
 namespace {
@@ -141,27 +146,52 @@ int sp_open(sp_ctx* c, const uint64_t* iotas, uint32_t q, sp_openings* out) {
     return SP_OK;
 }
 
-static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
-                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, bool on_device);
+static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& p,
+                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, StarkProver::TraceSource src,
+                            int col_enc = -1, uint64_t col_stride = 0);
 
 int sp_cairo_prove(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
                    const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
-    return cairo_prove_impl(c, main_trace, n, cols, pub, opt, proof_out, proof_len, false);
+    if (!pub) return SP_E_INVALID_ARG;
+    try { return cairo_prove_impl(c, main_trace, n, cols, to_host_pub(pub), opt, proof_out, proof_len, StarkProver::TRACE_HOST_ROWS); }
+    catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
 }
 int sp_cairo_prove_dev(sp_ctx* c, const void* main_trace_dev, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
                        const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
-    return cairo_prove_impl(c, static_cast<const uint8_t*>(main_trace_dev), n, cols, pub, opt, proof_out, proof_len, true);
+    if (!pub) return SP_E_INVALID_ARG;
+    try { return cairo_prove_impl(c, static_cast<const uint8_t*>(main_trace_dev), n, cols, to_host_pub(pub), opt, proof_out, proof_len, StarkProver::TRACE_DEVICE_ROWS); }
+    catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
+}
+int sp_cairo_prove_columns(sp_ctx* c, const uint8_t* main_trace_cols, uint64_t n, uint32_t cols, uint64_t col_stride, int device_layout,
+                           const sp_cairo_public_inputs* pub, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    if (!pub || !c) return SP_E_INVALID_ARG;
+    try {
+        return cairo_prove_impl(c, main_trace_cols, n, cols, to_host_pub(pub), opt, proof_out, proof_len, StarkProver::TRACE_HOST_COLUMNS,
+                                device_layout ? -1 : c->enc, col_stride);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
+}
+int sp_cairo_prove_run(sp_ctx* c, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
+    if (!run) return SP_E_INVALID_ARG;
+    const TraceColumns& T = cairo_run_columns(run);
+    return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.data), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
+                            proof_len, StarkProver::TRACE_HOST_COLUMNS, -1, T.n_rows);
 }
 
-static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const sp_cairo_public_inputs* pub,
-                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, bool on_device) {
-    if (!c || !main_trace || !pub || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
+int sp_last_upload_stats(sp_ctx* c, double out[10]) {
+    if (!c || !out) return SP_E_INVALID_ARG;
+    std::memcpy(out, c->upload_stats, sizeof(double) * 10);
+    return SP_OK;
+}
+
+static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& p,
+                            const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, StarkProver::TraceSource src,
+                            int col_enc, uint64_t col_stride) {
+    if (!c || !main_trace || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
     try {
-        PublicInputs p = to_host_pub(pub);
         ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
         std::vector<uint8_t> bytes;
         float ms[5] = {0, 0, 0, 0, 0};
-        int rc = cairo_prove(c, main_trace, n, cols, p, o, bytes, ms, on_device);
+        int rc = cairo_prove(c, main_trace, n, cols, p, o, bytes, ms, src, col_enc, col_stride);
         if (rc != SP_OK) return rc;
         std::memcpy(c->round_ms, ms, sizeof(ms));
         *proof_out = (uint8_t*)std::malloc(bytes.size());

@@ -22,6 +22,7 @@ struct sp_ctx {
     float round_ms[5] = {0, 0, 0, 0, 0};
     uint32_t proof_info[4] = {0, 0, 0, 0};   // sp_last_proof_info
     uint64_t prover_device_bytes = 0;         // sp_prover_device_bytes
+    double upload_stats[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // sp_last_upload_stats
     sp_deletable* prover_state_deleter_holder = nullptr;  // round-level prover state (prover.cpp)
     // coset sharding across GPUs: world size (power of two), rank and the blocking all-gather hook (see sp_set_collective)
     int world = 1, rank = 0;

@@ -33,6 +33,8 @@ StarkProver::~StarkProver() {
     free_all();
     for (auto& e : ev_dma_) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
+    for (auto& u : up_ev_) for (hipEvent_t e : {u.dma0, u.dma1, u.ready, u.done}) if (e) (void)hipEventDestroy(e);
+    if (up_start_) (void)hipEventDestroy(up_start_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
@@ -339,13 +341,20 @@ int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncol
     return readback(root_out, tree.top, 32);
 }
 
-int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], bool rows_on_device) {
+int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], TraceSource src, int col_enc, uint64_t col_stride) {
     if (!rows_host || !root_out) return SP_E_INVALID_ARG;
     if (!((segment == 0 && stage_ == 1 && cols == Cm_) || (segment == 1 && stage_ == 2 && cols == Ca_))) {
         sp_set_error("commit_trace: wrong segment order or column count");
         return SP_E_STATE;
     }
     SP_HIP_CHECK(hipSetDevice(c_->device));
+    for (double& x : c_->upload_stats) x = 0.0;
+    if (src == TRACE_HOST_COLUMNS) {
+        if (col_enc >= 0 && col_enc != SP_FE_MONT_LIMBS && col_enc != SP_FE_CANON_BE) return SP_E_INVALID_ARG;
+        if (col_stride && col_stride < n_) return SP_E_INVALID_ARG;
+        return commit_trace_columns(segment, rows_host, cols, col_enc, col_stride ? col_stride : n_, root_out);
+    }
+    const bool rows_on_device = src == TRACE_DEVICE_ROWS;
     if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20) && (uint64_t)UPLOAD_SLOTS * 9 * n_ <= scratch_elems())
         return commit_trace_pipelined(segment, rows_host, cols, root_out);   // (landing slots of up to nine columns each live in the scratch area)
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
@@ -360,6 +369,93 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     if (segment == 0) SP_TRY(launch_aux_presort());
     return commit_segment_resident(segment, cols, root_out);
+}
+
+int StarkProver::ensure_upload(uint32_t groups) {
+    if (groups > (uint32_t)UPLOAD_MAX_GROUPS) { sp_set_error("commit_trace: too many column groups"); return SP_E_UNSUPPORTED; }
+    if (!copy_stream_) {
+        SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
+    }
+    if (!up_start_) SP_HIP_CHECK(hipEventCreate(&up_start_));
+    for (uint32_t g = 0; g < groups; ++g)
+        for (hipEvent_t* e : {&up_ev_[g].dma0, &up_ev_[g].dma1, &up_ev_[g].ready, &up_ev_[g].done})
+            if (!*e) SP_HIP_CHECK(hipEventCreate(e));
+    SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
+    return SP_OK;
+}
+
+// After the commitment's read-back (every event has completed): what the upload cost and how long the compute stream waited
+// for it.  kind 1: gathered from a row-major host buffer, 2: DMA of host columns.
+int StarkProver::finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind) {
+    double dma_ms = 0, exposed = 0, worst = 0;
+    for (uint32_t g = 0; g < groups; ++g) {
+        float d = 0, w = 0;
+        if (hipEventElapsedTime(&d, up_ev_[g].dma0, up_ev_[g].dma1) == hipSuccess) dma_ms += d;
+        // the compute stream could have started group g when it was done with group g - 1 (or, for the first one, at the start)
+        if (hipEventElapsedTime(&w, g ? up_ev_[g - 1].done : up_start_, up_ev_[g].ready) == hipSuccess && w > 0) { exposed += w; worst = std::max<double>(worst, w); }
+    }
+    (void)hipGetLastError();
+    double* u = c_->upload_stats;
+    u[0] = kind; u[1] = groups; u[2] = (double)bytes; u[3] = gather_ms; u[4] = gather_ms > 0 ? bytes / gather_ms * 1e-6 : 0;
+    u[5] = dma_ms; u[6] = dma_ms > 0 ? bytes / dma_ms * 1e-6 : 0; u[7] = exposed; u[8] = worst; u[9] = host_ms;
+    return SP_OK;
+}
+
+// interpolate_and_commit (reference prover.rs:126-159) from host COLUMNS (the layout trace.rs:23-31 `cols()` produces, and what
+// sp_cairo_run keeps): a column group is one contiguous DMA straight into the trace area - no gather, no landing slot - and the
+// groups double (1, 1, 2, 4, 8, 8, ...) so that only the first column's 0.6 ms stay in front of the transforms.
+int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]) {
+    const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    std::vector<uint32_t> gsize;
+    for (uint32_t done = 0; done < cols;) {
+        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(1, done));
+        if (G_ > 1 && d_cstage_) w = cols;            // column-sharded interpolation works on the whole segment
+        w = std::min(w, cols - done);
+        gsize.push_back(w);
+        done += w;
+    }
+    const uint32_t groups = (uint32_t)gsize.size();
+    SP_TRY(ensure_upload(groups));
+    const double t0 = wall_ms();
+    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
+    fe* trace = d_trace_ + (uint64_t)col0 * n_;
+    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
+    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the trace area's previous readers are behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
+    const bool sharded_interp = G_ > 1 && d_cstage_ && cols >= G_;
+    uint32_t c0 = 0;
+    for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
+        const uint32_t w = gsize[g];
+        fe* dst = trace + (uint64_t)c0 * n_;
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
+        if (col_stride == n_) {
+            SP_HIP_CHECK(hipMemcpyAsync(dst, cols_host + (size_t)c0 * n_ * 32, (size_t)w * n_ * 32, hipMemcpyHostToDevice, copy_stream_));
+        } else {
+            for (uint32_t j = 0; j < w; ++j)
+                SP_HIP_CHECK(hipMemcpyAsync(dst + (uint64_t)j * n_, cols_host + (size_t)(c0 + j) * col_stride * 32, (size_t)n_ * 32, hipMemcpyHostToDevice, copy_stream_));
+        }
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
+        if (col_enc >= 0) SP_TRY(decode_elements(copy_stream_, col_enc, reinterpret_cast<const uint8_t*>(dst), (uint64_t)w * n_, dst));   // element-wise, in place
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
+        if (!sharded_interp) {
+            // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
+            SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, dst));
+            SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, (int)logG_, (int)rank_));
+        }
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
+    }
+    const double host_ms = wall_ms() - t0;
+    if (segment == 0) SP_TRY(launch_aux_presort());   // every column is behind this point of the compute stream
+    int rc;
+    if (sharded_interp) rc = commit_segment_resident(segment, cols, root_out);
+    else {
+        rc = commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out);
+        if (rc == SP_OK) stage_ = segment == 0 ? 2 : 3;
+    }
+    if (rc == SP_OK) SP_TRY(finish_upload_stats(groups, (uint64_t)cols * n_ * 32, 0.0, host_ms, 2));
+    return rc;
 }
 
 // A few parked host threads for the column gathers of the upload pipeline (creating them per group would put ~5 ms of
@@ -450,11 +546,8 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const size_t chunk = (size_t)n_ * gc * 32;
     if (UPLOAD_SLOTS * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
     if (!pool_) pool_ = new HostPool(std::min(c_->opt_upload_threads, std::max(1u, std::thread::hardware_concurrency())) - 1u);   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
-    if (!copy_stream_) {
-        SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
-        for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
-    }
-    SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
+    const uint32_t groups = (uint32_t)gsize.size();
+    SP_TRY(ensure_upload(groups));
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
         stage_bytes_ = 0;
@@ -466,27 +559,38 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
+    const double t0 = wall_ms();
+    double gather_ms = 0;
+    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
     uint32_t c0 = 0;
-    for (uint32_t g = 0; g < gsize.size(); c0 += gsize[g], ++g) {
+    for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
         const uint32_t w = gsize[g], slot = g % UPLOAD_SLOTS;
         if (g >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));       // the pinned slot has crossed PCIe
+        const double tg = wall_ms();
         host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
+        gather_ms += wall_ms() - tg;
         // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the group has been
         // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the upload
         // stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
         SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)n_ * w * 32, hipMemcpyHostToDevice, copy_stream_));
         SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
         SP_TRY(rows_to_columns(copy_stream_, c_->enc, landing[slot], n_, w, trace + (uint64_t)c0 * n_, n_));
         SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
         SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_r2c_[slot], 0));
         // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
         SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
     }
+    const double host_ms = wall_ms() - t0;
     if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;
-    return SP_OK;
+    return finish_upload_stats(groups, (uint64_t)cols * n_ * 32, gather_ms, host_ms, 1);
 }
 
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.
@@ -1540,7 +1644,8 @@ static void serialize_proof(uint64_t n, const std::vector<std::array<uint8_t, 32
 }
 
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
-                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device) {
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5],
+                StarkProver::TraceSource src, int col_enc, uint64_t col_stride) {
     try {
         CairoAirInfo air = cairo_air_info(pub);
         if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
@@ -1566,7 +1671,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         P->request_aux_presort(pub);                    // the sorts of the auxiliary trace: beside round 1 too
         if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
             SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
-        SP_TRY(P->commit_trace(0, main_trace, cols, root, trace_on_device));
+        SP_TRY(P->commit_trace(0, main_trace, cols, root, src, col_enc, col_stride));
         uint8_t main_root[32]; std::memcpy(main_root, root, 32);
         SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");
         tr.append(root, 32);
@@ -1680,7 +1785,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         uint8_t root[32];
         std::vector<std::array<uint8_t, 32>> roots;
         // ---- round 1 (reference prover.rs:187-224)
-        SP_TRY(P->commit_trace(0, main_trace, air.main_cols, root, false));
+        SP_TRY(P->commit_trace(0, main_trace, air.main_cols, root));
         roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
         tr.append(root, 32);
         std::vector<fe> rap(air.n_rap);
@@ -1691,7 +1796,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
             std::vector<uint8_t> rap_bytes(std::max<size_t>(1, rap.size()) * 32), aux_rows((size_t)n * air.aux_cols * 32);
             if (!rap.empty()) SP_TRY(sp_fe_from_device(ctx->enc, reinterpret_cast<const uint8_t*>(rap.data()), rap.size(), rap_bytes.data()));
             if (air.aux_fn(air.aux_user, rap_bytes.data(), (uint32_t)rap.size(), aux_rows.data()) != 0) { sp_set_error("air_prove: the auxiliary-trace callback failed"); return SP_E_INVALID_ARG; }
-            SP_TRY(P->commit_trace(1, aux_rows.data(), air.aux_cols, root, false));
+            SP_TRY(P->commit_trace(1, aux_rows.data(), air.aux_cols, root));
             roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
             tr.append(root, 32);
         } else if (air.aux_cols) {
@@ -1717,7 +1822,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
                 if (ctx->enc == SP_FE_CANON_BE) fe_to_bytes_be(zacc, &aux_rows[(size_t)i * 32]);
                 else { uint64_t l[4]; fe_to_lw_limbs(zacc, l); std::memcpy(&aux_rows[(size_t)i * 32], l, 32); }
             }
-            SP_TRY(P->commit_trace(1, aux_rows.data(), 1, root, false));
+            SP_TRY(P->commit_trace(1, aux_rows.data(), 1, root));
             roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
             tr.append(root, 32);
         }

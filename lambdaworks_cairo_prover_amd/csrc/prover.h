@@ -45,7 +45,11 @@ class StarkProver : public sp_deletable {
     int setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
     // round 1: interpolate + LDE + Merkle of one trace segment (0 = main, 1 = aux); rows = row-major n x cols, ABI encoding
     // rows_on_device: `rows` is device memory (same row-major ABI encoding) — no PCIe copy inside the round
-    int commit_trace(int segment, const uint8_t* rows, uint32_t cols, uint8_t root_out[32], bool rows_on_device = false);
+    // src = TRACE_HOST_COLUMNS: column-major [cols][n] host memory (column j at src + j * col_stride * 32; col_stride 0 = n), in the
+    // DEVICE layout (col_enc < 0) or an ABI encoding (col_enc = sp_fe_encoding): every column group is one DMA, no host gather
+    enum TraceSource { TRACE_HOST_ROWS = 0, TRACE_DEVICE_ROWS = 1, TRACE_HOST_COLUMNS = 2 };
+    int commit_trace(int segment, const uint8_t* rows, uint32_t cols, uint8_t root_out[32], TraceSource src = TRACE_HOST_ROWS,
+                     int col_enc = -1, uint64_t col_stride = 0);
     // round 1, Cairo auxiliary segment built on the device from the resident main trace (reference cairo/air.rs:660-729)
     int commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]);
     // round 2: constraint composition, H1/H2 split, LDE and commitment
@@ -107,6 +111,15 @@ class StarkProver : public sp_deletable {
     }
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    int commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]);
+    // upload pipeline bookkeeping (sp_last_upload_stats): per column group the DMA interval on the copy stream, the moment the
+    // group is usable and the moment the compute stream is done with it
+    static constexpr int UPLOAD_MAX_GROUPS = 48;
+    struct UploadTimers { hipEvent_t dma0 = nullptr, dma1 = nullptr, ready = nullptr, done = nullptr; };
+    UploadTimers up_ev_[UPLOAD_MAX_GROUPS];
+    hipEvent_t up_start_ = nullptr;
+    int ensure_upload(uint32_t groups);
+    int finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind);
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
     static constexpr int UPLOAD_SLOTS = 3;                    // the gather may run two groups ahead of the DMA
     hipEvent_t ev_dma_[UPLOAD_SLOTS] = {}, ev_r2c_[UPLOAD_SLOTS] = {};
@@ -213,7 +226,8 @@ class StarkProver : public sp_deletable {
 // Whole proof on the device: generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + serialize
 // (src/starks/proof/stark.rs:161-218). main_trace: row-major n x cols in the context encoding.
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
-                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5], bool trace_on_device = false);
+                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5],
+                StarkProver::TraceSource src = StarkProver::TRACE_HOST_ROWS, int col_enc = -1, uint64_t col_stride = 0);
 // Whole proof for an AIR given as a constraint program: `prove::<F, A>` (reference src/starks/prover.rs:532-766) + serialize.
 // main_trace: row-major n x air.main_cols in the context encoding (host memory).
 int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, uint64_t n, const ProofOptionsHost& opt,

@@ -129,3 +129,30 @@ def test_larger_than_config3_proves_and_verifies(hip_ctx):
     bad = bytearray(proof)
     bad[200] ^= 0x80
     assert not api.cairo_verify(bytes(bad), run.public_inputs_c, opt)
+
+
+def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
+    """The three host-side forms of the main trace - the reference's row-major table (sp_cairo_prove, gathered into column
+    groups by host threads), host columns in the ABI encoding (sp_cairo_prove_columns) and the run's own page-locked
+    device-layout columns (sp_cairo_prove_run, plain DMA) - give the bytes of the device-resident call and of the oracle."""
+    run = api.CairoRun.fibonacci(9000)          # 2^16 rows x 34 columns = 71 MB: above the threshold of the upload pipeline
+    assert run.n_rows == 1 << 16
+    opt = api.ProofOptions(4, 5, 3, 8)
+    trace = run.main_trace()
+    want = oracle.cairo_prove(trace, run.public_inputs_c, (4, 5, 3, 8))
+    rows = hip_ctx.cairo_prove(trace, run.public_inputs_c, opt)
+    st_rows = hip_ctx.last_upload_stats()
+    assert rows == want
+    assert st_rows["kind"].startswith("row-major") and st_rows["groups"] > 3 and st_rows["bytes"] == trace.nbytes
+    by_run = hip_ctx.cairo_prove_run(run, opt)
+    st_run = hip_ctx.last_upload_stats()
+    assert by_run == want
+    assert st_run["kind"].startswith("host columns") and st_run["bytes"] == trace.nbytes and st_run["gather_ms"] == 0
+    addr, n, c, pinned = run.columns()
+    assert (n, c) == (run.n_rows, run.n_cols) and pinned
+    cols_be = np.ascontiguousarray(trace.transpose(1, 0, 2))          # (cols, n, 32) canonical big-endian, pageable
+    assert hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt) == want
+    # a strided column store (the columns of a wider table) in the device layout
+    wide = np.zeros((c, n + 64, 32), dtype=np.uint8)
+    wide[:, :n] = api.fe_to_device(cols_be.reshape(-1, 32)).reshape(c, n, 32)
+    assert hip_ctx.cairo_prove_columns(wide, n, c, run.public_inputs_c, opt, col_stride=n + 64, device_layout=True) == want

@@ -84,3 +84,19 @@ def test_dump_parsers_reject_truncated_files(hip_lib):
         api.CairoRun.from_dumps(trace[:-1], memory, program_size=5)
     with pytest.raises(api.SpError):   # IncorrectNumberOfBytes (cairo_mem.rs:105-118)
         api.CairoRun.from_dumps(trace, memory[:-1], program_size=5)
+
+
+def test_run_column_store_matches_the_row_major_trace():
+    """sp_cairo_run_columns: the run's own store is the column-major device-layout form of sp_cairo_run_main_trace."""
+    import ctypes
+    import numpy as np
+    from lambdaworks_cairo_prover_amd import api
+    run = api.CairoRun.fibonacci(300)
+    addr, n, c, _pinned = run.columns()
+    assert (n, c) == (run.n_rows, run.n_cols)
+    raw = np.frombuffer(ctypes.string_at(addr, n * c * 32), dtype=np.uint8).reshape(c, n, 32)
+    be = api.fe_from_device(raw.reshape(-1, 32)).reshape(c, n, 32)
+    assert np.array_equal(be.transpose(1, 0, 2), run.main_trace())
+    # the lambdaworks limb encoding of the same table
+    lw = run.main_trace(api.SP_FE_MONT_LIMBS)
+    assert np.array_equal(api.fe_to_device(lw.reshape(-1, 32), api.SP_FE_MONT_LIMBS).reshape(n, c, 32), raw.transpose(1, 0, 2))

@@ -21,8 +21,15 @@ for it in range(6):
         print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms, device rounds {['%.1f' % x for x in ctx.last_round_ms()]} ms", flush=True)
         continue
     t2 = time.time(); p3 = ctx.cairo_prove(tr, run.public_inputs_c, opt); t3 = time.time()
+    up_rows = ctx.last_upload_stats()
+    t4 = time.time(); p4 = ctx.cairo_prove_run(run, opt); t5 = time.time()
+    up_run = ctx.last_upload_stats()
     if it >= 3:
-        print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms   from host buffer {1e3*(t3-t2):.1f} ms   (same bytes: {p2 == p3 == proof})", flush=True)
+        print(f"warm[{it}]: resident {1e3*(t1-t0):.1f} ms   from host rows {1e3*(t3-t2):.1f} ms   from the run's pinned columns {1e3*(t5-t4):.1f} ms"
+              f"   (same bytes: {p2 == p3 == p4 == proof})", flush=True)
+        if it == 5:
+            print("  upload, host rows:", up_rows, flush=True)
+            print("  upload, run columns:", up_run, flush=True)
 if len(sys.argv) > 5:
     import oracle_lib as O
     t0 = time.time(); ok = O.cairo_verify(proof, run.public_inputs_c, (b, q, 3, g)); print("oracle verify:", ok, f"{time.time()-t0:.1f}s")
