@@ -61,6 +61,9 @@ typedef int (*sp_allgather_fn)(void* user, const void* send_dev, void* recv_dev,
 const char* sp_version(void);
 const char* sp_last_error(void);          /* thread-local description of the last failure */
 int sp_device_count(int* count_out);      /* number of visible HIP devices (0 without a GPU) */
+/* CPUs the host side of the library may really use: hardware threads cut down by the affinity mask and the cgroup CPU quota
+ * (what sizes the gather threads of sp_cairo_prove and the front-end's trace builder). */
+int sp_host_cpus(int* count_out);
 
 int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
 void sp_ctx_destroy(sp_ctx* ctx);

@@ -224,6 +224,13 @@ class Context:
         check(self._lib.sp_sync(self._h))
 
 
+def host_cpus():
+    """sp_host_cpus: hardware threads cut down by the affinity mask and the cgroup CPU quota."""
+    n = ctypes.c_int()
+    check(_lib.load().sp_host_cpus(ctypes.byref(n)))
+    return n.value
+
+
 def fe_to_device(values_be, fe_encoding=SP_FE_CANON_BE):
     """ABI-encoded (n, 32) array -> device layout bytes (8 x u32 little-endian Montgomery), on the host."""
     a = np.ascontiguousarray(values_be, dtype=np.uint8).reshape(-1, 32)

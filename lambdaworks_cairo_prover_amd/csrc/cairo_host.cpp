@@ -4,6 +4,10 @@
 #include <cstring>
 #include <stdexcept>
 #include <thread>
+#include <atomic>
+#include <sched.h>
+#include <cstdio>
+#include <cmath>
 #include <cstdlib>
 #include <exception>
 #include <new>
@@ -103,24 +107,71 @@ void TraceColumns::release() {
     if (data) { if (pinned) (void)hipHostFree(data); else std::free(data); }
     data = nullptr; n_rows = n_cols = 0; pinned = false;
 }
+static std::atomic<int> g_hip_in_use{0};
+void hip_runtime_mark_in_use() { g_hip_in_use.store(1); }
+bool hip_runtime_in_use() { return g_hip_in_use.load() != 0; }
+
+static void* alloc_pinned(size_t bytes) {
+    void* p = nullptr;
+    const char* env = std::getenv("SP_HOST_PINNED");
+    if (env && env[0] == '0') return nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) return p;
+    (void)hipGetLastError();
+    return nullptr;
+}
 void TraceColumns::allocate(size_t rows, size_t cols) {
     release();
     const size_t bytes = std::max<size_t>(rows * cols * sizeof(fe), 64);
-    void* p = nullptr;
-    // page-locked when a device is there (the upload of a column group is then a plain DMA); SP_HOST_PINNED=0 turns it off
-    const char* env = std::getenv("SP_HOST_PINNED");
-    if (!(env && env[0] == '0') && hipHostMalloc(&p, bytes, hipHostMallocDefault) == hipSuccess && p) pinned = true;
-    else {
-        (void)hipGetLastError();
-        p = nullptr;
-        if (posix_memalign(&p, 4096, bytes) != 0 || !p) throw std::bad_alloc();
-    }
+    // page-locked when this process already drives a device (the upload of a column group is then a plain DMA); a process that
+    // has not touched the GPU stays host-only here - try_pin() migrates the table when a prover first needs it
+    void* p = hip_runtime_in_use() ? alloc_pinned(bytes) : nullptr;
+    if (p) pinned = true;
+    else if (posix_memalign(&p, 4096, bytes) != 0 || !p) throw std::bad_alloc();
     data = static_cast<fe*>(p); n_rows = rows; n_cols = cols;
+}
+bool TraceColumns::try_pin() {
+    if (pinned || !data) return pinned;
+    const size_t bytes = std::max<size_t>(n_rows * n_cols * sizeof(fe), 64);
+    uint8_t* p = static_cast<uint8_t*>(alloc_pinned(bytes));
+    if (!p) return false;
+    const uint8_t* src = reinterpret_cast<const uint8_t*>(data);
+    host_parallel_for(bytes, 1 << 22, [&](size_t b, size_t e) { std::memcpy(p + b, src + b, e - b); });
+    std::free(data);
+    data = reinterpret_cast<fe*>(p); pinned = true;
+    return true;
+}
+
+// CPUs this process may really use: the hardware threads, cut down by the affinity mask and by the cgroup CPU quota (a container
+// on a 256-thread host is often limited to a few CPUs' worth of time per period; threads beyond the quota only get the whole
+// group throttled - the 100 ms stalls of an oversubscribed upload).
+unsigned host_effective_cpus() {
+    static const unsigned cached = [] {
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min<unsigned>(n, (unsigned)std::max(1, CPU_COUNT(&set)));
+        auto quota = [](const char* path_max, const char* path_quota, const char* path_period) -> double {
+            if (FILE* f = std::fopen(path_max, "r")) {                      // cgroup v2: "max 100000" or "<quota> <period>"
+                char q[64] = {0}; long long per = 0;
+                const int got = std::fscanf(f, "%63s %lld", q, &per);
+                std::fclose(f);
+                if (got == 2 && per > 0 && q[0] != 'm') return std::atof(q) / (double)per;
+                return 0.0;
+            }
+            long long qv = -1, pv = 0;                                      // cgroup v1
+            if (FILE* f = std::fopen(path_quota, "r")) { if (std::fscanf(f, "%lld", &qv) != 1) qv = -1; std::fclose(f); }
+            if (FILE* f = std::fopen(path_period, "r")) { if (std::fscanf(f, "%lld", &pv) != 1) pv = 0; std::fclose(f); }
+            return (qv > 0 && pv > 0) ? (double)qv / (double)pv : 0.0;
+        };
+        const double q = quota("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us");
+        if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max(1.0, std::floor(q + 0.5)));
+        return n;
+    }();
+    return cached;
 }
 
 void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
     static const unsigned max_threads = [] {
-        unsigned t = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+        unsigned t = std::min(64u, host_effective_cpus());
         if (const char* e = std::getenv("SP_HOST_THREADS")) { int v = std::atoi(e); if (v >= 1) t = (unsigned)std::min(v, 256); }
         return t;
     }();

@@ -57,12 +57,20 @@ struct TraceColumns {
     TraceColumns& operator=(const TraceColumns&) = delete;
     ~TraceColumns() { release(); }
     void allocate(size_t rows, size_t cols);   // throws std::bad_alloc
+    bool try_pin();                            // moves a pageable table into page-locked memory (false: the runtime has none to give)
     void release();
     fe& at(size_t row, size_t col) { return data[col * n_rows + row]; }
     const fe& at(size_t row, size_t col) const { return data[col * n_rows + row]; }
 };
 
-// fn(begin, end) over [0, n) on up to SP_HOST_THREADS (default: the hardware threads, at most 64) host threads
+// Set by sp_ctx_create: host-only entry points never initialise the HIP runtime by themselves (a process may want PyTorch's
+// copy of it to come first), so a run built before any context keeps its trace in ordinary memory.
+void hip_runtime_mark_in_use();
+bool hip_runtime_in_use();
+
+// hardware threads, affinity mask and cgroup CPU quota taken together
+unsigned host_effective_cpus();
+// fn(begin, end) over [0, n) on up to SP_HOST_THREADS (default: host_effective_cpus(), at most 64) host threads
 void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn);
 
 struct MemorySegment { uint8_t type; uint64_t start, end; };  // type 0 RangeCheck, 1 Output (air.rs:156-160)

@@ -1,6 +1,7 @@
 // C ABI: context and the fine-grained device entry points (sp_ntt, sp_lde, sp_merkle_build, sp_batch_inverse).
 // See include/stark252_hip.h for the reference call sites each one replaces.
 #include "ctx.h"
+#include "cairo_host.h"
 #include <rccl/rccl.h>
 #include <cstring>
 #include <vector>
@@ -44,6 +45,7 @@ int sp_ctx_create(sp_ctx** out, const sp_config* cfg) {
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->tev0) != hipSuccess || hipEventCreate(&c->tev1) != hipSuccess) { sp_ctx_destroy(c); return SP_E_HIP; }
     if (hipMalloc(&c->d_flag, sizeof(int)) != hipSuccess) { sp_ctx_destroy(c); return SP_E_ALLOC; }
+    sp::hip_runtime_mark_in_use();
     *out = c;
     return SP_OK;
 }
@@ -95,7 +97,7 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             break;
         case SP_OPT_SHARD_INTERPOLATION: c->opt_shard_interpolation = value != 0; break;
         case SP_OPT_UPLOAD_THREADS:
-            if (value < 1 || value > 64) return SP_E_INVALID_ARG;
+            if (value < 1 || value > 128) return SP_E_INVALID_ARG;
             c->opt_upload_threads = (uint32_t)value;
             break;
         default: sp_set_error("sp_set_option: unknown key"); return SP_E_INVALID_ARG;

@@ -59,6 +59,11 @@ extern "C" {
 
 const char* sp_version(void) { return "stark252-hip 0.1 (gfx950)"; }
 const char* sp_last_error(void) { return g_last_error.c_str(); }
+int sp_host_cpus(int* count_out) {
+    if (!count_out) return SP_E_INVALID_ARG;
+    *count_out = (int)sp::host_effective_cpus();
+    return SP_OK;
+}
 
 int sp_fe_to_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
     if (!in || !out) return SP_E_INVALID_ARG;
@@ -179,7 +184,7 @@ int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_
 int sp_host_alloc(uint64_t bytes, void** out) {
     if (!out) return SP_E_INVALID_ARG;
     *out = nullptr;
-    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {   // (initialises the HIP runtime: see INTEGRATION.md section 6 on PyTorch)
         (void)hipGetLastError();
         *out = nullptr;
         sp_set_error("sp_host_alloc: hipHostMalloc failed (" + std::to_string(bytes) + " bytes)");

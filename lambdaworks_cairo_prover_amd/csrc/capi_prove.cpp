@@ -171,7 +171,8 @@ int sp_cairo_prove_columns(sp_ctx* c, const uint8_t* main_trace_cols, uint64_t n
     } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_INVALID_ARG; }
 }
 int sp_cairo_prove_run(sp_ctx* c, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
-    if (!run) return SP_E_INVALID_ARG;
+    if (!run || !c) return SP_E_INVALID_ARG;
+    const_cast<TraceColumns&>(cairo_run_columns(run)).try_pin();   // a run built before this process had a context: migrate once
     const TraceColumns& T = cairo_run_columns(run);
     return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.data), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
                             proof_len, StarkProver::TRACE_HOST_COLUMNS, -1, T.n_rows);

@@ -1,6 +1,7 @@
 // Round-by-round STARK prover on the device (see prover.h). Host code only: it sequences kernels on the context
 // stream, keeps every polynomial / evaluation / tree resident in HBM and moves only roots, challenges and openings.
 #include "prover.h"
+#include "cairo_host.h"
 #include <array>
 #include "keccak.h"
 #include <algorithm>
@@ -16,6 +17,7 @@
 #include <condition_variable>
 #include <functional>
 #include <memory>
+#include <atomic>
 
 namespace sp {
 
@@ -466,60 +468,85 @@ class HostPool {
         for (unsigned w = 0; w < workers; ++w) threads_.emplace_back([this, w] { loop(w); });
     }
     ~HostPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; ++gen_; }
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1); }
         cv_.notify_all();
         for (auto& t : threads_) t.join();
     }
     unsigned size() const { return (unsigned)threads_.size() + 1; }
+    // Between begin_burst() and end_burst() idle workers spin on the generation counter instead of sleeping on the condition
+    // variable: the groups of one upload follow each other within a millisecond and a futex wake-up of 30-60 threads costs
+    // 50-100 us each time.
+    void begin_burst() { { std::lock_guard<std::mutex> lk(m_); burst_.store(true, std::memory_order_release); } cv_.notify_all(); }
+    void end_burst() { burst_.store(false, std::memory_order_release); }
     // runs job(part, parts) for part = 0 .. parts-1 (parts = workers + 1; the caller takes part 0) and waits for all of them
     void run(const std::function<void(unsigned, unsigned)>& job) {
-        { std::lock_guard<std::mutex> lk(m_); job_ = &job; pending_ = (unsigned)threads_.size(); ++gen_; }
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            job_ = &job; pending_.store((unsigned)threads_.size(), std::memory_order_relaxed);
+            gen_.fetch_add(1, std::memory_order_release);
+        }
         cv_.notify_all();
         job(0, size());
-        std::unique_lock<std::mutex> lk(m_);
-        done_.wait(lk, [this] { return pending_ == 0; });
+        // the parts are equal: the others finish within microseconds of the caller
+        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin) {
+            if (spin < 20000) { sp_cpu_relax(); continue; }
+            std::unique_lock<std::mutex> lk(m_);
+            done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
+        }
         job_ = nullptr;
     }
   private:
+    static void sp_cpu_relax() { __builtin_ia32_pause(); }
     void loop(unsigned w) {
         uint64_t seen = 0;
         for (;;) {
             const std::function<void(unsigned, unsigned)>* job;
+            // (bounded: a worker that finds nothing for ~0.3 ms goes back to sleep, so a stalled upload does not burn the cores)
+            for (int spin = 0; spin < 100000 && burst_.load(std::memory_order_acquire) && gen_.load(std::memory_order_acquire) == seen; ++spin) sp_cpu_relax();
             {
                 std::unique_lock<std::mutex> lk(m_);
-                cv_.wait(lk, [&] { return gen_ != seen; });
-                seen = gen_;
+                if (gen_.load(std::memory_order_acquire) == seen) {
+                    const bool was_burst = burst_.load(std::memory_order_acquire);
+                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || (!was_burst && burst_.load(std::memory_order_acquire)); });
+                    if (gen_.load(std::memory_order_acquire) == seen) continue;   // woken into a burst: go spinning
+                }
+                seen = gen_.load(std::memory_order_acquire);
                 if (stop_) return;
                 job = job_;
             }
             (*job)(w + 1, size());
-            { std::lock_guard<std::mutex> lk(m_); if (--pending_ == 0) done_.notify_one(); }
+            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m_); done_.notify_one(); }
         }
     }
     std::vector<std::thread> threads_;
     std::mutex m_;
     std::condition_variable cv_, done_;
     const std::function<void(unsigned, unsigned)>* job_ = nullptr;
-    unsigned pending_ = 0;
-    uint64_t gen_ = 0;
+    std::atomic<unsigned> pending_{0};
+    std::atomic<uint64_t> gen_{0};
+    std::atomic<bool> burst_{false};
     bool stop_ = false;
 };
 void host_pool_delete(HostPool* p) { delete p; }
 
-// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace, split over the pool
+// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace.  The rows are handed
+// out in blocks through a shared counter, so a thread that is slow (a busy core, a remote NUMA node, a throttled container)
+// takes fewer blocks instead of holding the whole group back.
 static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
-    pool.run([&](unsigned part, unsigned parts) {
-        const uint64_t per = (n + parts - 1) / parts, r0 = std::min<uint64_t>(n, part * per), r1 = std::min<uint64_t>(n, r0 + per);
-        const uint8_t* s = src + r0 * row_bytes + off;
-        uint8_t* d = dst + r0 * width;
-        // one or two field elements per row: fixed-size copies inline as vector moves (a libc memcpy call per 32 bytes costs more
-        // than the bytes it moves: 2.4x on a one-column group); wider groups are better off with memcpy
-        if (width == 32 || width == 64) {
+    const uint64_t block = std::max<uint64_t>(256, (256u << 10) / width);   // ~256 KB written per block
+    std::atomic<uint64_t> next{0};
+    pool.run([&](unsigned, unsigned) {
+        for (;;) {
+            const uint64_t r0 = next.fetch_add(block, std::memory_order_relaxed);
+            if (r0 >= n) return;
+            const uint64_t r1 = std::min<uint64_t>(n, r0 + block);
+            const uint8_t* s = src + r0 * row_bytes + off;
+            uint8_t* d = dst + r0 * width;
+            // fixed-size 32-byte copies inline as vector moves (a libc memcpy call per row costs more than the bytes it moves on
+            // narrow groups)
             const size_t units = width / 32;
             for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width)
                 for (size_t u = 0; u < units; ++u) __builtin_memcpy(d + 32 * u, s + 32 * u, 32);
-        } else {
-            for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width) std::memcpy(d, s, width);
         }
     });
 }
@@ -536,16 +563,22 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // of what is already on the device (1, 1, 1, 2, 2, 3, 4, 5, 7, 8 for 34 columns), eight columns at most.
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(1, done / 3 + 1));
-        if (cols - done - w < 2) w = cols - done;     // no one-column tail
-        w = std::min(w, cols - done);
+        static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 3u; }();
+        static const uint32_t maxw = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 8u; }();
+        // two columns share a 64-byte line of the row-major table (rows are cols x 32 bytes): after the two single columns that
+        // start the pipeline every group begins on an even column and takes an even number of them, so the gather reads whole
+        // lines (a two-column group on an odd boundary moved 39 GB/s where an aligned one moves 58)
+        uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done / grow + 1) / 2)));
+        if (cols - done <= w + 1) w = cols - done;     // no one-column tail
         gsize.push_back(w);
         done += w;
     }
     const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
     const size_t chunk = (size_t)n_ * gc * 32;
     if (UPLOAD_SLOTS * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
-    if (!pool_) pool_ = new HostPool(std::min(c_->opt_upload_threads, std::max(1u, std::thread::hardware_concurrency())) - 1u);   // 8 gather threads saturate the copy (profiles/r02_upload_paths.txt)
+    // gather threads: the option, but never more than the CPUs this process can really have minus the two that poll the stream
+    // and run the HIP runtime's own threads (a 16-CPU container quota on a 256-thread host throttles everything beyond it)
+    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, host_effective_cpus() > 3 ? host_effective_cpus() - 2 : 2u)) - 1u);
     const uint32_t groups = (uint32_t)gsize.size();
     SP_TRY(ensure_upload(groups));
     if (stage_bytes_ < chunk) {
@@ -561,15 +594,20 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     const double t0 = wall_ms();
     double gather_ms = 0;
+    struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
+    pool_->begin_burst();
     SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
     uint32_t c0 = 0;
     for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
         const uint32_t w = gsize[g], slot = g % UPLOAD_SLOTS;
+        const double tw = wall_ms();
         if (g >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));       // the pinned slot has crossed PCIe
         const double tg = wall_ms();
         host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
         gather_ms += wall_ms() - tg;
+        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   group %2u: %u columns, waited %.3f ms for the slot, gather %.3f ms (%.1f GB/s)\n", g, w, tg - tw,
+                                           wall_ms() - tg, (double)n_ * w * 32 / (wall_ms() - tg) * 1e-6);
         // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the group has been
         // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the upload
         // stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)

@@ -149,7 +149,7 @@ def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
     assert by_run == want
     assert st_run["kind"].startswith("host columns") and st_run["bytes"] == trace.nbytes and st_run["gather_ms"] == 0
     addr, n, c, pinned = run.columns()
-    assert (n, c) == (run.n_rows, run.n_cols) and pinned
+    assert (n, c) == (run.n_rows, run.n_cols) and pinned          # (built after the context existed, or migrated by the call above)
     cols_be = np.ascontiguousarray(trace.transpose(1, 0, 2))          # (cols, n, 32) canonical big-endian, pageable
     assert hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt) == want
     # a strided column store (the columns of a wider table) in the device layout
