@@ -35,16 +35,34 @@ def per_kernel(path, counter):
 def main():
     fpath, wpath, log_n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     f, w = per_kernel(fpath, "FETCH_SIZE"), per_kernel(wpath, "WRITE_SIZE")
-    passes = {k: v for k, v in f.items() if "ntt_pass_kernel" in k}
-    # every NTT of the run launches each of its pass kernels the same number of times: launches of the first pass = NTTs
-    ntts = min(c for c, _ in passes.values())
-    launches = sum(c for c, _ in passes.values()) / ntts
-    fetch_kb = sum(t for _, t in passes.values()) / ntts
-    write_kb = sum(t for k, (_, t) in w.items() if "ntt_pass_kernel" in k) / ntts
+    fp = {k: v for k, v in f.items() if "ntt_pass_kernel" in k}
+    wp = {k: v for k, v in w.items() if "ntt_pass_kernel" in k}
+    assert fp and set(fp) == set(wp), "the two PMC passes must have run the same pass kernels"
+
+    def launches_per_ntt(passes):
+        # every NTT launches each of its pass kernels a fixed number of times: transforms of the run = the smallest dispatch count
+        # (bench.py's warm_until() runs a different number of transforms under each profiler pass, so each pass is normalised by
+        # ITS OWN count - dividing the WRITE_SIZE total by the FETCH pass's count was the 1.28 GB bug of round 2)
+        ntts = min(c for c, _ in passes.values())
+        mult = {}
+        for k, (c, _) in passes.items():
+            assert c % ntts == 0, f"{k}: {c} dispatches is not a multiple of {ntts} transforms"
+            mult[k] = c // ntts
+        return ntts, mult
+
+    ntts_f, mult_f = launches_per_ntt(fp)
+    ntts_w, mult_w = launches_per_ntt(wp)
+    assert mult_f == mult_w, (mult_f, mult_w)
+    launches = sum(mult_f.values())
+    fetch_kb = sum(mult_f[k] * t / c for k, (c, t) in fp.items())     # per-dispatch average x dispatches per transform
+    write_kb = sum(mult_w[k] * t / c for k, (c, t) in wp.items())
+    passes = fp
     res = {
         "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `bench.py --proof 0 --steps 20 --warmup 3`",
         "log_n": log_n,
         "launches_per_ntt": launches,
+        "transforms_in_fetch_pass": ntts_f,
+        "transforms_in_write_pass": ntts_w,
         "fetch_size_kb_per_ntt": fetch_kb,
         "write_size_kb_per_ntt": write_kb,
         "ntt_source_sha16": ntt_source_sha16(),
@@ -53,7 +71,10 @@ def main():
                       "report 0.5 GiB, writes report 1:1).  The figure includes the twiddle fetches (32-byte gathers, mostly served by "
                       "L2 / the 256 MiB infinity cache, which FETCH_SIZE counts).",
         "traffic_bytes_per_ntt": (2 * fetch_kb + write_kb) * 1024,
-        "per_kernel_fetch_kb_avg": {k: t / c for k, (c, t) in passes.items()},
+        "traffic_over_algorithmic": (2 * fetch_kb + write_kb) * 1024 / (64.0 * (1 << log_n)),
+        "per_kernel_fetch_kb_avg": {k: t / c for k, (c, t) in fp.items()},
+        "per_kernel_write_kb_avg": {k: t / c for k, (c, t) in wp.items()},
+        "per_kernel_launches_per_ntt": mult_f,
     }
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
