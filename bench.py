@@ -38,8 +38,8 @@ VALU_BUTTERFLY_CEILING = 1.72e11
 MAD_ISSUE_NS = 2.299
 MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
 VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_ntt22_traffic.json")
-MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_merkle_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_ntt22_traffic.json")
+MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_merkle_traffic.json")
 
 
 def ntt_source_sha16():
@@ -54,6 +54,16 @@ def merkle_source_sha16():
     for f in ("merkle.hip", "merkle.h", "keccak.h", "fp.h"):
         h.update(open(os.path.join(ROOT, "lambdaworks_cairo_prover_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
+
+
+def host_cpus():
+    """CPUs this process may really use (sp_host_cpus: hardware threads cut down by the affinity mask and the cgroup CPU quota -
+    the GPU boxes of the pool give a container 16 CPUs' worth of time on a 256-thread host)."""
+    try:
+        from lambdaworks_cairo_prover_amd import api
+        return max(1, api.host_cpus())
+    except Exception:
+        return os.cpu_count() or 1
 
 
 def cpu_model():
@@ -90,7 +100,7 @@ def cpu_baseline(log_n=22):
     rng = np.random.default_rng(1)
     x = rng.integers(0, 256, size=(n, 32), dtype=np.uint8)
     x[:, 0] &= 0x07
-    cores = os.cpu_count() or 1
+    cores = host_cpus()
     out = (ctypes.c_double * 3)()
     xp = x.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
     lib.oracle_ntt_bench(xp, ctypes.c_uint64(1 << 12), 1, 1, out)          # load + warm
@@ -101,9 +111,11 @@ def cpu_baseline(log_n=22):
     allc = (n // 2) * log_n * vectors / out[1]
     return {"value": one, "unit": "butterflies/s", "cores": 1, "kind": "port",
             "sample": f"2 x forward NTT 2^{log_n} in the oracle's field representation, single thread (codec excluded)",
-            "codec_s_per_vector": codec_s, "cpu_model": cpu_model(), "nproc": cores,
+            "codec_s_per_vector": codec_s, "cpu_model": cpu_model(), "nproc": os.cpu_count() or 1, "usable_cpus": cores,
             "all_cores": {"value": allc, "unit": "butterflies/s", "cores": vectors,
-                          "sample": f"{vectors} x forward NTT 2^{log_n}, one vector per thread (OpenMP)"}}
+                          "sample": f"{vectors} x forward NTT 2^{log_n}, one vector per thread (OpenMP): {vectors} threads of the "
+                                    f"{cores} CPUs this process may use (affinity mask and cgroup CPU quota) on a host with "
+                                    f"{os.cpu_count()} hardware threads"}}
 
 
 def merkle_roofline(torch, ctx, dev, log_leaves=23, cols=34, reps=5):
@@ -150,7 +162,7 @@ def cpu_proof_sample(api, ctx):
     the device prover on that very input; the two proofs must be the same bytes."""
     import ctypes
     import oracle_lib as oracle
-    cores = os.cpu_count() or 1
+    cores = host_cpus()
     try:
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
     except OSError:
@@ -176,7 +188,7 @@ def cpu_proof_child(args):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib as oracle
     from lambdaworks_cairo_prover_amd import api
-    cores = os.cpu_count() or 1
+    cores = host_cpus()
     try:
         ctypes.CDLL("libgomp.so.1").omp_set_num_threads(cores)
     except OSError:
@@ -188,7 +200,7 @@ def cpu_proof_child(args):
     proof = oracle.cairo_prove(trace, run.public_inputs_c, (blowup, 80, 3, 20))
     ms = (time.perf_counter() - t0) * 1e3
     with open(args.cpu_proof_child, "w") as f:
-        json.dump({"cpu_ms": ms, "cores": cores, "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof), "trace_rows": run.n_rows}, f)
+        json.dump({"cpu_ms": ms, "cores": cores, "nproc": os.cpu_count() or 1, "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof), "trace_rows": run.n_rows}, f)
 
 
 def cpu_proof_cfg4(args, device_proof):
@@ -198,7 +210,7 @@ def cpu_proof_cfg4(args, device_proof):
     os.close(fd)
     os.unlink(path)
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-proof-child", path, "--cpu-proof-shape", str(args.cfg4_fib), str(args.cfg4_blowup)]
-    child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    child = subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, env=dict(os.environ, SP_HOST_PINNED="0"))
     base = {"sample": f"whole proof, fib({args.cfg4_fib}) program, blowup {args.cfg4_blowup}, 80 queries, grinding 20 (configs[3], full size)",
             "kind": "port", "cpu_model": cpu_model(), "budget_s": args.cpu_proof_budget}
     try:
@@ -219,6 +231,51 @@ def cpu_proof_cfg4(args, device_proof):
         base["gpu_ms_same_input"] = device_proof.get("proof_gen_ms_from_host_buffer")
         base["identical_bytes"] = device_proof["proof_sha256"] == res["proof_sha256"]
     return base
+
+
+def cold_child(args):
+    """Child of cold_start: a fresh process proves once - context, setup, upload pipeline and all (the reference CLI proves once
+    per process, src/main.rs:85-108) - then twice more; result as JSON on a file."""
+    t_imp = time.perf_counter()
+    import torch
+    torch.cuda.init()
+    from lambdaworks_cairo_prover_amd import api
+    t_imp = (time.perf_counter() - t_imp) * 1e3
+    fib, blowup = args.cold_shape
+    opt = api.ProofOptions(blowup, 80, 3, 20)
+    t0 = time.perf_counter()
+    ctx = api.Context()
+    t_ctx = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    run = api.CairoRun.fibonacci(fib)
+    t_run = (time.perf_counter() - t0) * 1e3
+    trace = run.main_trace() if args.cold_path == "rows" else None
+    ms = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        proof = ctx.cairo_prove(trace, run.public_inputs_c, opt) if args.cold_path == "rows" else ctx.cairo_prove_run(run, opt)
+        ms.append((time.perf_counter() - t0) * 1e3)
+    with open(args.cold_child, "w") as f:
+        json.dump({"first_call_ms": ms[0], "second_call_ms": ms[1], "third_call_ms": ms[2], "context_create_ms": t_ctx,
+                   "front_end_run_ms": t_run, "import_torch_and_library_ms": t_imp, "proof_sha256": hashlib.sha256(proof).hexdigest()}, f)
+    ctx.close()
+
+
+def cold_start(args, fib, blowup, path):
+    """First proof of a fresh process through `path` ("rows": sp_cairo_prove on a pageable row-major table, "run":
+    sp_cairo_prove_run): first_call_ms includes sp_prove_setup's allocations and tables, the upload pipeline's threads and pinned
+    ring and every first kernel launch; context_create_ms (the library's HIP runtime and code objects) is reported beside it."""
+    fd, out = tempfile.mkstemp(prefix="sp_cold_", suffix=".json")
+    os.close(fd)
+    os.unlink(out)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cold-child", out, "--cold-shape", str(fib), str(blowup), "--cold-path", path]
+    try:
+        rc = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120).returncode
+        res = json.load(open(out))
+        os.unlink(out)
+        return res
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def proof_benchmark(api, ctx, fib, blowup, world, dist):
@@ -251,21 +308,35 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
             dt = float(t.item())
         times.append(dt)
     rounds_dev = ctx.last_round_ms()
-    host_ms = []
-    ctx.cairo_prove(trace, run.public_inputs_c, opt)        # (first call: pinned staging buffers, gather threads)
+    host_ms, run_ms, up_rows, up_run = [], [], None, None
+    ctx.cairo_prove(trace, run.public_inputs_c, opt)        # (first call: pinned staging ring, gather threads)
+    ctx.cairo_prove_run(run, opt)
     for _ in range(4):
         if dist is not None:
             dist.barrier()
         t0 = time.perf_counter()
         proof_h = ctx.cairo_prove(trace, run.public_inputs_c, opt)
         host_ms.append((time.perf_counter() - t0) * 1e3)
-    assert proof_h == proof
+        if host_ms[-1] == min(host_ms):
+            up_rows = ctx.last_upload_stats()
+        if dist is not None:
+            dist.barrier()
+        t0 = time.perf_counter()
+        proof_r = ctx.cairo_prove_run(run, opt)
+        run_ms.append((time.perf_counter() - t0) * 1e3)
+        if run_ms[-1] == min(run_ms):
+            up_run = ctx.last_upload_stats()
+    assert proof_h == proof and proof_r == proof
     return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": rounds_dev, "trace_rows": run.n_rows,
             "trace_cols": 52, "blowup": blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
-            "proof_gen_ms_from_host_buffer": min(host_ms),
-            "note": "wall time of sp_cairo_prove_dev (main trace resident in HBM); the *_from_host_buffer figure is sp_cairo_prove, "
-                    "the drop-in call, PCIe upload of the trace included"}
+            "proof_gen_ms_from_host_buffer": min(host_ms), "proof_gen_ms_from_host_buffer_all": host_ms, "upload": up_rows,
+            "proof_gen_ms_from_run": min(run_ms), "proof_gen_ms_from_run_all": run_ms, "upload_run": up_run,
+            "note": "proof_gen_ms: wall time of sp_cairo_prove_dev (main trace resident in HBM).  *_from_host_buffer: sp_cairo_prove, the "
+                    "drop-in call on the reference's row-major TraceTable in pageable memory (host threads gather column groups into a "
+                    "pinned ring, DMA, transforms of the groups overlapped).  *_from_run: sp_cairo_prove_run, the front-end's own "
+                    "page-locked column-major trace (plain DMA per column group).  upload / upload_run: sp_last_upload_stats of the "
+                    "fastest of those calls - exposed_ms is how long the compute stream waited for column groups"}
 
 
 def _free_port():
@@ -411,9 +482,15 @@ def main():
     ap.add_argument("--cpu-proof-budget", type=int, default=150, help="seconds the CPU oracle may take for the full-size configs[3] proof (0: skip)")
     ap.add_argument("--cpu-proof-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-proof-shape", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cold-child", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cold-shape", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--cold-path", type=str, default="rows", help=argparse.SUPPRESS)
+    ap.add_argument("--no-cold-start", action="store_true", help="skip the first-proof-of-a-fresh-process measurements")
     args = ap.parse_args()
     if args.cpu_proof_child:
         return cpu_proof_child(args)
+    if args.cold_child:
+        return cold_child(args)
     if args.proof_child:
         return proof_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -515,6 +592,11 @@ def main():
             if world == 1:
                 out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
                 out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
+                if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
+                    for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
+                        cold = cold_start(args, fib, blowup, "rows")
+                        out[key]["first_call_ms"] = cold.get("first_call_ms")
+                        out[key]["first_call"] = {"sp_cairo_prove": cold, "sp_cairo_prove_run": cold_start(args, fib, blowup, "run")}
             else:
                 res = proof_isolated(args, rank, local_rank, world, dist)
                 if rank == 0:

@@ -46,8 +46,10 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
 // trace: public-memory substitution, the stable sort of the 4n accesses by address with the gather of the sorted (address,
 // value) pairs, and the sort of the 3n offsets.  A later cairo_aux_trace_device(..., presorted = true) on the same workspace
 // starts from there.  *flag_dev is set on malformed input like there.
+// The address sort looks at log2(8n) key bits only (the memory of a valid run is continuous); *wide_flag_dev is set when an
+// address lies beyond them - the presort's order is then not the stable order by address and the caller must not use it.
 int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                      uint64_t pm, int* flag_dev);
+                      uint64_t pm, int* flag_dev, int* wide_flag_dev);
 
 // In-place inclusive prefix product of M elements (block_tot: workspace of >= M/2048 + 2 elements).
 int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot);

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) aux_gather_kernel(const fe* a_aux, const 
 // ---- the same two steps split at the challenges: keys / sorted pairs first (cairo_aux_presort), numerators and
 // denominators once alpha and z are known
 __global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint64_t n, const fe* pm_addr, const fe* pm_val, uint64_t pm,
-                                                       fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag) {
+                                                       fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag, uint32_t key_bits, int* wide_flag) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= 4 * n) return;
     uint64_t i = e >> 2; uint32_t k = (uint32_t)e & 3;
@@ -71,7 +71,9 @@ __global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint6
     ax_st(a_aux + e, a); ax_st(v_aux + e, v);
     fe raw = fe_from_mont(a);
     if (raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 2);
-    keys[e] = (uint64_t)raw.v[0] | ((uint64_t)raw.v[1] << 32);
+    const uint64_t key = (uint64_t)raw.v[0] | ((uint64_t)raw.v[1] << 32);
+    if (key_bits < 64 && (key >> key_bits)) atomicExch(wide_flag, 1);   // beyond the bits the presort looks at: the caller sorts again, all 64
+    keys[e] = key;
     idx[e] = (uint32_t)e;
 }
 __global__ void __launch_bounds__(256) aux_gather_pairs_kernel(const fe* a_aux, const fe* v_aux, const uint32_t* idx, uint64_t M, fe* a_s, fe* v_s) {
@@ -263,7 +265,7 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
 }
 
 int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                      uint64_t pm, int* flag) {
+                      uint64_t pm, int* flag, int* wide_flag) {
     if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
     const uint64_t M = 4 * n, M3 = 3 * n;
     auto blocks = [](uint64_t x) { return dim3((unsigned)((x + 255) / 256)); };
@@ -271,9 +273,15 @@ int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint6
         SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
         SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
     }
-    hipLaunchKernelGGL(aux_keys_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag);
+    // The memory of a valid run is continuous (every address up to the largest is accessed, execution_trace.rs:195-255 fills the
+    // holes), so its 4n addresses are below 4n + |public memory|: the sort looks at log2(8n) key bits - three 8-bit digit passes
+    // at 2^20 rows instead of eight - and a key beyond them raises *wide_flag, on which the caller falls back to all 64.
+    uint32_t key_bits = 4;
+    while ((1ULL << key_bits) < 8 * n && key_bits < 64) ++key_bits;
+    hipLaunchKernelGGL(aux_keys_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag,
+                       key_bits, wide_flag);
     size_t tmp = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, 64, st));
+    SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, key_bits, st));
     hipLaunchKernelGGL(aux_gather_pairs_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
     hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
     size_t tmp2 = w.sort_tmp_bytes;

@@ -11,23 +11,7 @@ const TraceColumns& cairo_run_columns(const sp_cairo_run* run);
 using namespace sp;
 
 namespace {
-struct ProverHolder : public sp_deletable {
-    StarkProver prover;
-    Openings open;
-    std::vector<uint8_t> trace_evals, comp_evals, fri_evals, fri_evals_sym;
-    float round_ms[5] = {0, 0, 0, 0, 0};
-    explicit ProverHolder(sp_ctx* c) : prover(c) {}
-};
-
-ProverHolder* holder(sp_ctx* c, bool create) {
-    ProverHolder* h = dynamic_cast<ProverHolder*>(c->prover_state_deleter_holder);
-    if (!h && create) {
-        delete c->prover_state_deleter_holder;
-        h = new ProverHolder(c);
-        c->prover_state_deleter_holder = h;
-    }
-    return h;
-}
+ProverHolder* holder(sp_ctx* c, bool create) { return prover_holder(c, create); }
 int dec(sp_ctx* c, const uint8_t* in, uint64_t n, fe* out) { return sp_fe_to_device(c->enc, in, n, reinterpret_cast<uint8_t*>(out)); }
 int enc(sp_ctx* c, const fe* in, uint64_t n, uint8_t* out) { return sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(in), n, out); }
 

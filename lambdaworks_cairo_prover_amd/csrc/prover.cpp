@@ -131,6 +131,8 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     G_ = std::min<uint32_t>(world_, 1u << lb); logG_ = (uint32_t)sp_log2_exact(G_); rank_ = wrank_ & (G_ - 1);
     Nl_ = N_ >> logG_;
     if (G_ > 1 && N_ < 2ull * G_ * G_) { sp_set_error("setup: the LDE domain is too small for this many ranks"); return SP_E_INVALID_ARG; }
+    double _tp = wall_ms();
+    sp_ctx* ctx = c_;
     h_ = fe_from_u64(opt.coset_offset);
     if (fe_is_zero(h_)) return SP_E_INVALID_ARG;
     hinv_ = fe_inv(h_);
@@ -174,6 +176,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         d_fri_evals_.push_back(e);
         if (l < logn_) { TreeBuf t; SP_TRY(alloc_tree(t, M, fri_sharded(l))); fri_trees_.push_back(t); }
     }
+    SP_TIMEPOINT("  setup: device allocations");
     // T1[q] = n^-1 h^rev(q): turns the unscaled DIF output into h-scaled coefficients c_k h^k (bit-reversed order)
     fe ninv = fe_inv(fe_from_u64(n_));
     SP_TRY(gen_power_table(c_->stream, d_t1_, n_, logn_, h_, ninv));
@@ -201,6 +204,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
             SP_TRY(gen_power_table(c_->stream, d_post_comp0_ + n_, n_, logn_, hinv_, fe_mul(minv, hinv_)));
         }
     }
+    SP_TIMEPOINT("  setup: tables");
     ready_ = true;
     stage_ = 1;
     return SP_OK;
@@ -357,8 +361,8 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         return commit_trace_columns(segment, rows_host, cols, col_enc, col_stride ? col_stride : n_, root_out);
     }
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
-    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20) && (uint64_t)UPLOAD_SLOTS * 9 * n_ <= scratch_elems())
-        return commit_trace_pipelined(segment, rows_host, cols, root_out);   // (landing slots of up to nine columns each live in the scratch area)
+    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20))
+        return commit_trace_pipelined(segment, rows_host, cols, root_out);   // (the landing ring of the chunks lives in the scratch area)
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
@@ -551,35 +555,37 @@ static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, 
     });
 }
 
-// interpolate_and_commit (reference prover.rs:126-159) from a HOST buffer, in column groups: while group g is interpolated and
-// extended on the compute stream, group g + 1 crosses PCIe on a second stream and group g + 2 is gathered out of the
-// row-major trace into pinned memory by a few host threads.  The 1.1 GB upload of a 2^20 x 34 trace (22 ms at PCIe speed)
-// hides behind the transforms of the main segment instead of preceding them.
+// interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
+// in column groups: while group g is interpolated and extended on the compute stream, the chunks of the groups behind it are
+// gathered out of the table into a small ring of page-locked slots by a few host threads and cross PCIe on a second stream.
+// A chunk is two adjacent columns (one 64-byte line of every row) of a block of rows, 32 MB at most: the gather reads whole
+// lines, the DMA of one chunk runs beside the gather of the next whatever the size of the group, and the ring (4 x 32 MB) takes
+// a sixth of the time to pin that three group-sized slots did (56 ms of a first proof at 2^20 rows).
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.66 ms per column of 2^20 rows) and everything
-    // behind it still has to be transformed (~0.8 ms per column): the finish time is max_g [upload(0..g) + transform(g..)], i.e.
-    // a group may grow only as fast as the columns before it have bought time - small groups first, growing by about a fifth
-    // of what is already on the device (1, 1, 1, 2, 2, 3, 4, 5, 7, 8 for 34 columns), eight columns at most.
+    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything
+    // behind it still has to be transformed (~0.7 ms per column): the finish time is max_g [upload(0..g) + transform(g..)], i.e.
+    // a group may grow only as fast as the columns before it have bought time - small groups first, growing by about a third
+    // of what is already on the device, eight columns at most, always whole column pairs after the two single columns that
+    // start the pipeline (1, 1, 2, 2, 2, 2, 4, 4, 6, 8, 2 for 34 columns).
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
         static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 3u; }();
         static const uint32_t maxw = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 8u; }();
-        // two columns share a 64-byte line of the row-major table (rows are cols x 32 bytes): after the two single columns that
-        // start the pipeline every group begins on an even column and takes an even number of them, so the gather reads whole
-        // lines (a two-column group on an odd boundary moved 39 GB/s where an aligned one moves 58)
         uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done / grow + 1) / 2)));
         if (cols - done <= w + 1) w = cols - done;     // no one-column tail
         gsize.push_back(w);
         done += w;
     }
-    const uint32_t gc = *std::max_element(gsize.begin(), gsize.end());
-    const size_t chunk = (size_t)n_ * gc * 32;
-    if (UPLOAD_SLOTS * chunk > scratch_elems() * sizeof(fe)) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    const uint32_t groups = (uint32_t)gsize.size();
+    // chunk size: 32 MB, less when the scratch area (the landing ring on the device) is small
+    size_t chunk = std::min<size_t>((size_t)32 << 20, (scratch_elems() * sizeof(fe) / UPLOAD_SLOTS) & ~(size_t)4095);
+    if (chunk < (size_t)64 * 256) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    double _tp = wall_ms();
+    sp_ctx* ctx = c_;
     // gather threads: the option, but never more than the CPUs this process can really have minus the two that poll the stream
     // and run the HIP runtime's own threads (a 16-CPU container quota on a 256-thread host throttles everything beyond it)
     if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, host_effective_cpus() > 3 ? host_effective_cpus() - 2 : 2u)) - 1u);
-    const uint32_t groups = (uint32_t)gsize.size();
     SP_TRY(ensure_upload(groups));
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -592,41 +598,57 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
+    SP_TIMEPOINT("  upload: threads, streams, pinned slots");
     const double t0 = wall_ms();
     double gather_ms = 0;
     struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
     pool_->begin_burst();
     SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
+    uint64_t chunk_no = 0;
     uint32_t c0 = 0;
     for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
-        const uint32_t w = gsize[g], slot = g % UPLOAD_SLOTS;
-        const double tw = wall_ms();
-        if (g >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));       // the pinned slot has crossed PCIe
+        const uint32_t w = gsize[g];
         const double tg = wall_ms();
-        host_gather_columns(*pool_, rows_host, n_, (size_t)cols * 32, (size_t)c0 * 32, (size_t)w * 32, static_cast<uint8_t*>(h_stage_[slot]));
-        gather_ms += wall_ms() - tg;
-        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   group %2u: %u columns, waited %.3f ms for the slot, gather %.3f ms (%.1f GB/s)\n", g, w, tg - tw,
-                                           wall_ms() - tg, (double)n_ * w * 32 / (wall_ms() - tg) * 1e-6);
-        // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the group has been
-        // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the upload
-        // stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
+        double waited = 0;
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
-        SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)n_ * w * 32, hipMemcpyHostToDevice, copy_stream_));
-        SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
+        for (uint32_t cc = 0; cc < w; cc += 2) {                        // column pairs (a single column in the first two groups)
+            const uint32_t cw = std::min<uint32_t>(2, w - cc), c = c0 + cc;
+            const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk / ((size_t)cw * 32)) & ~(uint64_t)255);
+            for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk, ++chunk_no) {
+                const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
+                const uint32_t slot = (uint32_t)(chunk_no % UPLOAD_SLOTS);
+                const double tw = wall_ms();
+                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));   // the pinned slot has crossed PCIe
+                waited += wall_ms() - tw;
+                host_gather_columns(*pool_, rows_host + r0 * (size_t)cols * 32, rows, (size_t)cols * 32, (size_t)c * 32, (size_t)cw * 32,
+                                    static_cast<uint8_t*>(h_stage_[slot]));
+                // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the chunk has been
+                // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the
+                // upload stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
+                SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)rows * cw * 32, hipMemcpyHostToDevice, copy_stream_));
+                SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
+                SP_TRY(rows_to_columns(copy_stream_, c_->enc, landing[slot], rows, cw, trace + (uint64_t)c * n_ + r0, n_));
+            }
+        }
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        SP_TRY(rows_to_columns(copy_stream_, c_->enc, landing[slot], n_, w, trace + (uint64_t)c0 * n_, n_));
-        SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], copy_stream_));
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_r2c_[slot], 0));
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
+        const double tge = wall_ms();
+        gather_ms += tge - tg - waited;
+        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   group %2u: %u columns, waited %.3f ms for slots, gather + enqueue %.3f ms (%.1f GB/s)\n", g, w, waited,
+                                           tge - tg - waited, (double)n_ * w * 32 / (tge - tg - waited) * 1e-6);
         // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
         SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
     }
     const double host_ms = wall_ms() - t0;
+    SP_TIMEPOINT("  upload + transforms of the groups");
     if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
+    SP_TIMEPOINT("  aux presort queued (+ its workspace)");
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
+    SP_TIMEPOINT("  leaf hashing + tree");
     stage_ = segment == 0 ? 2 : 3;
     return finish_upload_stats(groups, (uint64_t)cols * n_ * 32, gather_ms, host_ms, 1);
 }
@@ -709,8 +731,8 @@ int StarkProver::launch_aux_presort() {
     if (!d_flag_side_) SP_TRY(alloc((void**)&d_flag_side_, 4 * sizeof(int)));
     SP_HIP_CHECK(hipEventRecord(ev_side_fork_, c_->stream));          // the main trace columns are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
-    SP_HIP_CHECK(hipMemsetAsync(d_flag_side_ + 2, 0, sizeof(int), side_stream_));
-    SP_TRY(cairo_aux_presort(side_stream_, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, d_flag_side_ + 2));
+    SP_HIP_CHECK(hipMemsetAsync(d_flag_side_ + 2, 0, 2 * sizeof(int), side_stream_));
+    SP_TRY(cairo_aux_presort(side_stream_, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, d_flag_side_ + 2, d_flag_side_ + 3));
     SP_HIP_CHECK(hipEventRecord(ev_side_presort_, side_stream_));
     presorted_ = true;
     return SP_OK;
@@ -719,9 +741,15 @@ int StarkProver::launch_aux_presort() {
 int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint8_t root_out[32]) {
     if (stage_ != 2 || Ca_ != 18 || Cm_ < 34) { sp_set_error("commit_aux_cairo: main segment not committed or not a Cairo layout"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
-    const bool pre = presorted_;
+    bool pre = presorted_;
     presorted_ = false;
-    if (!pre) SP_TRY(public_memory_lists(pub));     // (the presort built them from the same public inputs)
+    if (pre) {   // an address beyond the key bits the presort looked at (a trace with a discontinuous memory): sort again, all 64 bits
+        int wide = 0;
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_presort_, 0));
+        SP_TRY(readback(&wide, d_flag_side_ + 3, sizeof(int)));
+        if (wide) pre = false;
+    }
+    else SP_TRY(public_memory_lists(pub));     // (the presort built them from the same public inputs)
     const uint64_t pm = pm_addr_h_.size();
     if (pm != pub.public_memory.size()) { sp_set_error("commit_aux_cairo: public memory changed since the presort"); return SP_E_STATE; }
     SP_TRY(ensure_aux_workspace(pm));
@@ -1681,18 +1709,23 @@ static void serialize_proof(uint64_t n, const std::vector<std::array<uint8_t, 32
     proof_out.swap(w.b);
 }
 
+ProverHolder* prover_holder(sp_ctx* c, bool create) {
+    ProverHolder* h = dynamic_cast<ProverHolder*>(c->prover_state_deleter_holder);
+    if (!h && create) {
+        delete c->prover_state_deleter_holder;
+        h = new ProverHolder(c);
+        c->prover_state_deleter_holder = h;
+    }
+    return h;
+}
+
 int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
                 const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5],
                 StarkProver::TraceSource src, int col_enc, uint64_t col_stride) {
     try {
         CairoAirInfo air = cairo_air_info(pub);
         if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
-        StarkProver* P = dynamic_cast<StarkProver*>(ctx->prover_state_deleter_holder);
-        if (!P) {  // keep the prover (and its device buffers) across proofs of the same shape on this context
-            P = new StarkProver(ctx);
-            delete ctx->prover_state_deleter_holder;
-            ctx->prover_state_deleter_holder = P;
-        }
+        StarkProver* P = &prover_holder(ctx, true)->prover;   // kept (with its device buffers) across proofs of the same shape on this context
         struct Events {   // released on every exit path
             hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
             ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
@@ -1812,12 +1845,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
               std::vector<uint8_t>& proof_out) {
     try {
         if (air.main_cols == 0 || air.main_cols + air.aux_cols > 64) { sp_set_error("air_prove: column count out of range"); return SP_E_INVALID_ARG; }
-        StarkProver* P = dynamic_cast<StarkProver*>(ctx->prover_state_deleter_holder);
-        if (!P) {
-            P = new StarkProver(ctx);
-            delete ctx->prover_state_deleter_holder;
-            ctx->prover_state_deleter_holder = P;
-        }
+        StarkProver* P = &prover_holder(ctx, true)->prover;   // kept (with its device buffers) across proofs of the same shape on this context
         SP_TRY(P->setup(n, air.main_cols, air.aux_cols, false, opt));
         HostTranscript tr;
         uint8_t root[32];

@@ -121,9 +121,9 @@ class StarkProver : public sp_deletable {
     int ensure_upload(uint32_t groups);
     int finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind);
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
-    static constexpr int UPLOAD_SLOTS = 3;                    // the gather may run two groups ahead of the DMA
+    static constexpr int UPLOAD_SLOTS = 4;                    // ring of chunk slots: the gather may run three chunks ahead of the DMA
     hipEvent_t ev_dma_[UPLOAD_SLOTS] = {}, ev_r2c_[UPLOAD_SLOTS] = {};
-    void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging, one column group each
+    void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging ring, one chunk (<= 32 MB) each
     HostPool* pool_ = nullptr;
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the
     // per-level power tables of up to five points, which dominate for tiny traces)
@@ -222,6 +222,17 @@ class StarkProver : public sp_deletable {
     std::vector<uint32_t> offsets_{0, 1};   // transition offsets of the AIR (frame rows); Cairo: {0, 1}
     int stage_ = 0;  // 0 new, 1 setup, 2 main committed, 3 aux committed, 4 composition, 5 ood, 6 fri running, 7 fri done
 };
+
+// The prover of a context with the host-side buffers of the round-level ABI: one object whichever entry point created it, so a
+// caller can size and warm everything with sp_prove_setup while its trace is still being built and prove with any of them.
+struct ProverHolder : public sp_deletable {
+    StarkProver prover;
+    Openings open;
+    std::vector<uint8_t> trace_evals, comp_evals, fri_evals, fri_evals_sym;
+    float round_ms[5] = {0, 0, 0, 0, 0};
+    explicit ProverHolder(sp_ctx* c) : prover(c) {}
+};
+ProverHolder* prover_holder(sp_ctx* c, bool create);
 
 // Whole proof on the device: generate_cairo_proof (reference src/cairo/air.rs:1165-1171) + serialize
 // (src/starks/proof/stark.rs:161-218). main_trace: row-major n x cols in the context encoding.

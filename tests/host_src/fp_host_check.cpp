@@ -19,6 +19,8 @@ int main() {
         else if (!strcmp(op, "subkp")) show(fe_sub_add_kp(a, b, k));
         else if (!strcmp(op, "mullazy")) show(fe_mul_lazy(a, b));
         else if (!strcmp(op, "mul")) show(fe_mul(a, b));
+        else if (!strcmp(op, "sqrlazy")) show(fe_sqr_lazy(a));
+        else if (!strcmp(op, "sqr")) show(fe_sqr(a));
         else if (!strcmp(op, "negone")) show(fe_neg_one());
         else if (!strcmp(op, "sub2p")) show(fe_sub_add_2p(a, b));
         else if (!strcmp(op, "inv")) show(fe_inv(a));

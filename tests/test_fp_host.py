@@ -76,6 +76,19 @@ def test_lazy_product_accepts_any_256_bit_operand(probe):
         assert g == a * b * rinv % P
 
 
+def test_dedicated_square(probe):
+    """fe_sqr_lazy (triangular CIOS rows: 36 + 8 multiply-adds): a^2 / R mod p in [0, 2p) for every a < 2^253, fe_sqr canonical."""
+    rng = random.Random(16)
+    vals = [0, 1, P - 1, P, P + 1, 2 * P - 1, 2**251, 2**252, 2**253 - 1, 2**32 - 1, 2**64 - 1, (2**253 - 1) ^ (2**31), 0x80000000 * (2**32 + 1)]
+    vals += [(1 << k) - 1 for k in range(1, 254, 7)] + [((1 << 31) << (32 * j)) for j in range(7)] + [rng.randrange(2**253) for _ in range(4000)]
+    rinv = pow(R, -1, P)
+    for a, g in zip(vals, probe([("sqrlazy", a, 0, 0) for a in vals])):
+        assert g < 2 * P and g % P == a * a * rinv % P, hex(a)
+    canon = [v % P for v in vals]
+    for a, g in zip(canon, probe([("sqr", a, 0, 0) for a in canon])):
+        assert g == a * a * rinv % P, hex(a)
+
+
 def test_minus_one(probe):
     assert probe([("negone", 0, 0, 0)])[0] == (P - R % P) % P
 
