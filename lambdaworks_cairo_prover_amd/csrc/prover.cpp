@@ -558,19 +558,19 @@ static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, 
 // interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
 // in column groups: while group g is interpolated and extended on the compute stream, the chunks of the groups behind it are
 // gathered out of the table into a small ring of page-locked slots by a few host threads and cross PCIe on a second stream.
-// A chunk is two adjacent columns (one 64-byte line of every row) of a block of rows, 32 MB at most: the gather reads whole
-// lines, the DMA of one chunk runs beside the gather of the next whatever the size of the group, and the ring (4 x 32 MB) takes
-// a sixth of the time to pin that three group-sized slots did (56 ms of a first proof at 2^20 rows).
+// A chunk is a block of rows of one group, 32 MB at most: the DMA of one chunk runs beside the gather of the next whatever the
+// size of the group, and the ring (4 x 32 MB) takes a sixth of the time to pin that three group-sized slots did (56 ms of a
+// first proof at 2^20 rows).
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything
-    // behind it still has to be transformed (~0.7 ms per column): the finish time is max_g [upload(0..g) + transform(g..)], i.e.
-    // a group may grow only as fast as the columns before it have bought time - small groups first, growing by about a third
-    // of what is already on the device, eight columns at most, always whole column pairs after the two single columns that
-    // start the pipeline (1, 1, 2, 2, 2, 2, 4, 4, 6, 8, 2 for 34 columns).
+    // behind it still has to be transformed (~0.7 ms per column; 0.2 ms at blowup 4, where the upload is the bound): two single
+    // columns start the pipeline, then the groups double up to eight columns, always from an even column on (two columns share a
+    // 64-byte line of a row) - 1, 1, 2, 4, 8, 8, 8, 2 for 34 columns.  Wide groups are what the gather is good at; their upload is
+    // pipelined inside (chunks of rows), so their width costs little latency.
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 3u; }();
+        static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1u; }();
         static const uint32_t maxw = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 8u; }();
         uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done / grow + 1) / 2)));
         if (cols - done <= w + 1) w = cols - done;     // no one-column tail
@@ -583,9 +583,11 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     if (chunk < (size_t)64 * 256) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
-    // gather threads: the option, but never more than the CPUs this process can really have minus the two that poll the stream
-    // and run the HIP runtime's own threads (a 16-CPU container quota on a 256-thread host throttles everything beyond it)
-    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, host_effective_cpus() > 3 ? host_effective_cpus() - 2 : 2u)) - 1u);
+    // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
+    // 100 ms period and the upload is a burst of a quarter of a proof, so twice the quota's CPUs for that long stays inside it
+    // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
+    // proofs of a 64-thread gather in a 16-CPU container.
+    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
     SP_TRY(ensure_upload(groups));
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -612,8 +614,9 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         const double tg = wall_ms();
         double waited = 0;
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
-        for (uint32_t cc = 0; cc < w; cc += 2) {                        // column pairs (a single column in the first two groups)
-            const uint32_t cw = std::min<uint32_t>(2, w - cc), c = c0 + cc;
+        {   // the group in blocks of rows: whole rows of the group (w x 32 contiguous bytes each: the wider, the better the gather
+            // streams - 2 columns move ~40 GB/s, 8 columns ~58) and at most one ring slot of them at a time
+            const uint32_t cw = w, c = c0;
             const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk / ((size_t)cw * 32)) & ~(uint64_t)255);
             for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk, ++chunk_no) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
