@@ -339,6 +339,52 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
                     "fastest of those calls - exposed_ms is how long the compute stream waited for column groups"}
 
 
+XGMI_LINK_GBS_PER_DIRECTION = 76.8   # /opt/skills/guides/MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU
+XGMI_LINK_EFFICIENCY = 0.6           # what RCCL's point-to-point and ring kernels are assumed to reach of a link (not measured here)
+COLLECTIVE_LATENCY_MS = 0.03
+
+
+def project_ranks(api, fib, blowup, ranks, single_gpu_ms):
+    """PROJECTION, not a measurement: rank 0's share of a `ranks`-way sharded proof on this one GPU over the library's timing-only
+    transport (sp_comm_init_null: nothing is exchanged, received blocks are zero-filled), which gives the per-rank compute time with
+    every kernel at its real size, plus a model of the xGMI time of the collectives it issued (their byte counts are exact):
+    received bytes / ((ranks - 1) links x 76.8 GB/s x 0.6) + 30 us per call.  The proof bytes of such a run are meaningless."""
+    import torch
+    run = api.CairoRun.fibonacci(fib)
+    trace = run.main_trace()
+    opt = api.ProofOptions(blowup, 80, 3, 20)
+    dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))
+    torch.cuda.synchronize()
+    n, cols = trace.shape[0], trace.shape[1]
+    ctx = api.Context(device=torch.cuda.current_device())
+    try:
+        ctx.init_null(ranks, 0)
+        for _ in range(3):
+            ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+        before = ctx.comm_stats()
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+            times.append((time.perf_counter() - t0) * 1e3)
+        after = ctx.comm_stats()
+        info, dev_bytes = ctx.last_proof_info(), ctx.prover_device_bytes()
+    finally:
+        ctx.close()
+    per = {k: (after[k] - before[k]) / 3 for k in ("allgather_calls", "allgather_bytes", "alltoall_calls", "alltoall_bytes", "received_bytes")}
+    groups = max(1, info["groups"])
+    ingest_gbs = max(1, groups - 1) * XGMI_LINK_GBS_PER_DIRECTION * XGMI_LINK_EFFICIENCY
+    comm_ms = per["received_bytes"] / (ingest_gbs * 1e9) * 1e3 + (per["allgather_calls"] + per["alltoall_calls"]) * COLLECTIVE_LATENCY_MS
+    compute_ms = min(times)
+    return {"projection": True, "ranks": ranks, "groups": groups, "compute_ms": compute_ms, "comm_ms_model": comm_ms,
+            "collectives_per_proof": per, "assumed_ingest_gbs": ingest_gbs, "device_bytes_per_rank": dev_bytes,
+            "single_gpu_ms": single_gpu_ms, "speedup_ceiling": single_gpu_ms / (compute_ms + comm_ms) if single_gpu_ms else None,
+            "speedup_if_comm_hidden": single_gpu_ms / compute_ms if single_gpu_ms else None,
+            "note": "NOT a measurement of a multi-GPU run: rank 0's compute share timed on one GPU with a null transport (bytes not "
+                    "exchanged, proof bytes meaningless) + a bandwidth model of the exact collective byte counts; the collectives are "
+                    "blocking in this run, so compute_ms + comm_ms_model assumes no overlap"}
+
+
 def _free_port():
     import socket
     s = socket.socket()
@@ -486,6 +532,7 @@ def main():
     ap.add_argument("--cold-shape", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cold-path", type=str, default="rows", help=argparse.SUPPRESS)
     ap.add_argument("--no-cold-start", action="store_true", help="skip the first-proof-of-a-fresh-process measurements")
+    ap.add_argument("--project-ranks", type=int, default=8, help="N = 1 only: also PROJECT (not measure) an N-rank sharded proof from rank 0's share on this GPU (0: off)")
     args = ap.parse_args()
     if args.cpu_proof_child:
         return cpu_proof_child(args)
@@ -592,6 +639,13 @@ def main():
             if world == 1:
                 out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
                 out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
+                if args.project_ranks > 1:
+                    out["projected"] = {}
+                    for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
+                        try:
+                            out["projected"][key] = project_ranks(api, fib, blowup, args.project_ranks, out[key].get("proof_gen_ms"))
+                        except Exception as e:
+                            out["projected"][key] = {"error": repr(e)}
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
                         cold = cold_start(args, fib, blowup, "rows")

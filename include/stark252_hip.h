@@ -59,6 +59,12 @@ typedef struct sp_ctx sp_ctx;
 typedef int (*sp_allgather_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
 
 const char* sp_version(void);
+/* Layout version of the structures of this header (sp_air_desc, sp_openings, sp_cairo_public_inputs, sp_proof_options): bumped
+ * whenever one of them changes.  A binding compares it (and sp_air_desc_size against its own idea of the struct) when it loads
+ * the library, so a stale mirror of a struct fails at load time instead of being read with shifted fields. */
+#define SP_ABI_VERSION 3
+int sp_abi_version(void);
+uint64_t sp_air_desc_size(void);
 const char* sp_last_error(void);          /* thread-local description of the last failure */
 int sp_device_count(int* count_out);      /* number of visible HIP devices (0 without a GPU) */
 /* CPUs the host side of the library may really use: hardware threads cut down by the affinity mask and the cgroup CPU quota
@@ -78,6 +84,10 @@ int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void
  * sp_comm_init_rccl with it. */
 int sp_comm_unique_id(uint8_t id_out[128]);
 int sp_comm_init_rccl(sp_ctx* ctx, const uint8_t id[128], int world, int rank);
+/* Timing-only transport for projections on fewer GPUs than ranks (bench.py --project-ranks): nothing is exchanged - the own block
+ * lands where a collective would put it, the other ranks' blocks are zero-filled (the HBM writes a receive costs) - so ONE rank's
+ * share of a sharded proof runs at its real kernel sizes.  The proof bytes that come out are meaningless; never use it to prove. */
+int sp_comm_init_null(sp_ctx* ctx, int world, int rank);
 /* Optional second hook ("Merkle combine"): blocking all-to-all of equal blocks, send_dev =
  * [world][bytes_per_pair] (block d goes to rank d), recv_dev = [world][bytes_per_pair] (block s came from rank s).  With it
  * the 32-byte leaf digests of a commitment travel once (each rank receives only the contiguous 1/world of the leaves whose

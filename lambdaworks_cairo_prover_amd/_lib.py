@@ -19,6 +19,8 @@ SP_E_ZERO_INVERSE = -6
 SP_E_UNSUPPORTED = -7
 SP_E_PROGRAM = -8
 
+SP_ABI_VERSION = 3   # include/stark252_hip.h
+
 SP_FE_MONT_LIMBS = 0
 SP_FE_CANON_BE = 1
 
@@ -60,6 +62,9 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.sp_version.restype = ctypes.c_char_p
     lib.sp_last_error.restype = ctypes.c_char_p
+    lib.sp_air_desc_size.restype = ctypes.c_uint64
+    if lib.sp_abi_version() != SP_ABI_VERSION:
+        raise ImportError(f"{LIB_PATH} has ABI version {lib.sp_abi_version()}, this binding was written for {SP_ABI_VERSION}: rebuild the library")
     _lib = lib
     return lib
 

@@ -39,6 +39,14 @@ class AirDescC(ctypes.Structure):
                 ("aux_fn", AUX_TRACE_FN), ("aux_user", ctypes.c_void_p)]
 
 
+def _check_layout():
+    """The library reports the size of its sp_air_desc: a mirror with other field sizes must not reach sp_air_prove."""
+    from . import _lib
+    want = _lib.load().sp_air_desc_size()
+    if ctypes.sizeof(AirDescC) != want:
+        raise ImportError(f"AirDescC is {ctypes.sizeof(AirDescC)} bytes, the library's sp_air_desc {want}: the binding is out of date")
+
+
 AUX_NONE, AUX_FIBONACCI_RAP, AUX_CALLBACK = 0, 1, 2
 _RAP_TAG = 0x8000
 
@@ -102,6 +110,7 @@ class AirBuilder:
 
     def build(self):
         """Returns (AirDescC, keepalive)."""
+        _check_layout()
         d = AirDescC()
         d.main_cols, d.aux_cols = self.main_cols, self.aux_cols
         d.n_offsets = len(self.offsets)

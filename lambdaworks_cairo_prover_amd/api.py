@@ -450,6 +450,11 @@ def _ctx_set_collective(self, world, rank, hook, alltoall=True):
         check(self._lib.sp_set_alltoall(self._h, hook.a2a_cfn))
 
 
+def _ctx_init_null(self, world, rank):
+    """sp_comm_init_null: timing-only transport (projection of one rank's share on a single GPU; the proof bytes are meaningless)."""
+    check(self._lib.sp_comm_init_null(self._h, world, rank))
+
+
 def _ctx_comm_selftest(self, bytes_per_block=1 << 20):
     check(self._lib.sp_comm_selftest(self._h, ctypes.c_uint64(bytes_per_block)))
 
@@ -483,6 +488,7 @@ def _ctx_init_rccl(self, group=None):
 
 Context.set_collective = _ctx_set_collective
 Context.init_rccl = _ctx_init_rccl
+Context.init_null = _ctx_init_null
 Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option

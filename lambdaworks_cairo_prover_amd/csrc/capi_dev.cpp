@@ -126,15 +126,50 @@ int rccl_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
     const uint8_t* s = static_cast<const uint8_t*>(send);
     uint8_t* r = static_cast<uint8_t*>(recv);
     if (ncclGroupStart() != ncclSuccess) return -1;
-    for (int peer = 0; peer < rc->world; ++peer) {
-        if (ncclSend(s + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) return -1;
-        if (ncclRecv(r + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) return -1;
+    int rcode = 0;   // the group is closed whatever happens inside it: a communicator left in group mode queues every later call
+    for (int peer = 0; peer < rc->world && rcode == 0; ++peer) {
+        if (ncclSend(s + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) rcode = -3;
+        else if (ncclRecv(r + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) rcode = -4;
     }
-    if (ncclGroupEnd() != ncclSuccess) return -1;
+    if (ncclGroupEnd() != ncclSuccess && rcode == 0) rcode = -5;
+    if (rcode != 0) return rcode;
     if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
     return 0;
 }
 }  // namespace
+
+namespace {
+// Timing-only transport (sp_comm_init_null): nothing is exchanged.  The own block lands where a real collective would put it and
+// the blocks of the other ranks are zero-filled - the HBM writes a real receive would cost - so a single GPU can run ONE rank's
+// share of a sharded proof with every kernel at its real size.  The proof bytes that come out are meaningless.
+struct NullComm : public sp_deletable { hipStream_t stream = nullptr; int world = 1, rank = 0; };
+int null_allgather(void* user, const void* send, void* recv, uint64_t bytes) {
+    NullComm* nc = static_cast<NullComm*>(user);
+    uint8_t* r = static_cast<uint8_t*>(recv);
+    uint8_t* mine = r + (size_t)nc->rank * bytes;
+    if (mine != send && hipMemcpyAsync(mine, send, bytes, hipMemcpyDeviceToDevice, nc->stream) != hipSuccess) return -1;
+    if (nc->rank > 0 && hipMemsetAsync(r, 0, (size_t)nc->rank * bytes, nc->stream) != hipSuccess) return -1;
+    if (nc->rank + 1 < nc->world && hipMemsetAsync(mine + bytes, 0, (size_t)(nc->world - 1 - nc->rank) * bytes, nc->stream) != hipSuccess) return -1;
+    return hipStreamSynchronize(nc->stream) == hipSuccess ? 0 : -2;
+}
+int null_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
+    NullComm* nc = static_cast<NullComm*>(user);
+    uint8_t* r = static_cast<uint8_t*>(recv);
+    if (hipMemsetAsync(r, 0, (size_t)nc->world * bytes, nc->stream) != hipSuccess) return -1;
+    if (hipMemcpyAsync(r + (size_t)nc->rank * bytes, static_cast<const uint8_t*>(send) + (size_t)nc->rank * bytes, bytes, hipMemcpyDeviceToDevice, nc->stream) != hipSuccess) return -1;
+    return hipStreamSynchronize(nc->stream) == hipSuccess ? 0 : -2;
+}
+}  // namespace
+
+int sp_comm_init_null(sp_ctx* c, int world, int rank) {
+    if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1))) return SP_E_INVALID_ARG;
+    NullComm* nc = new NullComm();
+    nc->stream = c->stream; nc->world = world; nc->rank = rank;
+    delete c->comm_holder;
+    c->comm_holder = nc;
+    SP_TRY(sp_set_collective(c, world, rank, null_allgather, nc));
+    return sp_set_alltoall(c, null_alltoall);
+}
 
 int sp_comm_unique_id(uint8_t id_out[128]) {
     if (!id_out) return SP_E_INVALID_ARG;

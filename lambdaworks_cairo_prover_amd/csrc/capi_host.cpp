@@ -57,7 +57,9 @@ PublicInputs public_inputs_from_c(const sp_cairo_public_inputs* p) {
 
 extern "C" {
 
-const char* sp_version(void) { return "stark252-hip 0.1 (gfx950)"; }
+const char* sp_version(void) { return "stark252-hip 0.3 (gfx950)"; }
+int sp_abi_version(void) { return SP_ABI_VERSION; }
+uint64_t sp_air_desc_size(void) { return sizeof(sp_air_desc); }
 const char* sp_last_error(void) { return g_last_error.c_str(); }
 int sp_host_cpus(int* count_out) {
     if (!count_out) return SP_E_INVALID_ARG;

@@ -218,9 +218,24 @@ int StarkProver::alloc_tree(TreeBuf& t, uint64_t leaves_total, bool sharded) {
     return SP_OK;
 }
 
+// Frees a buffer this prover outgrew (everything that could still read it has finished first).
+void StarkProver::release(void* p, size_t bytes) {
+    if (!p) return;
+    (void)hipStreamSynchronize(c_->stream);
+    if (side_stream_) (void)hipStreamSynchronize(side_stream_);
+    if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    auto it = std::find(allocs_.begin(), allocs_.end(), p);
+    if (it != allocs_.end()) allocs_.erase(it);
+    (void)hipFree(p);
+    alloc_bytes_ -= std::min<uint64_t>(alloc_bytes_, bytes);
+    c_->prover_device_bytes = alloc_bytes_;
+}
+
 int StarkProver::ensure_gather(uint64_t elems) {
     if (elems <= gather_cap_) return SP_OK;
-    SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
+    release(d_gather_, sizeof(fe) * gather_cap_);
+    d_gather_ = nullptr; gather_cap_ = 0;
+    SP_TRY(alloc((void**)&d_gather_, sizeof(fe) * elems));
     gather_cap_ = elems;
     return SP_OK;
 }
@@ -282,7 +297,9 @@ int StarkProver::prefetch_boundary_inverses(const std::vector<uint64_t>& steps_i
 
 int StarkProver::ensure_deep_scratch(uint64_t elems) {
     if (elems <= deepx_cap_) return SP_OK;
-    SP_TRY(alloc((void**)&d_deepx_, sizeof(fe) * elems));   // an outgrown buffer stays in allocs_ until the next reshaping setup()
+    release(d_deepx_, sizeof(fe) * deepx_cap_);
+    d_deepx_ = nullptr; deepx_cap_ = 0; deep_pref_ = false;
+    SP_TRY(alloc((void**)&d_deepx_, sizeof(fe) * elems));
     deepx_cap_ = elems;
     return SP_OK;
 }
@@ -714,8 +731,10 @@ int StarkProver::ensure_aux_workspace(uint64_t pm) {
     size_t sort_tmp = 0;
     uint64_t cap = std::max<uint64_t>(pm, 1024);
     size_t bytes = aux_workspace_bytes(n_, cap, &sort_tmp);
+    release(d_auxws_, auxws_bytes_);   // (a context reused with a growing public memory must not keep every workspace it outgrew)
+    d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; presorted_ = false;
     void* base = nullptr;
-    SP_TRY(alloc(&base, bytes));  // an outgrown workspace stays in allocs_ until the next reshaping setup()
+    SP_TRY(alloc(&base, bytes));
     d_auxws_ = base; auxws_bytes_ = bytes; auxws_pm_cap_ = cap;
     aux_workspace_carve(auxws_, base, n_, cap, sort_tmp);
     return SP_OK;
@@ -904,11 +923,29 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
         if (!ok) { sp_set_error("composition_air: malformed constraint program"); return SP_E_INVALID_ARG; }
     }
     {
-        std::vector<uint16_t> slot_of(prog.n_ops, 0), free_slots;
+        // Values nobody reads (directly or through other unread values) are not part of the program the device runs: giving such
+        // a value "any" slot would overwrite a live one when all 64 are taken.  Liveness backwards from the OUT ops, then slots.
+        const uint32_t n_src = prog.n_ops;
+        std::vector<uint8_t> live(n_src, 0);
+        for (uint32_t t = n_src; t-- > 0;) {
+            const AirOpHost& o = air.ops[t];
+            if (o.op == 5) { live[t] = 1; live[o.b] = 1; }
+            else if (live[t] && o.op >= 2 && o.op <= 4) { live[o.a] = 1; live[o.b] = 1; }
+        }
+        std::fill(last_use.begin(), last_use.end(), 0u);
+        for (uint32_t t = 0; t < n_src; ++t) {
+            if (!live[t]) continue;
+            const AirOpHost& o = air.ops[t];
+            if (o.op >= 2 && o.op <= 4) { last_use[o.a] = t; last_use[o.b] = t; }
+            else if (o.op == 5) last_use[o.b] = t;
+        }
+        std::vector<uint16_t> slot_of(n_src, 0), free_slots;
         for (int sl = AIR_MAX_LIVE - 1; sl >= 0; --sl) free_slots.push_back((uint16_t)sl);
-        std::vector<std::vector<uint32_t>> dying(prog.n_ops);    // values whose last use is op t
-        for (uint32_t t = 0; t < prog.n_ops; ++t) if (air.ops[t].op != 5 && last_use[t] > t) dying[last_use[t]].push_back(t);
-        for (uint32_t t = 0; t < prog.n_ops; ++t) {
+        std::vector<std::vector<uint32_t>> dying(n_src);    // values whose last use is op t
+        for (uint32_t t = 0; t < n_src; ++t) if (live[t] && air.ops[t].op != 5) dying[last_use[t]].push_back(t);
+        uint32_t emitted = 0;
+        for (uint32_t t = 0; t < n_src; ++t) {
+            if (!live[t]) continue;
             const AirOpHost& o = air.ops[t];
             AirOpDev d{};
             d.op = o.op;
@@ -917,15 +954,13 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
             else { d.a = o.a; d.b = o.b; }
             for (uint32_t v : dying[t]) free_slots.push_back(slot_of[v]);   // operands read before the result is written
             if (o.op != 5) {
-                if (last_use[t] <= t) { d.dst = AIR_MAX_LIVE - 1; if (free_slots.empty()) { /* unused value: any slot */ } else d.dst = free_slots.back(); }
-                else {
-                    if (free_slots.empty()) { sp_set_error("composition_air: more than 64 values alive at once in the constraint program"); return SP_E_UNSUPPORTED; }
-                    d.dst = free_slots.back(); free_slots.pop_back();
-                }
+                if (free_slots.empty()) { sp_set_error("composition_air: more than 64 values alive at once in the constraint program"); return SP_E_UNSUPPORTED; }
+                d.dst = free_slots.back(); free_slots.pop_back();
                 slot_of[t] = d.dst;
             }
-            prog.ops[t] = d;
+            prog.ops[emitted++] = d;
         }
+        prog.n_ops = emitted;
     }
     for (size_t i = 0; i < air.consts.size(); ++i) prog.consts[i] = air.consts[i];
     for (size_t i = 0; i < rap.size(); ++i) prog.consts[air.consts.size() + i] = rap[i];
@@ -1413,7 +1448,8 @@ int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], st
     fe* d_cst = d_cmul + L;
     uint64_t* d_roots = reinterpret_cast<uint64_t*>(d_cst + L);
     // constants half / offset_k of every layer (offset_k = h^(2^k)) and the transcript state, in one upload
-    std::vector<uint8_t> up(32 + (size_t)L * 32);
+    std::vector<uint8_t>& up = h_up_fri_;     // (a member: the asynchronous copy below may still read it when an error path returns)
+    up.assign(32 + (size_t)L * 32, 0);
     std::memcpy(up.data(), state32, 32);
     fe oi = fri_offset_inv_;
     for (uint32_t k = 0; k < L; ++k) { const fe c = fe_mul(half_, oi); std::memcpy(up.data() + 32 + (size_t)k * 32, &c, 32); oi = fe_sqr(oi); }
@@ -1514,7 +1550,8 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
         t.ipos = nidx; nidx += t.idx.size();
         t.iown = nidx; if (t.du) nidx += t.idx.size();
     }
-    std::vector<uint64_t> hidx(nidx);
+    std::vector<uint64_t>& hidx = h_idx_open_;   // (members, like `up` below: read by asynchronous copies)
+    hidx.assign(nidx, 0);
     for (auto& v : vj) std::copy(v.local.begin(), v.local.end(), hidx.begin() + v.ipos);
     for (auto& t : tj)
         for (size_t s = 0; s < t.idx.size(); ++s) {
@@ -1548,7 +1585,8 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     GatherJob* d_jobs = reinterpret_cast<GatherJob*>(base + idx_bytes);
     fe* blk = reinterpret_cast<fe*>(base + idx_bytes + job_bytes);
     fe* all_dev = blk + items;
-    std::vector<uint8_t> up(idx_bytes + job_bytes, 0);
+    std::vector<uint8_t>& up = h_up_open_;
+    up.assign(idx_bytes + job_bytes, 0);
     std::memcpy(up.data(), hidx.data(), nidx * sizeof(uint64_t));
     std::memcpy(up.data() + idx_bytes, jobs.data(), jobs.size() * sizeof(GatherJob));
     SP_HIP_CHECK(hipMemcpyAsync(base, up.data(), up.size(), hipMemcpyHostToDevice, st));

@@ -100,6 +100,9 @@ class StarkProver : public sp_deletable {
     int readback(void* dst_host, const void* src_dev, size_t bytes);
     int wait_stream();
     int alloc(void** p, size_t bytes);
+    void release(void* p, size_t bytes);
+    std::vector<uint8_t> h_up_fri_, h_up_open_;   // host sides of small asynchronous uploads (fri_commit_chain, open)
+    std::vector<uint64_t> h_idx_open_;
     int alloc_tree(TreeBuf& t, uint64_t leaves_total, bool sharded);
     int setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc_builtin, const ProofOptionsHost& opt);
     bool ready_ = false;   // setup() completed: every buffer below exists
