@@ -643,7 +643,8 @@ def main():
                     out["projected"] = {}
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
                         try:
-                            out["projected"][key] = project_ranks(api, fib, blowup, args.project_ranks, out[key].get("proof_gen_ms"))
+                            # (more ranks than LDE cosets only replicate roles: project blowup-many ranks at most)
+                            out["projected"][key] = project_ranks(api, fib, blowup, min(args.project_ranks, blowup), out[key].get("proof_gen_ms"))
                         except Exception as e:
                             out["projected"][key] = {"error": repr(e)}
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)

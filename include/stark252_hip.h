@@ -84,6 +84,13 @@ int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void
  * sp_comm_init_rccl with it. */
 int sp_comm_unique_id(uint8_t id_out[128]);
 int sp_comm_init_rccl(sp_ctx* ctx, const uint8_t id[128], int world, int rank);
+/* Optional stream-ordered all-gather (same layout as sp_allgather_fn): enqueue the exchange on `hip_stream` (a hipStream_t) and
+ * return without waiting.  With it the sharded prover splits the coefficient all-gather of a trace segment into column blocks on a
+ * stream of its own, so that the exchange of one block runs beside the inverse transforms of the next and the LDE of the one
+ * before (prover.rs:161-185 has no such dependency between columns).  sp_comm_init_rccl installs it (ncclAllGather on that
+ * stream); the blocking hook stays in use for every other exchange.  Call after sp_set_collective. */
+typedef int (*sp_allgather_async_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, void* hip_stream);
+int sp_set_collective_async(sp_ctx* ctx, sp_allgather_async_fn fn);
 /* Timing-only transport for projections on fewer GPUs than ranks (bench.py --project-ranks): nothing is exchanged - the own block
  * lands where a collective would put it, the other ranks' blocks are zero-filled (the HBM writes a receive costs) - so ONE rank's
  * share of a sharded proof runs at its real kernel sizes.  The proof bytes that come out are meaningless; never use it to prove. */

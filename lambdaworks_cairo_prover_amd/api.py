@@ -442,6 +442,68 @@ def _staged_call_a2a(self, user, send, recv, nbytes):
 StagedAllGather._call_a2a = _staged_call_a2a
 
 
+ALLGATHER_ASYNC_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+_HOST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
+class StagedAsyncAllGather:
+    """Test aid for the stream-ordered all-gather hook (sp_set_collective_async) when the ranks share one GPU: the exchange is a
+    device-to-host copy, a host function (hipLaunchHostFunc) that runs a gloo all_gather on a process group OF ITS OWN - it runs
+    beside the blocking hooks' collectives of the main thread - and a host-to-device copy, all enqueued on the stream the prover
+    hands over.  Production runs use the library's RCCL communicator (ncclAllGather on that stream)."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = dist.new_group(backend="gloo")
+        self.world = dist.get_world_size()
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
+        self.hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        self.hip.hipLaunchHostFunc.argtypes = [ctypes.c_void_p, _HOST_FN, ctypes.c_void_p]
+        self.pending, self.calls = {}, 0
+        self.cfn = ALLGATHER_ASYNC_FN(self._call)
+        self.hostfn = _HOST_FN(self._host)
+
+    def _call(self, user, send, recv, nbytes, stream):
+        try:
+            hs, hr = ctypes.c_void_p(), ctypes.c_void_p()
+            if self.hip.hipHostMalloc(ctypes.byref(hs), nbytes, 0) != 0 or self.hip.hipHostMalloc(ctypes.byref(hr), nbytes * self.world, 0) != 0:
+                return -1
+            self.calls += 1
+            self.pending[self.calls] = (hs.value, hr.value, nbytes)
+            if self.hip.hipMemcpyAsync(hs, send, nbytes, 2, stream) != 0:
+                return -2
+            if self.hip.hipLaunchHostFunc(stream, self.hostfn, ctypes.c_void_p(self.calls)) != 0:
+                return -3
+            if self.hip.hipMemcpyAsync(recv, hr, nbytes * self.world, 1, stream) != 0:
+                return -4
+            return 0
+        except Exception:  # never let an exception cross the C boundary
+            import traceback
+            traceback.print_exc()
+            return -5
+
+    def _host(self, key):
+        try:
+            import torch
+            hs, hr, nbytes = self.pending[int(key)]
+            mine = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(hs)).copy())
+            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
+            self.dist.all_gather(outs, mine, group=self.group)
+            for i, o in enumerate(outs):
+                ctypes.memmove(hr + i * nbytes, o.data_ptr(), nbytes)
+        except Exception:
+            import traceback
+            traceback.print_exc()
+
+
+def _ctx_set_collective_async(self, hook):
+    """Install a stream-ordered all-gather hook (sp_set_collective_async); call after set_collective."""
+    self._async_hook = hook  # keep the callbacks alive
+    check(self._lib.sp_set_collective_async(self._h, hook.cfn if hook is not None else None))
+
+
 def _ctx_set_collective(self, world, rank, hook, alltoall=True):
     """Install the blocking all-gather hook (and, unless alltoall=False, the all-to-all hook of the digest exchange)."""
     self._hook = hook  # keep the callbacks alive
@@ -489,8 +551,9 @@ def _ctx_init_rccl(self, group=None):
 Context.set_collective = _ctx_set_collective
 Context.init_rccl = _ctx_init_rccl
 Context.init_null = _ctx_init_null
+Context.set_collective_async = _ctx_set_collective_async
 Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
-__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "shard_global_index", "interleave_shards",
+__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS"]

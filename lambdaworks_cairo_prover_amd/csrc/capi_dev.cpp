@@ -71,7 +71,13 @@ int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* 
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) || (world > 1 && !fn)) return SP_E_INVALID_ARG;
     delete c->prover_state_deleter_holder;   // a prover shaped for another world size must not survive
     c->prover_state_deleter_holder = nullptr;
-    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr;
+    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr; c->allgather_async = nullptr;
+    return SP_OK;
+}
+
+int sp_set_collective_async(sp_ctx* c, sp_allgather_async_fn fn) {
+    if (!c) return SP_E_INVALID_ARG;
+    c->allgather_async = fn;
     return SP_OK;
 }
 
@@ -120,6 +126,10 @@ int rccl_allgather(void* user, const void* send, void* recv, uint64_t bytes) {
     if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
     return 0;
 }
+int rccl_allgather_async(void* user, const void* send, void* recv, uint64_t bytes, void* stream) {
+    RcclComm* rc = static_cast<RcclComm*>(user);
+    return ncclAllGather(send, recv, bytes, ncclUint8, rc->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : -1;
+}
 // all-to-all of equal blocks as grouped point-to-point transfers (xGMI is point-to-point: every pair uses its own link)
 int rccl_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
     RcclComm* rc = static_cast<RcclComm*>(user);
@@ -152,6 +162,16 @@ int null_allgather(void* user, const void* send, void* recv, uint64_t bytes) {
     if (nc->rank + 1 < nc->world && hipMemsetAsync(mine + bytes, 0, (size_t)(nc->world - 1 - nc->rank) * bytes, nc->stream) != hipSuccess) return -1;
     return hipStreamSynchronize(nc->stream) == hipSuccess ? 0 : -2;
 }
+int null_allgather_async(void* user, const void* send, void* recv, uint64_t bytes, void* stream) {
+    NullComm* nc = static_cast<NullComm*>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint8_t* r = static_cast<uint8_t*>(recv);
+    uint8_t* mine = r + (size_t)nc->rank * bytes;
+    if (mine != send && hipMemcpyAsync(mine, send, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+    if (nc->rank > 0 && hipMemsetAsync(r, 0, (size_t)nc->rank * bytes, st) != hipSuccess) return -1;
+    if (nc->rank + 1 < nc->world && hipMemsetAsync(mine + bytes, 0, (size_t)(nc->world - 1 - nc->rank) * bytes, st) != hipSuccess) return -1;
+    return 0;
+}
 int null_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
     NullComm* nc = static_cast<NullComm*>(user);
     uint8_t* r = static_cast<uint8_t*>(recv);
@@ -168,6 +188,7 @@ int sp_comm_init_null(sp_ctx* c, int world, int rank) {
     delete c->comm_holder;
     c->comm_holder = nc;
     SP_TRY(sp_set_collective(c, world, rank, null_allgather, nc));
+    SP_TRY(sp_set_collective_async(c, null_allgather_async));
     return sp_set_alltoall(c, null_alltoall);
 }
 
@@ -191,6 +212,7 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     delete c->comm_holder;
     c->comm_holder = rc;
     SP_TRY(sp_set_collective(c, world, rank, rccl_allgather, rc));
+    SP_TRY(sp_set_collective_async(c, rccl_allgather_async));
     return sp_set_alltoall(c, rccl_alltoall);
 }
 

@@ -28,6 +28,9 @@ struct sp_ctx {
     int world = 1, rank = 0;
     sp_allgather_fn allgather = nullptr;
     sp_alltoall_fn alltoall = nullptr;    // optional (sp_set_alltoall); same user pointer
+    // stream-ordered form of the all-gather (sp_comm_init_rccl, sp_set_collective_async): enqueued on the given stream, returns at
+    // once - lets the prover run an exchange beside its transforms instead of in front of them
+    sp_allgather_async_fn allgather_async = nullptr;
     void* allgather_user = nullptr;
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option

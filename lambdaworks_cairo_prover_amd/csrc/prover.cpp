@@ -42,6 +42,9 @@ StarkProver::~StarkProver() {
     if (h_pin_) (void)hipHostFree(h_pin_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
+    if (ev_comm_fork_) (void)hipEventDestroy(ev_comm_fork_);
+    for (auto& e : ev_comm_done_) if (e) (void)hipEventDestroy(e);
+    if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
 }
 
 int StarkProver::ensure_side() {
@@ -70,6 +73,7 @@ void StarkProver::free_all() {
     (void)hipStreamSynchronize(c_->stream);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
+    if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
     d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -319,6 +323,28 @@ int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes
     int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
     if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
     c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
+    return SP_OK;
+}
+
+int StarkProver::all_gather_begin(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, int slot) {
+    if (slot < 0 || slot >= COMM_BLOCKS) return SP_E_INVALID_ARG;
+    if (!comm_async()) return all_gather(send_dev, recv_dev, bytes_per_rank);
+    if (!comm_stream_) {
+        SP_HIP_CHECK(hipStreamCreateWithFlags(&comm_stream_, hipStreamNonBlocking));
+        SP_HIP_CHECK(hipEventCreateWithFlags(&ev_comm_fork_, hipEventDisableTiming));
+        for (auto& e : ev_comm_done_) SP_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    SP_HIP_CHECK(hipEventRecord(ev_comm_fork_, c_->stream));            // the send block is complete behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_comm_fork_, 0));
+    const int rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, comm_stream_);
+    if (rc != 0) { sp_set_error("stream-ordered all-gather failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+    SP_HIP_CHECK(hipEventRecord(ev_comm_done_[slot], comm_stream_));
+    c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
+    return SP_OK;
+}
+int StarkProver::all_gather_end(int slot) {
+    if (!comm_async()) return SP_OK;
+    SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_comm_done_[slot], 0));
     return SP_OK;
 }
 
@@ -678,24 +704,58 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients (the trace stays intact)
+    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     if (G_ > 1 && d_cstage_ && cols >= G_) {
         // columns are independent (prover.rs:174-183): role s interpolates the cpr columns from min(s cpr, cols - cpr) on
-        // (the last blocks overlap instead of being ragged), one all-gather brings every coefficient everywhere (§8(e) item 1)
+        // (the last blocks overlap instead of being ragged), all-gathers bring every coefficient everywhere (§8(e) item 1).
+        // With a stream-ordered transport the cpr columns go in up to four blocks: the exchange of block k runs on the
+        // communication stream beside the inverse transforms of block k + 1 and the LDE of block k - 1; a blocking transport
+        // keeps the one exchange (every call is a host round trip through the hook).
         const uint32_t cpr = (cols + G_ - 1) / G_;
         auto first_col = [&](uint32_t role) { return std::min(role * cpr, cols - cpr); };
-        const uint64_t blk = (uint64_t)cpr * n_;
-        fe* mine = d_cstage_ + (uint64_t)wrank_ * blk;
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(mine, (int)logn_, cpr, n_, d_t1_, d_trace_ + (uint64_t)(col0 + first_col(rank_)) * n_));
-        SP_TRY(all_gather(mine, d_cstage_, blk * sizeof(fe)));   // in place: slot `rank` of the receive buffer is the send buffer
-        for (uint32_t role = 0; role < G_; ++role)
-            SP_HIP_CHECK(hipMemcpyAsync(coeffs + (uint64_t)first_col(role) * n_, d_cstage_ + (uint64_t)role * blk, blk * sizeof(fe),
-                                        hipMemcpyDeviceToDevice, c_->stream));
+        const uint32_t K = comm_async() ? std::min<uint32_t>(cpr, (uint32_t)COMM_BLOCKS) : 1u;
+        const uint32_t bc = (cpr + K - 1) / K;
+        std::vector<uint8_t> extended(cols, 0);
+        struct Block { uint32_t j0, w; fe* stage; };
+        std::vector<Block> blocks;
+        uint64_t stage_off = 0;
+        for (uint32_t j0 = 0; j0 < cpr; j0 += bc) {
+            const uint32_t w = std::min(bc, cpr - j0);
+            blocks.push_back(Block{j0, w, d_cstage_ + stage_off});
+            stage_off += (uint64_t)world_ * w * n_;
+        }
+        auto finish = [&](size_t k) -> int {   // block k has arrived: into the coefficient array, then evaluate_offset_fft of its columns
+            const Block& b = blocks[k];
+            SP_TRY(all_gather_end((int)k));
+            for (uint32_t role = 0; role < G_; ++role)
+                SP_HIP_CHECK(hipMemcpyAsync(coeffs + (uint64_t)(first_col(role) + b.j0) * n_, b.stage + (uint64_t)role * b.w * n_, (uint64_t)b.w * n_ * sizeof(fe),
+                                            hipMemcpyDeviceToDevice, c_->stream));
+            if (K == 1) return SP_OK;          // one exchange: the whole segment is extended in one launch below
+            for (uint32_t role = 0; role < G_; ++role)
+                for (uint32_t j = 0; j < b.w;) {   // runs of columns not extended yet (the ranges of the last roles overlap)
+                    const uint32_t c = first_col(role) + b.j0 + j;
+                    if (extended[c]) { ++j; continue; }
+                    uint32_t run = 0;
+                    while (j + run < b.w && !extended[c + run]) { extended[c + run] = 1; ++run; }
+                    SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c * n_, lde + (uint64_t)c * Nl_, (int)logn_, (int)logb_, run, n_, Nl_, (int)logG_, (int)rank_));
+                    j += run;
+                }
+            return SP_OK;
+        };
+        for (size_t k = 0; k < blocks.size(); ++k) {
+            const Block& b = blocks[k];
+            fe* mine = b.stage + (uint64_t)wrank_ * b.w * n_;      // in place: slot `rank` of the receive block is the send buffer
+            SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(mine, (int)logn_, b.w, n_, d_t1_, d_trace_ + (uint64_t)(col0 + first_col(rank_) + b.j0) * n_));
+            SP_TRY(all_gather_begin(mine, b.stage, (uint64_t)b.w * n_ * sizeof(fe), (int)k));
+            if (k > 0) SP_TRY(finish(k - 1));
+        }
+        SP_TRY(finish(blocks.size() - 1));
+        if (K == 1) SP_TRY(c_->ntt->lde_coset_major(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     } else {
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
+        // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
+        SP_TRY(c_->ntt->lde_coset_major(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     }
-    // evaluate_offset_fft on the LDE coset (reference prover.rs:161-185)
-    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    SP_TRY(c_->ntt->lde_coset_major(coeffs, lde, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
     // batch_commit (reference prover.rs:96-104) straight from the column-major LDE
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
     stage_ = segment == 0 ? 2 : 3;

@@ -158,6 +158,15 @@ class StarkProver : public sp_deletable {
     fe* d_deepx_ = nullptr; uint64_t deepx_cap_ = 0;   // DEEP inverses when they outgrow the shared scratch
     int full_domain_buffer(fe** out);
     int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+    // The same in two halves: begin() starts the exchange behind everything queued on the compute stream so far - on the
+    // communication stream when the transport is stream-ordered, by blocking in the hook otherwise - and end() makes the compute
+    // stream wait for it.  What is queued on the compute stream between the two runs beside the exchange.
+    static constexpr int COMM_BLOCKS = 4;
+    hipStream_t comm_stream_ = nullptr;
+    hipEvent_t ev_comm_fork_ = nullptr, ev_comm_done_[COMM_BLOCKS] = {};
+    bool comm_async() const { return c_->allgather_async != nullptr; }
+    int all_gather_begin(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, int slot);
+    int all_gather_end(int slot);
     // recv[s] = the block rank s addressed to this role: send = [G][bytes], recv = [G][bytes]
     int exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes_per_block);
     ShardMap shard_map() const { return ShardMap{logb_, logG_, rank_}; }

@@ -58,6 +58,8 @@ def _worker(rank, world, port, case, options, knobs, q):
         ctx = api.Context(device=0)
         ctx.set_collective(world, rank, api.StagedAllGather(), alltoall=knobs.get("alltoall", True))
         ctx.comm_selftest(4096)
+        if knobs.get("async"):   # stream-ordered all-gather: the coefficient exchange of a segment goes in column blocks beside the transforms
+            ctx.set_collective_async(api.StagedAsyncAllGather())
         if "fri_min_log" in knobs:
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
@@ -105,6 +107,11 @@ CASES = [
     (4, RND(256, 12), (8, 4, 3, 2), {"fri_min_log": 6}),
     (4, RND(128, 13, rc=True), (4, 3, 3, 1), {"fri_min_log": 5, "alltoall": False}),
     (8, RND(256, 14), (8, 3, 3, 1), {}),
+    # stream-ordered all-gather hook: 17 (9) columns per role in four blocks, 9 (5) in three, replicas beyond the blowup factor
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "async": True}),
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "async": True}),
+    (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7, "async": True}),
+    (4, RND(256, 15, rc=True), (8, 4, 3, 2), {"fri_min_log": 6, "async": True}),
 ]
 
 
@@ -125,6 +132,8 @@ def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_
         assert stats["composition_path"] == (1 if case["kind"] == "fib" else 3)
         if knobs.get("alltoall", True) and world <= options[0]:
             assert stats["alltoall_calls"] >= 3          # main, aux and composition commitments at least
+        if knobs.get("async"):
+            assert stats["allgather_calls"] >= 2 * (3 + 3)   # two proofs, each segment's coefficients in three or four blocks
 
 
 def _rccl_worker(rank, world, port, fib_index, options, q):
