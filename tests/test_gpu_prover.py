@@ -156,3 +156,12 @@ def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
     wide = np.zeros((c, n + 64, 32), dtype=np.uint8)
     wide[:, :n] = api.fe_to_device(cols_be.reshape(-1, 32)).reshape(c, n, 32)
     assert hip_ctx.cairo_prove_columns(wide, n, c, run.public_inputs_c, opt, col_stride=n + 64, device_layout=True) == want
+
+
+def test_dropin_golden_on_device(hip_ctx):
+    """The device prover on every reference-generated proof file of tests/golden/dropin/ (README there): same bytes."""
+    from test_oracle_golden import dropin_files, parse_proof_file, run_from_proof_file
+    for path, options in dropin_files():
+        golden, pi = parse_proof_file(path)
+        run = run_from_proof_file(pi)
+        assert hip_ctx.cairo_prove_run(run, api.ProofOptions(*options)) == golden, path

@@ -31,7 +31,11 @@ def parse_proof_file(path):
             rc.append(None)
             p += 1
     nseg = struct.unpack(">Q", pi[p:p + 8])[0]
-    p += 8 + 17 * nseg
+    p += 8
+    segments = []
+    for _ in range(nseg):      # air.rs:247-258: type (1 byte), start, end
+        segments.append((pi[p], struct.unpack(">Q", pi[p + 1:p + 9])[0], struct.unpack(">Q", pi[p + 9:p + 17])[0]))
+        p += 17
     npm = struct.unpack(">Q", pi[p:p + 8])[0]
     p += 8
     pm = {}
@@ -39,7 +43,43 @@ def parse_proof_file(path):
         pm[int.from_bytes(pi[p:p + 32], "big")] = int.from_bytes(pi[p + 32:p + 64], "big")
         p += 64
     num_steps = struct.unpack(">Q", pi[p:p + 8])[0]
-    return proof, dict(regs=regs, rc=rc, public_memory=pm, num_steps=num_steps)
+    return proof, dict(regs=regs, rc=rc, public_memory=pm, num_steps=num_steps, segments=segments)
+
+
+def run_from_proof_file(pi):
+    """Rebuilds the run a CLI proof file was made from: program words = the public memory below the output cells, builtins from
+    the memory segments (0 range_check, 1 output), entry point = pc_init."""
+    out_cells = set()
+    for kind, start, end in pi["segments"]:
+        if kind == 1:
+            out_cells.update(range(start, end))
+    words = [pi["public_memory"][a] for a in sorted(pi["public_memory"]) if a not in out_cells]
+    kinds = {k for k, _, _ in pi["segments"]}
+    if kinds:
+        return api.CairoRun.from_program_builtins(words, output=1 in kinds, range_check=0 in kinds, entry_pc=pi["regs"][0])
+    return api.CairoRun.from_program(words, entry_pc=pi["regs"][0])
+
+
+def dropin_files():
+    import glob
+    import json
+    out = []
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "dropin", "*.proof"))):
+        opt_path = path[:-len(".proof")] + ".options.json"
+        out.append((path, tuple(json.load(open(opt_path))) if os.path.exists(opt_path) else DEFAULT_TEST_OPTIONS))
+    return out
+
+
+def test_dropin_golden(oracle, hip_lib):
+    """Every reference-generated CLI proof file dropped into tests/golden/dropin/ (see its README: e.g. a proof of rc_program,
+    which would pin the 50th constraint to a reference artefact) must be reproduced byte for byte.  None ships today."""
+    for path, options in dropin_files():
+        golden, pi = parse_proof_file(path)
+        run = run_from_proof_file(pi)
+        assert run.num_steps == pi["num_steps"], path
+        got = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+        assert got == golden, path
+        assert oracle.cairo_verify(got, run.public_inputs_c, options), path
 
 
 @pytest.mark.parametrize("name,sha,legacy", [
