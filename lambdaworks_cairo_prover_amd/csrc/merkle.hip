@@ -5,6 +5,7 @@
 // per-thread LDS block buffer so that arbitrary row widths need no run-time indexing of registers.
 #include "merkle.h"
 #include "keccak.h"
+#include <cstdlib>
 
 namespace sp {
 
@@ -125,6 +126,46 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
     nodes[p] = d;
 }
 
+// Two levels per launch for the large levels: thread t owns the subtree under node g = first + t of the UPPER level - it hashes the
+// four consecutive digests below its two children (128 contiguous bytes), writes the two children (64 contiguous bytes) and then
+// their parent.  The permutations are the same 3 per 4 digests; what goes away is every second launch boundary of the
+// throughput-bound part of a tree (the drain of one level and the fill of the next, ~10 - 20 us each) and the round trip of the
+// lower level's digests through HBM.
+__global__ void __launch_bounds__(MK_THREADS) node_hash2_kernel(digest32* nodes, uint64_t first, uint64_t count) {
+    uint64_t i = (uint64_t)blockIdx.x * MK_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t g = first + i, p0 = 2 * g + 1;           // children p0, p0 + 1; their children 2 p0 + 1 .. 2 p0 + 4
+    const digest32* c = nodes + 2 * p0 + 1;
+    uint64_t h[8];
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const digest32 l = c[2 * half], r = c[2 * half + 1];
+        uint64_t s[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) s[k] = 0;
+        s[0] = l.w[0]; s[1] = l.w[1]; s[2] = l.w[2]; s[3] = l.w[3];
+        s[4] = r.w[0]; s[5] = r.w[1]; s[6] = r.w[2]; s[7] = r.w[3];
+        s[8] = 0x01ULL;
+        s[16] = 0x8000000000000000ULL;
+        sp_keccak_f1600_dev(s);
+        h[4 * half] = s[0]; h[4 * half + 1] = s[1]; h[4 * half + 2] = s[2]; h[4 * half + 3] = s[3];
+        digest32 d;
+        d.w[0] = s[0]; d.w[1] = s[1]; d.w[2] = s[2]; d.w[3] = s[3];
+        nodes[p0 + half] = d;
+    }
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) s[k] = h[k];
+    s[8] = 0x01ULL;
+    s[16] = 0x8000000000000000ULL;
+    sp_keccak_f1600_dev(s);
+    digest32 d;
+    d.w[0] = s[0]; d.w[1] = s[1]; d.w[2] = s[2]; d.w[3] = s[3];
+    nodes[g] = d;
+}
+
 // ---- lane-parallel permutation for the small tree levels -------------------------------------------------------------
 // A level with few nodes is latency-bound in node_hash_kernel: one lane needs 24 x 180 dependent-issue instructions
 // (~11 us) however few nodes there are, and a proof has ~300 such levels.  Here 25 lanes share one permutation, lane
@@ -137,6 +178,10 @@ __global__ void __launch_bounds__(MK_THREADS) node_hash_kernel(digest32* nodes, 
 #define SP_MK_LANES_MAX_NODES 4096
 #endif
 constexpr uint32_t MK_LANES_MAX_NODES = SP_MK_LANES_MAX_NODES;
+#ifndef SP_MK_PAIR_MIN_UPPER
+#define SP_MK_PAIR_MIN_UPPER (1u << 17)
+#endif
+constexpr uint64_t MK_PAIR_MIN_UPPER = SP_MK_PAIR_MIN_UPPER;
 __device__ __constant__ const uint8_t SP_KECCAK_RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
 
 // rotation by a per-lane amount with 32-bit funnel shifts (two 64-bit variable shifts and an or are three slow VALU ops):
@@ -271,6 +316,15 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
 int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch) {
     if (ch && n_leaves < 2) return SP_E_INVALID_ARG;
     uint64_t count = n_leaves >> 1;
+    // throughput-bound levels in pairs: the level of `count` nodes and the one above it, while the upper one still fills the chip
+    // (2^17 threads = two waves per SIMD)
+    static const bool pairs = std::getenv("SP_MK_NO_PAIRS") == nullptr;   // (A/B switch of tools/merkle_pair_ab.py)
+    for (; pairs && (count >> 1) >= MK_PAIR_MIN_UPPER && (count >> 1) > MK_LANES_MAX_NODES; count >>= 2) {
+        const uint64_t upper = count >> 1;
+        unsigned blocks = (unsigned)((upper + MK_THREADS - 1) / MK_THREADS);
+        hipLaunchKernelGGL(node_hash2_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, upper - 1, upper);
+        SP_HIP_CHECK(hipGetLastError());
+    }
     for (; count > MK_LANES_MAX_NODES; count >>= 1) {
         unsigned blocks = (unsigned)((count + MK_THREADS - 1) / MK_THREADS);
         hipLaunchKernelGGL(node_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, nodes, count - 1, count);

@@ -38,6 +38,7 @@ StarkProver::~StarkProver() {
     for (auto& u : up_ev_) for (hipEvent_t e : {u.dma0, u.dma1, u.ready, u.done}) if (e) (void)hipEventDestroy(e);
     if (up_start_) (void)hipEventDestroy(up_start_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
+    if (r2c_stream_) (void)hipStreamDestroy(r2c_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
@@ -72,6 +73,7 @@ void StarkProver::free_all() {
     (void)hipSetDevice(c_->device);
     (void)hipStreamSynchronize(c_->stream);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    if (r2c_stream_) (void)hipStreamSynchronize(r2c_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
@@ -228,6 +230,7 @@ void StarkProver::release(void* p, size_t bytes) {
     (void)hipStreamSynchronize(c_->stream);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+    if (r2c_stream_) (void)hipStreamSynchronize(r2c_stream_);
     auto it = std::find(allocs_.begin(), allocs_.end(), p);
     if (it != allocs_.end()) allocs_.erase(it);
     (void)hipFree(p);
@@ -431,6 +434,7 @@ int StarkProver::ensure_upload(uint32_t groups) {
         for (hipEvent_t* e : {&up_ev_[g].dma0, &up_ev_[g].dma1, &up_ev_[g].ready, &up_ev_[g].done})
             if (!*e) SP_HIP_CHECK(hipEventCreate(e));
     SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
+    if (r2c_stream_) SP_HIP_CHECK(hipStreamSynchronize(r2c_stream_));
     return SP_OK;
 }
 
@@ -453,12 +457,15 @@ int StarkProver::finish_upload_stats(uint32_t groups, uint64_t bytes, double gat
 
 // interpolate_and_commit (reference prover.rs:126-159) from host COLUMNS (the layout trace.rs:23-31 `cols()` produces, and what
 // sp_cairo_run keeps): a column group is one contiguous DMA straight into the trace area - no gather, no landing slot - and the
-// groups double (1, 1, 2, 4, 8, 8, ...) so that only the first column's 0.6 ms stay in front of the transforms.
+// groups stay small (1, 1, 2, 2, ...) so that only the first column's 0.6 ms stay in front of the transforms.
 int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        uint32_t w = std::min<uint32_t>(8, std::max<uint32_t>(1, done));
+        // one, one, then two columns at a time: a group is ready when its DMA is (0.6 ms per column of 2^20 rows) and its
+        // transforms take 0.7 ms per column, so with small groups the compute stream waits for the first column only; doubling
+        // groups (1, 1, 2, 4, 8, 8, ...) made it wait 4 ms per proof - every group twice the size of the one being transformed
+        uint32_t w = done < 2 ? 1u : 2u;
         if (G_ > 1 && d_cstage_) w = cols;            // column-sharded interpolation works on the whole segment
         w = std::min(w, cols - done);
         gsize.push_back(w);
@@ -608,13 +615,19 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything
     // behind it still has to be transformed (~0.7 ms per column; 0.2 ms at blowup 4, where the upload is the bound): two single
-    // columns start the pipeline, then the groups double up to eight columns, always from an even column on (two columns share a
-    // 64-byte line of a row) - 1, 1, 2, 4, 8, 8, 8, 2 for 34 columns.  Wide groups are what the gather is good at; their upload is
-    // pipelined inside (chunks of rows), so their width costs little latency.
+    // columns start the pipeline, then groups of two or four columns, always from an even column on (two columns share a 64-byte
+    // line of a row).
+    // How wide may a group get?  A group is usable when all of it has landed, so with the transforms as the bound (blowup 8: 0.70
+    // ms per column against 0.65 ms of upload) narrow groups keep the compute stream fed - two columns: 75.0 ms where eight-column
+    // groups gave 80 - and with the upload as the bound (blowup 4: 0.18 ms of transforms per column) the gather's throughput
+    // decides, which grows with the width (two columns ~40 GB/s, four ~55, eight ~60): four columns.
+    const double transform_ms_per_col = (1.0 + (double)(1u << logb_)) * (double)n_ * logn_ / 2 / 1.35e11 * 1e3;
+    const double upload_ms_per_col = (double)n_ * 32 / 50e9 * 1e3;
+    static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1u; }();
+    static const uint32_t maxw_env = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 0u; }();
+    const uint32_t maxw = maxw_env ? maxw_env : (transform_ms_per_col >= 0.9 * upload_ms_per_col ? 2u : 4u);
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1u; }();
-        static const uint32_t maxw = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 8u; }();
         uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done / grow + 1) / 2)));
         if (cols - done <= w + 1) w = cols - done;     // no one-column tail
         gsize.push_back(w);
@@ -648,8 +661,10 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     double gather_ms = 0;
     struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
     pool_->begin_burst();
+    if (!r2c_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&r2c_stream_, hipStreamNonBlocking));
     SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
+    SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, up_start_, 0));
     uint64_t chunk_no = 0;
     uint32_t c0 = 0;
     for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
@@ -672,13 +687,18 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                 // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the chunk has been
                 // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the
                 // upload stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
+                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been turned into columns
                 SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)rows * cw * 32, hipMemcpyHostToDevice, copy_stream_));
                 SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
-                SP_TRY(rows_to_columns(copy_stream_, c_->enc, landing[slot], rows, cw, trace + (uint64_t)c * n_ + r0, n_));
+                // rows -> columns on a stream of its own: on the copy stream the DMA engine sat idle through every one of these
+                // kernels (~50 us x 34 chunks per proof); on the compute stream they queued behind the previous group's LDE
+                SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, ev_dma_[slot], 0));
+                SP_TRY(rows_to_columns(r2c_stream_, c_->enc, landing[slot], rows, cw, trace + (uint64_t)c * n_ + r0, n_));
+                SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], r2c_stream_));
             }
         }
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, r2c_stream_));
         SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
         const double tge = wall_ms();
         gather_ms += tge - tg - waited;
