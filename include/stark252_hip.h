@@ -260,7 +260,7 @@ int sp_host_alloc(uint64_t bytes, void** out);
 void sp_host_free(void* p);
 void sp_free(void* p);
 /* How the main trace of the last proof reached the device: out = {kind (0: one copy / resident, 1: row-major host buffer gathered
- * into column groups by host threads, 2: DMA of host columns), column groups, bytes, host gather ms (sum), gather GB/s, DMA ms
+ * into column groups by host threads, 2: DMA of page-locked host columns, 3: host columns in pageable memory), column groups, bytes, host gather ms (sum), gather GB/s, DMA ms
  * (sum over the groups), DMA GB/s, exposed ms (how long the compute stream waited for column groups in total), longest wait
  * for one group ms, host wall ms of the upload loop}. */
 int sp_last_upload_stats(sp_ctx* ctx, double out[10]);

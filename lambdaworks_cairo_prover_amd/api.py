@@ -170,7 +170,8 @@ class Context:
         """sp_last_upload_stats of the last proof's main-trace upload."""
         v = (ctypes.c_double * 10)()
         check(self._lib.sp_last_upload_stats(self._h, v))
-        kinds = {0: "single copy / resident", 1: "row-major host buffer, gathered by host threads", 2: "host columns, DMA"}
+        kinds = {0: "single copy / resident", 1: "row-major host buffer, gathered by host threads", 2: "host columns, DMA from page-locked memory",
+                 3: "host columns in PAGEABLE memory (staged by the runtime)"}
         return {"kind": kinds.get(int(v[0]), "?"), "groups": int(v[1]), "bytes": int(v[2]), "gather_ms": round(v[3], 3), "gather_gbs": round(v[4], 1),
                 "dma_ms": round(v[5], 3), "dma_gbs": round(v[6], 1), "exposed_ms": round(v[7], 3), "max_stall_ms": round(v[8], 3), "host_ms": round(v[9], 3)}
 

@@ -8,6 +8,8 @@ namespace sp {
 int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_flag_dev);
 // rows_dev: n_rows x n_cols row-major in ABI encoding `enc` (device memory) -> cols[c*col_stride + r] device layout
 int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n_rows, uint32_t n_cols, fe* cols, uint64_t col_stride);
+// dst_dev[0 .. bytes) = src_pinned_host[0 .. bytes) by a kernel reading the page-locked host memory (16-byte aligned, bytes % 16 == 0)
+int pull_copy(hipStream_t st, const void* src_pinned_host, void* dst_dev, size_t bytes);
 int encode_elements(hipStream_t st, int enc, const fe* in, uint64_t n, uint8_t* out_dev);
 int decode_elements(hipStream_t st, int enc, const uint8_t* in_dev, uint64_t n, fe* out);
 

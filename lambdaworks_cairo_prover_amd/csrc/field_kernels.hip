@@ -1,5 +1,6 @@
 // Element-wise field kernels: batch inversion, layout transposes.
 #include "field_kernels.h"
+#include <cstdlib>
 
 namespace sp {
 
@@ -181,6 +182,27 @@ __global__ void __launch_bounds__(256) decode_kernel(const uint8_t* in, uint64_t
         x = fe_to_mont(raw);
     }
     fk_st(out + i, x);
+}
+
+// Host-to-device copy by a kernel that reads page-locked host memory over PCIe itself (52 - 54 GB/s against 56 for the DMA engine,
+// tools/experiments/pinned_dma_probe.hip).  The prover's column uploads use it because hipMemcpyAsync from a page-locked buffer
+// was sometimes routed through the runtime's staging path - 28 - 37 GB/s and the enqueueing host thread blocked for milliseconds -
+// after earlier page-locked buffers of the process had been freed (profiles/r03_pinned_upload.txt).
+__global__ void __launch_bounds__(256) pull_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+}
+int pull_copy(hipStream_t st, const void* src_pinned_host, void* dst_dev, size_t bytes) {
+    if (bytes % 16 || (reinterpret_cast<uintptr_t>(src_pinned_host) | reinterpret_cast<uintptr_t>(dst_dev)) % 16) return SP_E_INVALID_ARG;
+    static const unsigned blocks = [] { const char* e = std::getenv("SP_UPLOAD_PULL"); int v = e ? std::atoi(e) : 0; return (unsigned)(v > 1 ? v : 64); }();
+    hipLaunchKernelGGL(pull_copy_kernel, dim3(blocks), dim3(256), 0, st, static_cast<const uint4*>(src_pinned_host), static_cast<uint4*>(dst_dev), bytes / 16);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
 }
 
 int encode_elements(hipStream_t st, int enc, const fe* in, uint64_t n, uint8_t* out_dev) {

@@ -426,7 +426,13 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
 int StarkProver::ensure_upload(uint32_t groups) {
     if (groups > (uint32_t)UPLOAD_MAX_GROUPS) { sp_set_error("commit_trace: too many column groups"); return SP_E_UNSUPPORTED; }
     if (!copy_stream_) {
-        SP_HIP_CHECK(hipStreamCreateWithFlags(&copy_stream_, hipStreamNonBlocking));
+        // highest priority: the little kernels of the upload (rows -> columns, decode, the pull copy) must not queue behind the
+        // thousands of work-groups of the transforms they feed (a kernel after every copy on an ordinary stream: 24 GB/s
+        // instead of 56, tools/experiments/dma_pattern_probe.hip)
+        int prio_lo = 0, prio_hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        SP_HIP_CHECK(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, prio_hi));
+        SP_HIP_CHECK(hipStreamCreateWithPriority(&r2c_stream_, hipStreamNonBlocking, prio_hi));
         for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
     }
     if (!up_start_) SP_HIP_CHECK(hipEventCreate(&up_start_));
@@ -473,6 +479,13 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
     }
     const uint32_t groups = (uint32_t)gsize.size();
     SP_TRY(ensure_upload(groups));
+    // page-locked source (sp_host_alloc, a run built after the context): DMA at PCIe speed; pageable: the runtime's staging copy.
+    // SP_UPLOAD_PULL=1 replaces the DMA of a page-locked source by a copy kernel that reads it over PCIe (experiment).
+    hipPointerAttribute_t attr{};
+    const bool pinned = hipPointerGetAttributes(&attr, cols_host) == hipSuccess && attr.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    static const bool want_pull = std::getenv("SP_UPLOAD_PULL") != nullptr;
+    const bool pull = pinned && want_pull && (reinterpret_cast<uintptr_t>(cols_host) % 16 == 0);
     const double t0 = wall_ms();
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
@@ -485,11 +498,15 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
         const uint32_t w = gsize[g];
         fe* dst = trace + (uint64_t)c0 * n_;
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
+        auto h2d = [&](void* to, const uint8_t* from, size_t bytes) -> int {
+            if (pull) return pull_copy(copy_stream_, from, to, bytes);
+            SP_HIP_CHECK(hipMemcpyAsync(to, from, bytes, hipMemcpyHostToDevice, copy_stream_));
+            return SP_OK;
+        };
         if (col_stride == n_) {
-            SP_HIP_CHECK(hipMemcpyAsync(dst, cols_host + (size_t)c0 * n_ * 32, (size_t)w * n_ * 32, hipMemcpyHostToDevice, copy_stream_));
+            SP_TRY(h2d(dst, cols_host + (size_t)c0 * n_ * 32, (size_t)w * n_ * 32));
         } else {
-            for (uint32_t j = 0; j < w; ++j)
-                SP_HIP_CHECK(hipMemcpyAsync(dst + (uint64_t)j * n_, cols_host + (size_t)(c0 + j) * col_stride * 32, (size_t)n_ * 32, hipMemcpyHostToDevice, copy_stream_));
+            for (uint32_t j = 0; j < w; ++j) SP_TRY(h2d(dst + (uint64_t)j * n_, cols_host + (size_t)(c0 + j) * col_stride * 32, (size_t)n_ * 32));
         }
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
         if (col_enc >= 0) SP_TRY(decode_elements(copy_stream_, col_enc, reinterpret_cast<const uint8_t*>(dst), (uint64_t)w * n_, dst));   // element-wise, in place
@@ -510,7 +527,9 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
         rc = commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out);
         if (rc == SP_OK) stage_ = segment == 0 ? 2 : 3;
     }
-    if (rc == SP_OK) SP_TRY(finish_upload_stats(groups, (uint64_t)cols * n_ * 32, 0.0, host_ms, 2));
+    if (rc == SP_OK) {
+        SP_TRY(finish_upload_stats(groups, (uint64_t)cols * n_ * 32, 0.0, host_ms, pinned ? 2 : 3));
+    }
     return rc;
 }
 
@@ -661,7 +680,6 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     double gather_ms = 0;
     struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
     pool_->begin_burst();
-    if (!r2c_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&r2c_stream_, hipStreamNonBlocking));
     SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
     SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, up_start_, 0));

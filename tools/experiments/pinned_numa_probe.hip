@@ -12,6 +12,15 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <sched.h>
+#include <unistd.h>
+#include <sys/syscall.h>
+static void run_on_cpu(int cpu) { cpu_set_t s; CPU_ZERO(&s); CPU_SET(cpu, &s); sched_setaffinity(0, sizeof s, &s); }
+static void run_anywhere() { cpu_set_t s; CPU_ZERO(&s); for (int i = 0; i < 256; ++i) CPU_SET(i, &s); sched_setaffinity(0, sizeof s, &s); }
+static long prefer_node(int node) {   // MPOL_PREFERRED = 1, MPOL_DEFAULT = 0
+    unsigned long mask = node >= 0 ? 1ul << node : 0;
+    return syscall(SYS_set_mempolicy, node >= 0 ? 1 : 0, node >= 0 ? &mask : nullptr, node >= 0 ? 64 : 0);
+}
 static double now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static std::string numa_of(void* p) {
     std::ifstream f("/proc/self/numa_maps");
@@ -37,6 +46,24 @@ int main() {
     hipDeviceGetPCIBusId(bus, sizeof bus, 0);
     { std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node"; for (auto& ch : path) ch = tolower(ch); std::ifstream f(path); f >> node; }
     printf("GPU 0 at %s, numa_node %d\n", bus, node);
+    {   // the allocating thread on the other socket, with and without a memory policy that prefers the GPU's node
+        struct C2 { const char* name; int cpu; int prefer; } c2[] = {{"allocated from CPU 70 (node 1), default policy", 70, -1}, {"allocated from CPU 70 (node 1), MPOL_PREFERRED node of the GPU", 70, node},
+                                                                     {"allocated from CPU 3 (node 0), default policy", 3, -1}};
+        for (auto& c : c2) {
+            run_on_cpu(c.cpu);
+            if (c.prefer >= 0) prefer_node(c.prefer);
+            void* h = nullptr;
+            if (hipHostMalloc(&h, bytes, hipHostMallocDefault) != hipSuccess) { printf("%s: allocation failed\n", c.name); continue; }
+            prefer_node(-1);
+            memset(h, 1, bytes);
+            hipMemcpy(dev, h, bytes, hipMemcpyHostToDevice);
+            double best = 1e9;
+            for (int r = 0; r < 3; ++r) { double a = now(); hipMemcpy(dev, h, bytes, hipMemcpyHostToDevice); best = std::min(best, now() - a); }
+            printf("%-64s H2D %5.1f GB/s, pages: %s\n", c.name, bytes / best * 1e-6, numa_of(h).c_str());
+            hipHostFree(h);
+            run_anywhere();
+        }
+    }
     struct Case { const char* name; unsigned flags; int touch_threads; } cases[] = {
         {"default flags, touched by this thread", hipHostMallocDefault, 1}, {"default flags, touched by 16 threads", hipHostMallocDefault, 16},
         {"hipHostMallocNumaUser, touched by this thread", hipHostMallocNumaUser, 1}, {"hipHostMallocNumaUser, touched by 16 threads", hipHostMallocNumaUser, 16},
