@@ -497,6 +497,11 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
     for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
         const uint32_t w = gsize[g];
         fe* dst = trace + (uint64_t)c0 * n_;
+        // One copy in flight at a time: the runtime picks the SDMA engine of a copy when it is ENQUEUED, and with the first engine
+        // still busy it takes another one - copies of one stream hopping between engines ran at 27 - 37 GB/s instead of 56 for whole
+        // proofs (profiles/r03_pinned_upload.txt: config #4 38 ms instead of 27).  The host has nothing else to do here.
+        static const bool free_running = std::getenv("SP_UPLOAD_FREE_RUNNING") != nullptr;
+        if (g >= 1 && !free_running) SP_HIP_CHECK(hipEventSynchronize(up_ev_[g - 1].dma1));
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
         auto h2d = [&](void* to, const uint8_t* from, size_t bytes) -> int {
             if (pull) return pull_copy(copy_stream_, from, to, bytes);
@@ -706,6 +711,9 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                 // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the
                 // upload stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
                 if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been turned into columns
+                // (no "one copy in flight" wait here, unlike commit_trace_columns: a chunk's DMA is enqueued after a gather that took
+                // about as long as the previous DMA, so the engine is mostly idle by then, and blocking this thread delays the next
+                // gather - 38.5 against 35 ms at config #4 on a slow host)
                 SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)rows * cw * 32, hipMemcpyHostToDevice, copy_stream_));
                 SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
                 // rows -> columns on a stream of its own: on the copy stream the DMA engine sat idle through every one of these
