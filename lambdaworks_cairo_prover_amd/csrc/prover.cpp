@@ -33,6 +33,9 @@ void host_pool_delete(HostPool* p);
 
 StarkProver::~StarkProver() {
     free_all();
+    if (arena_) (void)hipFree(arena_);
+    arena_ = nullptr; arena_cap_ = 0;
+    c_->prover_device_bytes = 0;
     for (auto& e : ev_dma_) if (e) (void)hipEventDestroy(e);
     for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
     for (auto& u : up_ev_) for (hipEvent_t e : {u.dma0, u.dma1, u.ready, u.done}) if (e) (void)hipEventDestroy(e);
@@ -83,17 +86,27 @@ void StarkProver::free_all() {
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
     alloc_bytes_ = 0;
+    arena_off_ = 0;      // the arena itself stays: the next shape is carved out of it
+    publish_device_bytes();
 }
 
 int StarkProver::alloc(void** p, size_t bytes) {
+    const uint64_t aligned = ((uint64_t)(bytes ? bytes : 1) + 255) & ~(uint64_t)255;
+    if (measuring_) { *p = reinterpret_cast<void*>(uintptr_t(256)); measured_ += aligned; return SP_OK; }   // (sizing pass of setup_impl)
+    if (arena_ && arena_off_ + aligned <= arena_cap_) {
+        *p = arena_ + arena_off_;
+        arena_off_ += aligned;
+        return SP_OK;
+    }
     *p = nullptr;
     if (hipMalloc(p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
         sp_set_error("hipMalloc failed (" + std::to_string(bytes) + " bytes)");
         return SP_E_ALLOC;
     }
     allocs_.push_back(*p);
     alloc_bytes_ += bytes;
-    c_->prover_device_bytes = alloc_bytes_;
+    publish_device_bytes();
     return SP_OK;
 }
 
@@ -117,7 +130,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         return SP_E_INVALID_ARG;
     }
     if (c_->world > 1 && !c_->allgather) { sp_set_error("setup: world > 1 needs sp_set_collective / sp_comm_init_rccl"); return SP_E_STATE; }
-    if (ready_ && !allocs_.empty() && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
+    if (ready_ && (arena_ || !allocs_.empty()) && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
         opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
@@ -144,44 +157,73 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     hinv_ = fe_inv(h_);
     half_ = fe_inv(fe_from_u64(2)); binv_ = fe_inv(fe_from_u64(1ull << lb));
     g_ = host_primitive_root((int)logn_);
-    SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
-    SP_TRY(alloc((void**)&d_trace_, sizeof(fe) * n_ * C_));
-    SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * std::max<uint64_t>(Nl_, n_) * C_));  // >= n per column: also stages the raw rows
-    SP_TRY(alloc((void**)&d_t1_, sizeof(fe) * n_));
-    SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
-    SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
-    SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * Nl_ * 2));
-    SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * scratch_elems()));
-    if (G_ > 1) {
-        SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
-        SP_TRY(alloc((void**)&d_recv_, sizeof(fe) * Nl_));
-        SP_TRY(alloc((void**)&d_roots_, sizeof(digest32) * world_));
-        if (c_->opt_shard_interpolation) {
-            cpr_max_ = (std::max(Cm_, Ca_) + G_ - 1) / G_;
-            SP_TRY(alloc((void**)&d_cstage_, sizeof(fe) * (uint64_t)world_ * cpr_max_ * n_));
+    // Every buffer whose size setup() knows, in one pass that runs twice: first to size the arena, then to carve it.
+    auto allocate_all = [&]() -> int {
+        SP_TRY(alloc((void**)&d_coeffs_, sizeof(fe) * n_ * C_));
+        SP_TRY(alloc((void**)&d_trace_, sizeof(fe) * n_ * C_));
+        SP_TRY(alloc((void**)&d_lde_, sizeof(fe) * std::max<uint64_t>(Nl_, n_) * C_));  // >= n per column: also stages the raw rows
+        SP_TRY(alloc((void**)&d_t1_, sizeof(fe) * n_));
+        SP_TRY(alloc((void**)&d_t2_, sizeof(fe) * n_));
+        SP_TRY(alloc((void**)&d_h12s_, sizeof(fe) * n_ * 2));
+        SP_TRY(alloc((void**)&d_h12_, sizeof(fe) * Nl_ * 2));
+        SP_TRY(alloc((void**)&d_scratch_, sizeof(fe) * scratch_elems()));
+        if (G_ > 1) {
+            SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
+            SP_TRY(alloc((void**)&d_recv_, sizeof(fe) * Nl_));
+            SP_TRY(alloc((void**)&d_roots_, sizeof(digest32) * world_));
+            if (c_->opt_shard_interpolation) {
+                cpr_max_ = (std::max(Cm_, Ca_) + G_ - 1) / G_;
+                SP_TRY(alloc((void**)&d_cstage_, sizeof(fe) * (uint64_t)world_ * cpr_max_ * n_));
+            }
         }
+        SP_TRY(alloc_tree(tree_main_, N_, G_ > 1));
+        SP_TRY(alloc_tree(tree_aux_, N_, G_ > 1));
+        SP_TRY(alloc_tree(tree_comp_, N_, G_ > 1));
+        SP_TRY(alloc((void**)&d_comp_consts_, sizeof(CompositionConsts)));
+        SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
+        SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
+        // FRI: layers of at least 2^opt_fri_shard_min_log leaves (and at least 2 G^2, so that every rank owns whole blocks of the
+        // digest exchange) stay sharded; from layer fri_rep_ on every rank holds the whole layer.  The last, uncommitted fold
+        // output (layer log n) is always replicated.
+        fri_rep_ = 0;
+        if (G_ > 1)
+            while (fri_rep_ < logn_ && (N_ >> fri_rep_) >= std::max<uint64_t>(1ull << c_->opt_fri_shard_min_log, 2ull * G_ * G_)) ++fri_rep_;
+        d_fri_evals_.clear(); fri_trees_.clear();
+        for (uint32_t l = 0; l <= logn_; ++l) {
+            fe* e = nullptr;
+            const uint64_t M = N_ >> l;
+            SP_TRY(alloc((void**)&e, sizeof(fe) * (fri_sharded(l) ? M >> logG_ : M)));
+            d_fri_evals_.push_back(e);
+            if (l < logn_) { TreeBuf t; SP_TRY(alloc_tree(t, M, fri_sharded(l))); fri_trees_.push_back(t); }
+        }
+        SP_TRY(alloc((void**)&d_post_comp_, sizeof(fe) * 2 * n_));
+        SP_TRY(alloc((void**)&d_post_deep_, sizeof(fe) * n_));
+        d_post_comp0_ = nullptr;
+        if (G_ > 1 && logG_ == logb_) SP_TRY(alloc((void**)&d_post_comp0_, sizeof(fe) * 2 * n_));
+        return SP_OK;
+    };
+    measuring_ = true; measured_ = 0;
+    const int rc_measure = allocate_all();
+    measuring_ = false;
+    SP_TRY(rc_measure);
+    {
+        // room for what a Cairo proof allocates on first use (auxiliary-trace workspace, side-stream inverses, upload landing
+        // ring is part of the scratch): those allocations find their place in the arena too instead of costing a hipMalloc each
+        size_t sort_tmp = 0;
+        const uint64_t lazy = (Ca_ == 18 ? aux_workspace_bytes(n_, 4096, &sort_tmp) : 0) + sizeof(fe) * 19 * n_ + (4u << 20);
+        const uint64_t need = measured_ + lazy;
+        if (arena_cap_ < need) {
+            if (arena_) (void)hipFree(arena_);
+            arena_ = nullptr; arena_cap_ = 0;
+            void* a = nullptr;
+            if (hipMalloc(&a, need) == hipSuccess) { arena_ = static_cast<uint8_t*>(a); arena_cap_ = need; }
+            else (void)hipGetLastError();     // no single block of that size: the buffers are allocated one by one
+        }
+        arena_off_ = 0;
+        publish_device_bytes();
     }
-    SP_TRY(alloc_tree(tree_main_, N_, G_ > 1));
-    SP_TRY(alloc_tree(tree_aux_, N_, G_ > 1));
-    SP_TRY(alloc_tree(tree_comp_, N_, G_ > 1));
-    SP_TRY(alloc((void**)&d_comp_consts_, sizeof(CompositionConsts)));
-    SP_TRY(alloc((void**)&d_deep_consts_, sizeof(DeepConsts)));
-    SP_TRY(alloc((void**)&d_nonce_, sizeof(unsigned long long)));
+    SP_TRY(allocate_all());
     d_memcols_ = d_trace_ + 19 * n_;  // pc .. off_op1 columns of the main trace (input of the Cairo auxiliary trace)
-    // FRI: layers of at least 2^opt_fri_shard_min_log leaves (and at least 2 G^2, so that every rank owns whole blocks of the
-    // digest exchange) stay sharded; from layer fri_rep_ on every rank holds the whole layer.  The last, uncommitted fold
-    // output (layer log n) is always replicated.
-    fri_rep_ = 0;
-    if (G_ > 1)
-        while (fri_rep_ < logn_ && (N_ >> fri_rep_) >= std::max<uint64_t>(1ull << c_->opt_fri_shard_min_log, 2ull * G_ * G_)) ++fri_rep_;
-    d_fri_evals_.clear(); fri_trees_.clear();
-    for (uint32_t l = 0; l <= logn_; ++l) {
-        fe* e = nullptr;
-        const uint64_t M = N_ >> l;
-        SP_TRY(alloc((void**)&e, sizeof(fe) * (fri_sharded(l) ? M >> logG_ : M)));
-        d_fri_evals_.push_back(e);
-        if (l < logn_) { TreeBuf t; SP_TRY(alloc_tree(t, M, fri_sharded(l))); fri_trees_.push_back(t); }
-    }
     SP_TIMEPOINT("  setup: device allocations");
     // T1[q] = n^-1 h^rev(q): turns the unscaled DIF output into h-scaled coefficients c_k h^k (bit-reversed order)
     fe ninv = fe_inv(fe_from_u64(n_));
@@ -194,8 +236,6 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     // post factors of the 2n-point composition split and of the one-coset DEEP interpolation: functions of the shape and of
     // this rank's first coset only, so they are generated once per setup instead of once per proof
     {
-        SP_TRY(alloc((void**)&d_post_comp_, sizeof(fe) * 2 * n_));
-        SP_TRY(alloc((void**)&d_post_deep_, sizeof(fe) * n_));
         const fe wN = host_primitive_root((int)logN_);
         const fe u = fe_inv(fe_pow_u64(wN, rank_));  // w_N^-c0
         const fe minv = fe_inv(fe_from_u64(2 * n_));
@@ -203,9 +243,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
         SP_TRY(gen_power_table(c_->stream, d_post_comp_, n_, logn_, base, minv));
         SP_TRY(gen_power_table(c_->stream, d_post_comp_ + n_, n_, logn_, base, fe_mul(minv, fe_mul(hinv_, u))));
         SP_TRY(gen_power_table(c_->stream, d_post_deep_, n_, logn_, u, fe_inv(fe_from_u64(n_))));
-        d_post_comp0_ = nullptr;
-        if (G_ > 1 && logG_ == logb_) {   // one coset per rank: the composition pair (0, b/2) is interpolated with c0 = 0 everywhere
-            SP_TRY(alloc((void**)&d_post_comp0_, sizeof(fe) * 2 * n_));
+        if (d_post_comp0_) {   // one coset per rank: the composition pair (0, b/2) is interpolated with c0 = 0 everywhere
             SP_TRY(gen_power_table(c_->stream, d_post_comp0_, n_, logn_, hinv_, minv));
             SP_TRY(gen_power_table(c_->stream, d_post_comp0_ + n_, n_, logn_, hinv_, fe_mul(minv, hinv_)));
         }
@@ -232,10 +270,11 @@ void StarkProver::release(void* p, size_t bytes) {
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (r2c_stream_) (void)hipStreamSynchronize(r2c_stream_);
     auto it = std::find(allocs_.begin(), allocs_.end(), p);
-    if (it != allocs_.end()) allocs_.erase(it);
+    if (it == allocs_.end()) return;     // carved out of the arena: the space comes back with the next setup()
+    allocs_.erase(it);
     (void)hipFree(p);
     alloc_bytes_ -= std::min<uint64_t>(alloc_bytes_, bytes);
-    c_->prover_device_bytes = alloc_bytes_;
+    publish_device_bytes();
 }
 
 int StarkProver::ensure_gather(uint64_t elems) {

@@ -173,8 +173,15 @@ class StarkProver : public sp_deletable {
     ShardMap shard_map() const { return ShardMap{logb_, logG_, rank_}; }
     bool has_rc_ = false;
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator
-    std::vector<void*> allocs_;
-    uint64_t alloc_bytes_ = 0;              // device memory held by this prover (sp_prover_device_bytes)
+    std::vector<void*> allocs_;             // buffers outside the arena (grown on demand, or when the arena could not be had)
+    uint64_t alloc_bytes_ = 0;              // bytes of those
+    // One device allocation for everything setup() sizes: a context that proves traces of different shapes re-carves it instead
+    // of freeing and allocating ~25 buffers (22 GB at config #3) - hipFree / hipMalloc of that took 35 ms on some boxes of the
+    // pool and 0.4 - 1.9 s on others (profiles/r03_pinned_upload.txt).  It only ever grows.
+    uint8_t* arena_ = nullptr;
+    uint64_t arena_cap_ = 0, arena_off_ = 0;
+    bool measuring_ = false; uint64_t measured_ = 0;
+    void publish_device_bytes() { c_->prover_device_bytes = arena_cap_ + alloc_bytes_; }
     fe *d_coeffs_ = nullptr, *d_lde_ = nullptr, *d_t1_ = nullptr, *d_t2_ = nullptr;
     fe* d_trace_ = nullptr;  // [C][n] the trace itself, natural order (kept for the constraint check of round 2)
     fe *d_h12s_ = nullptr, *d_h12_ = nullptr, *d_scratch_ = nullptr;  // scratch: 4N elements

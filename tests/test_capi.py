@@ -83,3 +83,32 @@ def test_header_is_plain_c_and_a_c_caller_links(hip_lib, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert ("ntt round trip: rc 0, identical" in out.stdout) or ("sp_ctx_create: -2" in out.stdout)
+
+
+def test_host_side_helpers_of_round_3(hip_lib):
+    """sp_abi_version / sp_air_desc_size (binding checks), sp_host_cpus (affinity mask and cgroup quota), and the argument checks
+    of the host-memory entry points - none of them needs a GPU."""
+    import ctypes
+    from lambdaworks_cairo_prover_amd import air
+    assert hip_lib.sp_abi_version() == _lib.SP_ABI_VERSION
+    hip_lib.sp_air_desc_size.restype = ctypes.c_uint64
+    assert hip_lib.sp_air_desc_size() == ctypes.sizeof(air.AirDescC)
+    n = ctypes.c_int(0)
+    assert hip_lib.sp_host_cpus(ctypes.byref(n)) == 0 and 1 <= n.value <= (os.cpu_count() or 1)
+    assert n.value <= len(os.sched_getaffinity(0))
+    assert hip_lib.sp_host_cpus(None) == _lib.SP_E_INVALID_ARG
+    assert hip_lib.sp_host_alloc(ctypes.c_uint64(64), None) == _lib.SP_E_INVALID_ARG
+    hip_lib.sp_host_free(None)                                   # a no-op, like free(NULL)
+    assert hip_lib.sp_cairo_prove_run(None, None, None, None, None) == _lib.SP_E_INVALID_ARG
+    assert hip_lib.sp_cairo_prove_columns(None, None, ctypes.c_uint64(8), 34, ctypes.c_uint64(0), 0, None, None, None, None) == _lib.SP_E_INVALID_ARG
+    assert hip_lib.sp_last_upload_stats(None, None) == _lib.SP_E_INVALID_ARG
+    assert hip_lib.sp_comm_init_null(None, 2, 0) == _lib.SP_E_INVALID_ARG
+    assert hip_lib.sp_set_collective_async(None, None) == _lib.SP_E_INVALID_ARG
+    # a run keeps its trace column-major; without a context in the process the store is ordinary memory (no HIP runtime touched)
+    run = api.CairoRun.fibonacci(30)
+    addr, rows, cols, pinned = run.columns()
+    assert addr and rows == run.n_rows and cols == 34
+    count = ctypes.c_int(0)
+    hip_lib.sp_device_count(ctypes.byref(count))
+    if count.value == 0:
+        assert not pinned

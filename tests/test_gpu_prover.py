@@ -165,3 +165,31 @@ def test_dropin_golden_on_device(hip_ctx):
         golden, pi = parse_proof_file(path)
         run = run_from_proof_file(pi)
         assert hip_ctx.cairo_prove_run(run, api.ProofOptions(*options)) == golden, path
+
+
+def test_column_entry_point_argument_checks(hip_ctx):
+    """sp_cairo_prove_columns / sp_host_alloc misuse is reported, not executed: a stride below the trace length, a column count the
+    Cairo AIR does not have; page-locked memory from sp_host_alloc works as a source and is reported as such."""
+    import ctypes
+    from lambdaworks_cairo_prover_amd import _lib
+    run = api.CairoRun.fibonacci(60)
+    opt = api.ProofOptions(4, 3, 3, 1)
+    n, c = run.n_rows, run.n_cols
+    cols_be = np.ascontiguousarray(run.main_trace().transpose(1, 0, 2))
+    want = hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt)
+    with pytest.raises(api.SpError) as e:
+        hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt, col_stride=n - 1)
+    assert e.value.code == _lib.SP_E_INVALID_ARG
+    with pytest.raises(api.SpError):
+        hip_ctx.cairo_prove_columns(cols_be, n, c - 1, run.public_inputs_c, opt)
+    lib = hip_ctx._lib
+    buf = ctypes.c_void_p()
+    assert lib.sp_host_alloc(ctypes.c_uint64(cols_be.nbytes), ctypes.byref(buf)) == 0 and buf.value
+    try:
+        ctypes.memmove(buf.value, cols_be.ctypes.data, cols_be.nbytes)
+        assert hip_ctx.cairo_prove_columns(buf.value, n, c, run.public_inputs_c, opt) == want
+        assert hip_ctx.last_upload_stats()["kind"].startswith("host columns, DMA from page-locked")
+    finally:
+        lib.sp_host_free(buf)
+    assert hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt) == want      # pageable columns
+    assert "PAGEABLE" in hip_ctx.last_upload_stats()["kind"]
