@@ -195,6 +195,12 @@ int sp_prove_setup(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_col
  * iNTT + LDE + batched Keccak Merkle tree; keeps polynomials, LDE and tree on the device. */
 int sp_commit_trace(sp_ctx* ctx, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]);
 
+/* The same from host COLUMNS - what interpolate_and_commit itself starts from (`trace.cols()`, prover.rs:130, trace.rs:23-31):
+ * column j of the segment at cols + j*col_stride*32 (col_stride in elements, 0 = n); device_layout != 0: elements in the DEVICE
+ * layout, 0: context encoding.  One DMA per column group, no host-side gather (see sp_cairo_prove_columns, sp_host_alloc). */
+int sp_commit_trace_columns(sp_ctx* ctx, int segment, const uint8_t* cols, uint64_t n, uint32_t n_cols, uint64_t col_stride,
+                            int device_layout, uint8_t root_out[32]);
+
 /* CairoAIR::build_auxiliary_trace + interpolate_and_commit of the auxiliary segment, entirely on the device
  * (reference src/cairo/air.rs:660-729, src/starks/prover.rs:199-213): rap = alpha_memory, z_memory, z_range_check
  * sampled by the caller after the main root. Requires sp_commit_trace(0) of a Cairo main trace (34|43 columns). */

@@ -35,6 +35,15 @@ int sp_commit_trace(sp_ctx* c, int segment, const uint8_t* rows, uint64_t n, uin
     return h->prover.commit_trace(segment, rows, cols, root_out);
 }
 
+int sp_commit_trace_columns(sp_ctx* c, int segment, const uint8_t* cols, uint64_t n, uint32_t n_cols, uint64_t col_stride, int device_layout,
+                            uint8_t root_out[32]) {
+    if (!c) return SP_E_INVALID_ARG;
+    ProverHolder* h = holder(c, false);
+    if (!h) { sp_set_error("sp_prove_setup not called"); return SP_E_STATE; }
+    if (n != h->prover.n()) return SP_E_INVALID_ARG;
+    return h->prover.commit_trace(segment, cols, n_cols, root_out, StarkProver::TRACE_HOST_COLUMNS, device_layout ? -1 : c->enc, col_stride);
+}
+
 int sp_cairo_commit_aux(sp_ctx* c, const uint8_t* rap, const sp_cairo_public_inputs* pub, uint8_t root_out[32]) {
     if (!c || !rap || !pub || !root_out) return SP_E_INVALID_ARG;
     ProverHolder* h = holder(c, false);

@@ -162,3 +162,32 @@ def test_mont_limbs_encoding_gives_the_same_proof(hip_lib, oracle):
     with api.Context(device=0, fe_encoding=api.SP_FE_MONT_LIMBS) as ctx:
         got = ctx.cairo_prove(trace_lw, run.public_inputs_c, api.ProofOptions(*options))
     assert got == want
+
+
+def test_commit_trace_columns_gives_the_root_of_the_row_major_call(hip_lib):
+    """sp_commit_trace_columns (`trace.cols()`, what interpolate_and_commit starts from, prover.rs:130): same root as
+    sp_commit_trace on the row-major table - in the context encoding, and strided in the device layout."""
+    import numpy as np
+    lib = hip_lib
+    run = api.CairoRun.fibonacci(200)
+    trace = run.main_trace()
+    n = trace.shape[0]
+    opt = api.ProofOptions(4, 4, 3, 2).to_c()
+    u8p = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))
+    roots = []
+    cols_be = np.ascontiguousarray(trace.transpose(1, 0, 2))
+    wide = np.zeros((34, n + 16, 32), dtype=np.uint8)
+    wide[:, :n] = api.fe_to_device(cols_be.reshape(-1, 32)).reshape(34, n, 32)
+    with api.Context(device=0) as ctx:
+        for how in ("rows", "columns", "device-layout columns"):
+            root = (ctypes.c_uint8 * 32)()
+            _lib.check(lib.sp_prove_setup(ctx._h, ctypes.c_uint64(n), 34, 18, 0, ctypes.byref(opt)))
+            if how == "rows":
+                _lib.check(lib.sp_commit_trace(ctx._h, 0, u8p(trace), ctypes.c_uint64(n), 34, root))
+            elif how == "columns":
+                _lib.check(lib.sp_commit_trace_columns(ctx._h, 0, u8p(cols_be), ctypes.c_uint64(n), 34, ctypes.c_uint64(0), 0, root))
+            else:
+                _lib.check(lib.sp_commit_trace_columns(ctx._h, 0, u8p(wide), ctypes.c_uint64(n), 34, ctypes.c_uint64(n + 16), 1, root))
+            roots.append(bytes(root))
+        assert lib.sp_commit_trace_columns(ctx._h, 0, u8p(cols_be), ctypes.c_uint64(n), 34, ctypes.c_uint64(0), 0, root) == _lib.SP_E_STATE   # segment 0 is committed
+    assert roots[0] == roots[1] == roots[2]
