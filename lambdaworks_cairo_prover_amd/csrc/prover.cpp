@@ -141,6 +141,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     ready_ = false; stage_ = 0;
     d_auxws_ = nullptr; auxws_bytes_ = 0; auxws_pm_cap_ = 0; d_hfull_ = nullptr; d_hnat_ = nullptr; h_full_ = false;
     d_air_prog_ = nullptr; d_ex_roots_ = nullptr; ex_roots_cap_ = 0;
+    d_flags_all_ = nullptr;
     d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_small_ = nullptr; d_deepx_ = nullptr; deepx_cap_ = 0; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
@@ -958,7 +959,7 @@ int StarkProver::composition_precheck(const fe rap[3], const std::vector<Boundar
     K.n_boundary = B; K.n_transitions = n_transitions; K.main_cols = Cm_; K.has_rc_builtin = has_rc_ ? 1 : 0;
     SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_chk_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
-    SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_chk_, c_->d_flag));
+    SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_chk_, c_->d_flag, check_row0(), check_rows()));
     check_pending_ = true;
     return SP_OK;
 }
@@ -1210,9 +1211,19 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     bool pair_path = allow_sub_coset && !sub_coset && G_ > 1 && logb_ == logG_ && d_post_comp0_;
     if (sub_coset || pair_path) {
         if (prog_dev) SP_TRY(air_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, prog_dev, c_->d_flag));
-        else if (!prechecked) SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag));
-        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
+        else if (!prechecked) SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_, c_->d_flag, check_row0(), check_rows()));
+        if (!prog_dev && world_ > 1 && n_ >= 256ull * world_) {
+            // every rank checked its own n / world rows of the (replicated) trace: one flag per rank, combined everywhere
+            if (!d_flags_all_) SP_TRY(alloc((void**)&d_flags_all_, sizeof(int) * world_));
+            SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int)));
+            std::vector<int> flags(world_, 0);
+            SP_HIP_CHECK(hipMemcpyAsync(flags.data(), d_flags_all_, sizeof(int) * world_, hipMemcpyDeviceToHost, c_->stream));
+            SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
+            for (int f : flags) flag |= f;
+        } else {
+            SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+            SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
+        }
         sub_coset = sub_coset && flag == 0;
         pair_path = pair_path && flag == 0;
         SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));

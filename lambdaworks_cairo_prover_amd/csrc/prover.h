@@ -154,6 +154,10 @@ class StarkProver : public sp_deletable {
     digest32* d_roots_ = nullptr;                          // [world] subtree roots
     fe* d_small_ = nullptr;                                // out-of-domain values of this rank's columns and their all-gather
     fe* d_fullN_ = nullptr;                                // [N] whole-domain scratch when FRI layer 0 is sharded (exceptional paths)
+    int* d_flags_all_ = nullptr;                           // [world] flags of the row-sharded trace check
+    // the slice of the trace rows this rank checks in round 2 (the Cairo constraint check is row-local: the trace is replicated)
+    uint64_t check_row0() const { return (world_ > 1 && n_ >= 256ull * world_) ? (n_ / world_) * wrank_ : 0; }
+    uint64_t check_rows() const { return (world_ > 1 && n_ >= 256ull * world_) ? (wrank_ + 1 == world_ ? n_ - (n_ / world_) * wrank_ : n_ / world_) : n_; }
     int ensure_gather(uint64_t elems);
     int ensure_deep_scratch(uint64_t elems);
     fe* d_deepx_ = nullptr; uint64_t deepx_cap_ = 0;   // DEEP inverses when they outgrow the shared scratch

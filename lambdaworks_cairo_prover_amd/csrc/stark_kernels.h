@@ -53,7 +53,8 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t co
                       const fe* roots_N, const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log = 0, uint32_t shard_rank = 0);
 // validate_trace (reference src/starks/debug.rs:13-104) on the device: *flag_dev |= 1 unless every transition
 // constraint vanishes on every row it is enforced on and every boundary value matches.  trace: [C][n] natural order.
-int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev);
+// rows row0 .. row0 + rows - 1 only (rows = 0: to the end): the ranks of a sharded prover check a slice each and combine the flags
+int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev, uint64_t row0 = 0, uint64_t rows = 0);
 
 // ---- AIRs given as a constraint program (include/stark252_hip.h sp_air_desc; reference trait src/starks/traits.rs:15-119)
 constexpr int AIR_MAX_OPS = 2048, AIR_MAX_LIVE = 64, AIR_MAX_CONSTS = 96, AIR_MAX_OFFSETS = 8, AIR_MAX_EXEMPT_KINDS = 4, AIR_MAX_TRANSITIONS = 64;

@@ -106,7 +106,7 @@ template <bool CHECK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SP_COMP_WAVES, SP_COMP_WAVES)))
 cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
                          const fe* __restrict__ roots, const CompositionConsts* __restrict__ K, const fe* __restrict__ binv,
-                         fe* __restrict__ out, int* __restrict__ flag, uint32_t shard_log, uint32_t shard_rank) {
+                         fe* __restrict__ out, int* __restrict__ flag, uint32_t shard_log, uint32_t shard_rank, uint64_t row0, uint64_t row_end) {
     extern __shared__ __attribute__((aligned(16))) uint4 sh_raw[];
     fe* sh_coef = reinterpret_cast<fe*>(sh_raw);  // [b][T + B]
     const uint32_t b = 1u << logb;
@@ -118,8 +118,9 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
         }
         __syncthreads();
     }
-    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= count) return;
+    // (CHECK: rows row0 .. row_end - 1 of the count-row trace - a rank of a sharded prover checks its own slice of the rows)
+    const uint64_t i = (CHECK ? row0 : 0) + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (CHECK ? row_end : count)) return;
     // element indices are LOCAL under coset sharding (this rank holds b_loc = b >> shard_log cosets); logN, b, c are global
     const uint32_t b_loc = b >> shard_log;
     const ShardMap sm{logb, shard_log, shard_rank};
@@ -287,14 +288,17 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t co
     if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
     size_t lds = (size_t)(1u << logb) * (CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY) * sizeof(fe);
     hipLaunchKernelGGL(cairo_composition_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), lds, st, lde, count, col_len, stride_log,
-                       logN, logb, roots_N, consts_dev, binv, out, (int*)nullptr, shard_log, shard_rank);
+                       logN, logb, roots_N, consts_dev, binv, out, (int*)nullptr, shard_log, shard_rank, (uint64_t)0, count);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
 
-int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev) {
-    hipLaunchKernelGGL(cairo_composition_kernel<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, trace, n, n, 0u, 0u, 0u,
-                       (const fe*)nullptr, consts_dev, (const fe*)nullptr, (fe*)nullptr, flag_dev, 0u, 0u);
+int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const CompositionConsts* consts_dev, int* flag_dev, uint64_t row0, uint64_t rows) {
+    if (rows == 0) rows = n - row0;
+    if (row0 + rows > n) return SP_E_INVALID_ARG;
+    // rows row0 .. row0 + rows - 1 (the frame's next row wraps modulo n as on the whole trace)
+    hipLaunchKernelGGL(cairo_composition_kernel<true>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, trace, n, n, 0u, 0u, 0u,
+                       (const fe*)nullptr, consts_dev, (const fe*)nullptr, (fe*)nullptr, flag_dev, 0u, 0u, row0, row0 + rows);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }

@@ -31,6 +31,11 @@ def _inputs(case):
     if kind == "fib":
         run = api.CairoRun.fibonacci(case["fib"])
         return run.main_trace(), run.public_inputs_c, run
+    if kind == "fib_flip":     # a valid trace with ONE cell changed: only the rank that checks that row sees the violation
+        run = api.CairoRun.fibonacci(case["fib"])
+        trace = run.main_trace().copy()
+        trace[case["row"], case["col"], 31] ^= 1
+        return trace, run.public_inputs_c, run
     import oracle_lib as oracle
     from test_gpu_random_traces import random_trace
     rng = random.Random(case["seed"])
@@ -112,6 +117,10 @@ CASES = [
     (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "async": True}),
     (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7, "async": True}),
     (4, RND(256, 15, rc=True), (8, 4, 3, 2), {"fri_min_log": 6, "async": True}),
+    # the exact trace check of round 2 is split by rows over the ranks (n >= 256 world): a violation in the last rank's slice only
+    (2, {"kind": "fib_flip", "fib": 100, "row": 700, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
+    (4, {"kind": "fib_flip", "fib": 100, "row": 3, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
+    (2, RND(1024, 16), (4, 3, 3, 1), {"fri_min_log": 6}),
 ]
 
 
@@ -129,7 +138,7 @@ def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_
         assert stats["world"] == world and stats["allgather_calls"] > 0
         # valid traces take the 2n-point composition (also with one coset per rank: cosets 0 and b/2 come from two ranks),
         # constraint-violating ones the whole domain with the general split
-        assert stats["composition_path"] == (1 if case["kind"] == "fib" else 3)
+        assert stats["composition_path"] == (1 if case["kind"] == "fib" else 3)     # (one flipped cell: deg H >= 2n, like a random trace)
         if knobs.get("alltoall", True) and world <= options[0]:
             assert stats["alltoall_calls"] >= 3          # main, aux and composition commitments at least
         if knobs.get("async"):
