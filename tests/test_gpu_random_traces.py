@@ -84,3 +84,40 @@ def test_valid_trace_still_verifies_after_the_sub_coset_path(hip_ctx, oracle):
     got = hip_ctx.cairo_prove(run.main_trace(), pub, api.ProofOptions(*options))
     assert got == oracle.cairo_prove(run.main_trace(), pub, options)
     assert oracle.cairo_verify(got, pub, options)
+
+
+def test_43_column_table_through_every_host_path(hip_ctx):
+    """A 2^16-row x 43-column (range-check-builtin layout) random table - 92 MB, above the threshold of the upload pipeline, an
+    odd number of columns (the last group of the row-major path is three columns wide, the last column pair of a row shares its
+    64-byte line with nothing) - gives the same bytes from the row-major host table, from host columns (ABI encoding, pageable)
+    and from device memory.  The small-trace tests above pin those bytes to the oracle; this one pins the big-trace paths to
+    each other."""
+    import ctypes
+    import oracle_lib as oracle
+    n, cols = 1 << 16, 43
+    rng = np.random.default_rng(43)
+    trace = rng.integers(0, 256, size=(n, cols, 32), dtype=np.uint8)
+    trace[:, :, 0] &= 0x07                                   # < 2^251 < p
+    trace[:, 19:23, :24] = 0                                 # memory addresses: 64-bit
+    trace[:, 27:30, :30] = 0                                 # instruction offsets: 16-bit
+    prng = random.Random(43)
+    pm = [(a, prng.randrange(P)) for a in range(1, 6)]
+    pub, keep = oracle.make_public_inputs(3, 5, 5, 7, 9, 5, 65000, pm, n - 7, [(0, 1000, 1010)])
+    opt = api.ProofOptions(4, 6, 3, 4)
+    rows = hip_ctx.cairo_prove(trace, pub, opt)
+    assert hip_ctx.last_upload_stats()["kind"].startswith("row-major")
+    assert hip_ctx.last_proof_info()["composition_path"] == 3          # a random trace: deg H >= 2n
+    cols_be = np.ascontiguousarray(trace.transpose(1, 0, 2))
+    assert hip_ctx.cairo_prove_columns(cols_be, n, cols, pub, opt) == rows
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    dev = ctypes.c_void_p()
+    assert hip.hipMalloc(ctypes.byref(dev), trace.nbytes) == 0
+    try:
+        assert hip.hipMemcpy(dev, trace.ctypes.data, trace.nbytes, 1) == 0
+        assert hip_ctx.cairo_prove_dev(dev.value, n, cols, pub, opt) == rows
+    finally:
+        hip.hipFree(dev)
+    assert not api.cairo_verify(rows, pub, opt)
