@@ -368,7 +368,7 @@ def project_ranks(api, fib, blowup, ranks, single_gpu_ms):
             ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
             times.append((time.perf_counter() - t0) * 1e3)
         after = ctx.comm_stats()
-        info, dev_bytes = ctx.last_proof_info(), ctx.prover_device_bytes()
+        info, dev_bytes, rounds = ctx.last_proof_info(), ctx.prover_device_bytes(), ctx.last_round_ms()
     finally:
         ctx.close()
     per = {k: (after[k] - before[k]) / 3 for k in ("allgather_calls", "allgather_bytes", "alltoall_calls", "alltoall_bytes", "received_bytes")}
@@ -377,7 +377,7 @@ def project_ranks(api, fib, blowup, ranks, single_gpu_ms):
     comm_ms = per["received_bytes"] / (ingest_gbs * 1e9) * 1e3 + (per["allgather_calls"] + per["alltoall_calls"]) * COLLECTIVE_LATENCY_MS
     compute_ms = min(times)
     return {"projection": True, "ranks": ranks, "groups": groups, "compute_ms": compute_ms, "comm_ms_model": comm_ms,
-            "collectives_per_proof": per, "assumed_ingest_gbs": ingest_gbs, "device_bytes_per_rank": dev_bytes,
+            "device_round_ms": rounds, "collectives_per_proof": per, "assumed_ingest_gbs": ingest_gbs, "device_bytes_per_rank": dev_bytes,
             "single_gpu_ms": single_gpu_ms, "speedup_ceiling": single_gpu_ms / (compute_ms + comm_ms) if single_gpu_ms else None,
             "speedup_if_comm_hidden": single_gpu_ms / compute_ms if single_gpu_ms else None,
             "note": "NOT a measurement of a multi-GPU run: rank 0's compute share timed on one GPU with a null transport (bytes not "

@@ -2,7 +2,7 @@
 #include "aux_kernels.h"
 #include "field_kernels.h"
 #include <cstring>
-#include <rocprim/device/device_radix_sort.hpp>
+#include "sort_kernels.h"
 
 namespace sp {
 
@@ -175,8 +175,8 @@ int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot) {
 }
 
 // ---- range-check part --------------------------------------------------------------------------------------
-// the 3n offsets as 16-bit keys in row-major (long) order; they are then sorted with a key-only radix sort
-// (a global-memory histogram would serialise: a Cairo trace uses only a handful of distinct offsets)
+// the 3n offsets as 16-bit keys in row-major (long) order; they are then sorted by counting (sort_kernels.hip: a Cairo trace uses
+// only a handful of distinct offsets, so a wave adds each class of equal keys to the histogram with one atomic)
 __global__ void __launch_bounds__(256) rc_keys_kernel(const fe* off_cols, uint64_t n, uint16_t* keys, int* flag) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= 3 * n) return;
@@ -220,13 +220,7 @@ __global__ void __launch_bounds__(256) aux_interleave_kernel(uint64_t n, const u
 static size_t align_up(size_t x) { return (x + 255) & ~size_t(255); }
 
 size_t aux_workspace_bytes(uint64_t n, uint64_t pm_cap, size_t* sort_tmp_bytes) {
-    size_t tmp = 0;
-    uint64_t* k = nullptr; uint32_t* v = nullptr;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp, k, k, v, v, (size_t)(4 * n), 0, 64, (hipStream_t)0);
-    size_t tmp16 = 0;
-    uint16_t* k16 = nullptr;
-    (void)rocprim::radix_sort_keys(nullptr, tmp16, k16, k16, (size_t)(3 * n), 0, 16, (hipStream_t)0);
-    if (tmp16 > tmp) tmp = tmp16;
+    const size_t tmp = radix_sort_workspace_bytes(4 * n);
     *sort_tmp_bytes = tmp;
     size_t b = 0;
     b += 7 * align_up(sizeof(fe) * 4 * n);          // a_aux v_aux num a_s v_s den inv_scratch
@@ -280,12 +274,10 @@ int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint6
     while ((1ULL << key_bits) < 8 * n && key_bits < 64) ++key_bits;
     hipLaunchKernelGGL(aux_keys_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag,
                        key_bits, wide_flag);
-    size_t tmp = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, key_bits, st));
+    SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, key_bits, w.sort_tmp));
     hipLaunchKernelGGL(aux_gather_pairs_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
     hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
-    size_t tmp2 = w.sort_tmp_bytes;
-    SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, st));
+    SP_TRY(counting_sort_u16(st, w.rc_keys, w.rc_sorted, M3, w.hist));
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }
@@ -312,8 +304,7 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
         // memory: substitute, sort (stable, by address), permutation column
         hipLaunchKernelGGL(aux_prepare_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, K, w.a_aux, w.v_aux, w.num,
                            w.keys_in, w.idx_in, flag);
-        size_t tmp = w.sort_tmp_bytes;
-        SP_HIP_CHECK(rocprim::radix_sort_pairs(w.sort_tmp, tmp, w.keys_in, w.keys_out, w.idx_in, w.idx_out, (size_t)M, 0, 64, st));
+        SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, 64, w.sort_tmp));
         hipLaunchKernelGGL(aux_gather_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, K, w.a_s, w.v_s, w.den);
     }
     SP_TRY(batch_inverse(st, w.den, w.inv_scratch, M, flag));
@@ -323,8 +314,7 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
     const fe* off_cols = mem_cols + 8 * n;
     if (!presorted) {
         hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_keys, flag);
-        size_t tmp2 = w.sort_tmp_bytes;
-        SP_HIP_CHECK(rocprim::radix_sort_keys(w.sort_tmp_rc, tmp2, w.rc_keys, w.rc_sorted, (size_t)M3, 0, 16, rs));
+        SP_TRY(counting_sort_u16(rs, w.rc_keys, w.rc_sorted, M3, w.hist));
     }
     hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, rs, w.rc_den, K);
     SP_TRY(batch_inverse(rs, w.rc_den, w.rc_den_scratch, 65536, flag));
