@@ -130,6 +130,7 @@ void TraceColumns::allocate(size_t rows, size_t cols) {
     data = static_cast<fe*>(p); n_rows = rows; n_cols = cols;
 }
 bool TraceColumns::try_pin() {
+    std::lock_guard<std::mutex> lk(pin_mutex);
     if (pinned || !data) return pinned;
     const size_t bytes = std::max<size_t>(n_rows * n_cols * sizeof(fe), 64);
     uint8_t* p = static_cast<uint8_t*>(alloc_pinned(bytes));

@@ -11,6 +11,7 @@
 #include <string>
 #include <unordered_map>
 #include <functional>
+#include <mutex>
 #include <algorithm>
 #include <vector>
 
@@ -52,6 +53,7 @@ struct TraceColumns {
     fe* data = nullptr;
     size_t n_rows = 0, n_cols = 0;
     bool pinned = false;
+    std::mutex pin_mutex;                      // try_pin() from two provers at once
     TraceColumns() = default;
     TraceColumns(const TraceColumns&) = delete;
     TraceColumns& operator=(const TraceColumns&) = delete;
