@@ -687,12 +687,11 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // decides, which grows with the width (two columns ~40 GB/s, four ~55, eight ~60): four columns.
     const double transform_ms_per_col = (1.0 + (double)(1u << logb_)) * (double)n_ * logn_ / 2 / 1.35e11 * 1e3;
     const double upload_ms_per_col = (double)n_ * 32 / 50e9 * 1e3;
-    static const uint32_t grow = [] { const char* e = std::getenv("SP_UPLOAD_GROW"); return e ? (uint32_t)std::max(1, std::atoi(e)) : 1u; }();
     static const uint32_t maxw_env = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 0u; }();
     const uint32_t maxw = maxw_env ? maxw_env : (transform_ms_per_col >= 0.9 * upload_ms_per_col ? 2u : 4u);
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
-        uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done / grow + 1) / 2)));
+        uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done + 1) / 2)));
         if (cols - done <= w + 1) w = cols - done;     // no one-column tail
         gsize.push_back(w);
         done += w;

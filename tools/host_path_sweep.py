@@ -14,8 +14,7 @@ ctx = api.Context()
 run = api.CairoRun.fibonacci(fib); tr = run.main_trace()
 opt = api.ProofOptions(b, 80, 3, 20)
 dev = torch.from_numpy(tr).cuda(); torch.cuda.synchronize()
-print(f"SP_UPLOAD_GROW={os.environ.get('SP_UPLOAD_GROW', 'default')} SP_UPLOAD_MAXW={os.environ.get('SP_UPLOAD_MAXW', 'default')} "
-      f"SP_GATHER_PREFETCH={os.environ.get('SP_GATHER_PREFETCH', '0')}")
+print(f"SP_UPLOAD_MAXW={os.environ.get('SP_UPLOAD_MAXW', 'default')} SP_UPLOAD_FREE_RUNNING={os.environ.get('SP_UPLOAD_FREE_RUNNING', '-')}")
 for threads in counts:
     ctx.set_option(api.SP_OPT_UPLOAD_THREADS, threads)
     for _ in range(3):
