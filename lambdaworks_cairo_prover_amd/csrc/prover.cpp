@@ -1,6 +1,6 @@
 // Round-by-round STARK prover on the device (see prover.h). Host code only: it sequences kernels on the context
 // stream, keeps every polynomial / evaluation / tree resident in HBM and moves only roots, challenges and openings.
-#include "prover.h"
+#include "prover_internal.h"
 #include "cairo_host.h"
 #include <array>
 #include "keccak.h"
@@ -9,25 +9,10 @@
 #include <cstring>
 #include <cmath>
 #include <stdexcept>
-#include <chrono>
-#include <cstdio>
-#include <cstdlib>
-#include <thread>
-#include <mutex>
-#include <condition_variable>
 #include <functional>
 #include <memory>
-#include <atomic>
 
 namespace sp {
-
-static double wall_ms() {
-    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-static bool timing_enabled() { static int v = -1; if (v < 0) v = std::getenv("SP_TIMING") ? 1 : 0; return v == 1; }
-#define SP_TIMEPOINT(label)                                                                 \
-    do { if (timing_enabled()) { (void)hipStreamSynchronize(ctx->stream); double _t = wall_ms(); \
-         std::fprintf(stderr, "[sp_timing] %-28s %9.2f ms\n", label, _t - _tp); _tp = _t; } } while (0)
 
 void host_pool_delete(HostPool* p);
 
@@ -461,327 +446,6 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     if (segment == 0) SP_TRY(launch_aux_presort());
     return commit_segment_resident(segment, cols, root_out);
-}
-
-int StarkProver::ensure_upload(uint32_t groups) {
-    if (groups > (uint32_t)UPLOAD_MAX_GROUPS) { sp_set_error("commit_trace: too many column groups"); return SP_E_UNSUPPORTED; }
-    if (!copy_stream_) {
-        // highest priority: the little kernels of the upload (rows -> columns, decode, the pull copy) must not queue behind the
-        // thousands of work-groups of the transforms they feed (a kernel after every copy on an ordinary stream: 24 GB/s
-        // instead of 56, tools/experiments/dma_pattern_probe.hip)
-        int prio_lo = 0, prio_hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        SP_HIP_CHECK(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, prio_hi));
-        SP_HIP_CHECK(hipStreamCreateWithPriority(&r2c_stream_, hipStreamNonBlocking, prio_hi));
-        for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
-    }
-    if (!up_start_) SP_HIP_CHECK(hipEventCreate(&up_start_));
-    for (uint32_t g = 0; g < groups; ++g)
-        for (hipEvent_t* e : {&up_ev_[g].dma0, &up_ev_[g].dma1, &up_ev_[g].ready, &up_ev_[g].done})
-            if (!*e) SP_HIP_CHECK(hipEventCreate(e));
-    SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
-    if (r2c_stream_) SP_HIP_CHECK(hipStreamSynchronize(r2c_stream_));
-    return SP_OK;
-}
-
-// After the commitment's read-back (every event has completed): what the upload cost and how long the compute stream waited
-// for it.  kind 1: gathered from a row-major host buffer, 2: DMA of host columns.
-int StarkProver::finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind) {
-    double dma_ms = 0, exposed = 0, worst = 0;
-    for (uint32_t g = 0; g < groups; ++g) {
-        float d = 0, w = 0;
-        if (hipEventElapsedTime(&d, up_ev_[g].dma0, up_ev_[g].dma1) == hipSuccess) dma_ms += d;
-        // the compute stream could have started group g when it was done with group g - 1 (or, for the first one, at the start)
-        if (hipEventElapsedTime(&w, g ? up_ev_[g - 1].done : up_start_, up_ev_[g].ready) == hipSuccess && w > 0) { exposed += w; worst = std::max<double>(worst, w); }
-    }
-    (void)hipGetLastError();
-    double* u = c_->upload_stats;
-    u[0] = kind; u[1] = groups; u[2] = (double)bytes; u[3] = gather_ms; u[4] = gather_ms > 0 ? bytes / gather_ms * 1e-6 : 0;
-    u[5] = dma_ms; u[6] = dma_ms > 0 ? bytes / dma_ms * 1e-6 : 0; u[7] = exposed; u[8] = worst; u[9] = host_ms;
-    return SP_OK;
-}
-
-// interpolate_and_commit (reference prover.rs:126-159) from host COLUMNS (the layout trace.rs:23-31 `cols()` produces, and what
-// sp_cairo_run keeps): a column group is one contiguous DMA straight into the trace area - no gather, no landing slot - and the
-// groups stay small (1, 1, 2, 2, ...) so that only the first column's 0.6 ms stay in front of the transforms.
-int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]) {
-    const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    std::vector<uint32_t> gsize;
-    for (uint32_t done = 0; done < cols;) {
-        // one, one, then two columns at a time: a group is ready when its DMA is (0.6 ms per column of 2^20 rows) and its
-        // transforms take 0.7 ms per column, so with small groups the compute stream waits for the first column only; doubling
-        // groups (1, 1, 2, 4, 8, 8, ...) made it wait 4 ms per proof - every group twice the size of the one being transformed
-        uint32_t w = done < 2 ? 1u : 2u;
-        if (G_ > 1 && d_cstage_) w = cols;            // column-sharded interpolation works on the whole segment
-        w = std::min(w, cols - done);
-        gsize.push_back(w);
-        done += w;
-    }
-    const uint32_t groups = (uint32_t)gsize.size();
-    SP_TRY(ensure_upload(groups));
-    // page-locked source (sp_host_alloc, a run built after the context): DMA at PCIe speed; pageable: the runtime's staging copy.
-    // SP_UPLOAD_PULL=1 replaces the DMA of a page-locked source by a copy kernel that reads it over PCIe (experiment).
-    hipPointerAttribute_t attr{};
-    const bool pinned = hipPointerGetAttributes(&attr, cols_host) == hipSuccess && attr.type == hipMemoryTypeHost;
-    (void)hipGetLastError();
-    static const bool want_pull = std::getenv("SP_UPLOAD_PULL") != nullptr;
-    const bool pull = pinned && want_pull && (reinterpret_cast<uintptr_t>(cols_host) % 16 == 0);
-    const double t0 = wall_ms();
-    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
-    fe* trace = d_trace_ + (uint64_t)col0 * n_;
-    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the trace area's previous readers are behind this point
-    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
-    const bool sharded_interp = G_ > 1 && d_cstage_ && cols >= G_;
-    uint32_t c0 = 0;
-    for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
-        const uint32_t w = gsize[g];
-        fe* dst = trace + (uint64_t)c0 * n_;
-        // One copy in flight at a time: the runtime picks the SDMA engine of a copy when it is ENQUEUED, and with the first engine
-        // still busy it takes another one - copies of one stream hopping between engines ran at 27 - 37 GB/s instead of 56 for whole
-        // proofs (profiles/r03_pinned_upload.txt: config #4 38 ms instead of 27).  The host has nothing else to do here.
-        static const bool free_running = std::getenv("SP_UPLOAD_FREE_RUNNING") != nullptr;
-        if (g >= 1 && !free_running) SP_HIP_CHECK(hipEventSynchronize(up_ev_[g - 1].dma1));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
-        auto h2d = [&](void* to, const uint8_t* from, size_t bytes) -> int {
-            if (pull) return pull_copy(copy_stream_, from, to, bytes);
-            SP_HIP_CHECK(hipMemcpyAsync(to, from, bytes, hipMemcpyHostToDevice, copy_stream_));
-            return SP_OK;
-        };
-        if (col_stride == n_) {
-            SP_TRY(h2d(dst, cols_host + (size_t)c0 * n_ * 32, (size_t)w * n_ * 32));
-        } else {
-            for (uint32_t j = 0; j < w; ++j) SP_TRY(h2d(dst + (uint64_t)j * n_, cols_host + (size_t)(c0 + j) * col_stride * 32, (size_t)n_ * 32));
-        }
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        if (col_enc >= 0) SP_TRY(decode_elements(copy_stream_, col_enc, reinterpret_cast<const uint8_t*>(dst), (uint64_t)w * n_, dst));   // element-wise, in place
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
-        if (!sharded_interp) {
-            // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
-            SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, dst));
-            SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, (int)logG_, (int)rank_));
-        }
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
-    }
-    const double host_ms = wall_ms() - t0;
-    if (segment == 0) SP_TRY(launch_aux_presort());   // every column is behind this point of the compute stream
-    int rc;
-    if (sharded_interp) rc = commit_segment_resident(segment, cols, root_out);
-    else {
-        rc = commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out);
-        if (rc == SP_OK) stage_ = segment == 0 ? 2 : 3;
-    }
-    if (rc == SP_OK) {
-        SP_TRY(finish_upload_stats(groups, (uint64_t)cols * n_ * 32, 0.0, host_ms, pinned ? 2 : 3));
-    }
-    return rc;
-}
-
-// A few parked host threads for the column gathers of the upload pipeline (creating them per group would put ~5 ms of
-// pthread_create on the critical path of a proof).
-class HostPool {
-  public:
-    explicit HostPool(unsigned workers) {
-        for (unsigned w = 0; w < workers; ++w) threads_.emplace_back([this, w] { loop(w); });
-    }
-    ~HostPool() {
-        { std::lock_guard<std::mutex> lk(m_); stop_ = true; gen_.fetch_add(1); }
-        cv_.notify_all();
-        for (auto& t : threads_) t.join();
-    }
-    unsigned size() const { return (unsigned)threads_.size() + 1; }
-    // Between begin_burst() and end_burst() idle workers spin on the generation counter instead of sleeping on the condition
-    // variable: the groups of one upload follow each other within a millisecond and a futex wake-up of 30-60 threads costs
-    // 50-100 us each time.
-    void begin_burst() { { std::lock_guard<std::mutex> lk(m_); burst_.store(true, std::memory_order_release); } cv_.notify_all(); }
-    void end_burst() { burst_.store(false, std::memory_order_release); }
-    // runs job(part, parts) for part = 0 .. parts-1 (parts = workers + 1; the caller takes part 0) and waits for all of them
-    void run(const std::function<void(unsigned, unsigned)>& job) {
-        {
-            std::lock_guard<std::mutex> lk(m_);
-            job_ = &job; pending_.store((unsigned)threads_.size(), std::memory_order_relaxed);
-            gen_.fetch_add(1, std::memory_order_release);
-        }
-        cv_.notify_all();
-        job(0, size());
-        // the parts are equal: the others finish within microseconds of the caller
-        for (int spin = 0; pending_.load(std::memory_order_acquire) != 0; ++spin) {
-            if (spin < 20000) { sp_cpu_relax(); continue; }
-            std::unique_lock<std::mutex> lk(m_);
-            done_.wait(lk, [this] { return pending_.load(std::memory_order_acquire) == 0; });
-        }
-        job_ = nullptr;
-    }
-  private:
-    static void sp_cpu_relax() { __builtin_ia32_pause(); }
-    void loop(unsigned w) {
-        uint64_t seen = 0;
-        for (;;) {
-            const std::function<void(unsigned, unsigned)>* job;
-            // (bounded: a worker that finds nothing for ~0.3 ms goes back to sleep, so a stalled upload does not burn the cores)
-            for (int spin = 0; spin < 100000 && burst_.load(std::memory_order_acquire) && gen_.load(std::memory_order_acquire) == seen; ++spin) sp_cpu_relax();
-            {
-                std::unique_lock<std::mutex> lk(m_);
-                if (gen_.load(std::memory_order_acquire) == seen) {
-                    const bool was_burst = burst_.load(std::memory_order_acquire);
-                    cv_.wait(lk, [&] { return gen_.load(std::memory_order_acquire) != seen || (!was_burst && burst_.load(std::memory_order_acquire)); });
-                    if (gen_.load(std::memory_order_acquire) == seen) continue;   // woken into a burst: go spinning
-                }
-                seen = gen_.load(std::memory_order_acquire);
-                if (stop_) return;
-                job = job_;
-            }
-            (*job)(w + 1, size());
-            if (pending_.fetch_sub(1, std::memory_order_acq_rel) == 1) { std::lock_guard<std::mutex> lk(m_); done_.notify_one(); }
-        }
-    }
-    std::vector<std::thread> threads_;
-    std::mutex m_;
-    std::condition_variable cv_, done_;
-    const std::function<void(unsigned, unsigned)>* job_ = nullptr;
-    std::atomic<unsigned> pending_{0};
-    std::atomic<uint64_t> gen_{0};
-    std::atomic<bool> burst_{false};
-    bool stop_ = false;
-};
-void host_pool_delete(HostPool* p) { delete p; }
-
-// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace.  The rows are handed
-// out in blocks through a shared counter, so a thread that is slow (a busy core, a remote NUMA node, a throttled container)
-// takes fewer blocks instead of holding the whole group back.
-static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
-    const uint64_t block = std::max<uint64_t>(256, (256u << 10) / width);   // ~256 KB written per block
-    std::atomic<uint64_t> next{0};
-    pool.run([&](unsigned, unsigned) {
-        for (;;) {
-            const uint64_t r0 = next.fetch_add(block, std::memory_order_relaxed);
-            if (r0 >= n) return;
-            const uint64_t r1 = std::min<uint64_t>(n, r0 + block);
-            const uint8_t* s = src + r0 * row_bytes + off;
-            uint8_t* d = dst + r0 * width;
-            // fixed-size 32-byte copies inline as vector moves (a libc memcpy call per row costs more than the bytes it moves on
-            // narrow groups)
-            const size_t units = width / 32;
-            for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width)
-                for (size_t u = 0; u < units; ++u) __builtin_memcpy(d + 32 * u, s + 32 * u, 32);
-        }
-    });
-}
-
-// interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
-// in column groups: while group g is interpolated and extended on the compute stream, the chunks of the groups behind it are
-// gathered out of the table into a small ring of page-locked slots by a few host threads and cross PCIe on a second stream.
-// A chunk is a block of rows of one group, 32 MB at most: the DMA of one chunk runs beside the gather of the next whatever the
-// size of the group, and the ring (4 x 32 MB) takes a sixth of the time to pin that three group-sized slots did (56 ms of a
-// first proof at 2^20 rows).
-int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
-    const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything
-    // behind it still has to be transformed (~0.7 ms per column; 0.2 ms at blowup 4, where the upload is the bound): two single
-    // columns start the pipeline, then groups of two or four columns, always from an even column on (two columns share a 64-byte
-    // line of a row).
-    // How wide may a group get?  A group is usable when all of it has landed, so with the transforms as the bound (blowup 8: 0.70
-    // ms per column against 0.65 ms of upload) narrow groups keep the compute stream fed - two columns: 75.0 ms where eight-column
-    // groups gave 80 - and with the upload as the bound (blowup 4: 0.18 ms of transforms per column) the gather's throughput
-    // decides, which grows with the width (two columns ~40 GB/s, four ~55, eight ~60): four columns.
-    const double transform_ms_per_col = (1.0 + (double)(1u << logb_)) * (double)n_ * logn_ / 2 / 1.35e11 * 1e3;
-    const double upload_ms_per_col = (double)n_ * 32 / 50e9 * 1e3;
-    static const uint32_t maxw_env = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 0u; }();
-    const uint32_t maxw = maxw_env ? maxw_env : (transform_ms_per_col >= 0.9 * upload_ms_per_col ? 2u : 4u);
-    std::vector<uint32_t> gsize;
-    for (uint32_t done = 0; done < cols;) {
-        uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done + 1) / 2)));
-        if (cols - done <= w + 1) w = cols - done;     // no one-column tail
-        gsize.push_back(w);
-        done += w;
-    }
-    const uint32_t groups = (uint32_t)gsize.size();
-    // chunk size: 32 MB, less when the scratch area (the landing ring on the device) is small
-    size_t chunk = std::min<size_t>((size_t)32 << 20, (scratch_elems() * sizeof(fe) / UPLOAD_SLOTS) & ~(size_t)4095);
-    if (chunk < (size_t)64 * 256) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
-    double _tp = wall_ms();
-    sp_ctx* ctx = c_;
-    // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
-    // 100 ms period and the upload is a burst of a quarter of a proof, so twice the quota's CPUs for that long stays inside it
-    // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
-    // proofs of a 64-thread gather in a 16-CPU container.
-    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
-    SP_TRY(ensure_upload(groups));
-    if (stage_bytes_ < chunk) {
-        for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
-        stage_bytes_ = 0;
-        for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
-        stage_bytes_ = chunk;
-    }
-    uint8_t* landing[UPLOAD_SLOTS];
-    for (int i = 0; i < UPLOAD_SLOTS; ++i) landing[i] = reinterpret_cast<uint8_t*>(d_scratch_) + (size_t)i * chunk;
-    fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
-    fe* trace = d_trace_ + (uint64_t)col0 * n_;
-    fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    SP_TIMEPOINT("  upload: threads, streams, pinned slots");
-    const double t0 = wall_ms();
-    double gather_ms = 0;
-    struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
-    pool_->begin_burst();
-    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
-    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
-    SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, up_start_, 0));
-    uint64_t chunk_no = 0;
-    uint32_t c0 = 0;
-    for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
-        const uint32_t w = gsize[g];
-        const double tg = wall_ms();
-        double waited = 0;
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
-        {   // the group in blocks of rows: whole rows of the group (w x 32 contiguous bytes each: the wider, the better the gather
-            // streams - 2 columns move ~40 GB/s, 8 columns ~58) and at most one ring slot of them at a time
-            const uint32_t cw = w, c = c0;
-            const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk / ((size_t)cw * 32)) & ~(uint64_t)255);
-            for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk, ++chunk_no) {
-                const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
-                const uint32_t slot = (uint32_t)(chunk_no % UPLOAD_SLOTS);
-                const double tw = wall_ms();
-                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));   // the pinned slot has crossed PCIe
-                waited += wall_ms() - tw;
-                host_gather_columns(*pool_, rows_host + r0 * (size_t)cols * 32, rows, (size_t)cols * 32, (size_t)c * 32, (size_t)cw * 32,
-                                    static_cast<uint8_t*>(h_stage_[slot]));
-                // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the chunk has been
-                // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the
-                // upload stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
-                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been turned into columns
-                // (no "one copy in flight" wait here, unlike commit_trace_columns: a chunk's DMA is enqueued after a gather that took
-                // about as long as the previous DMA, so the engine is mostly idle by then, and blocking this thread delays the next
-                // gather - 38.5 against 35 ms at config #4 on a slow host)
-                SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)rows * cw * 32, hipMemcpyHostToDevice, copy_stream_));
-                SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
-                // rows -> columns on a stream of its own: on the copy stream the DMA engine sat idle through every one of these
-                // kernels (~50 us x 34 chunks per proof); on the compute stream they queued behind the previous group's LDE
-                SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, ev_dma_[slot], 0));
-                SP_TRY(rows_to_columns(r2c_stream_, c_->enc, landing[slot], rows, cw, trace + (uint64_t)c * n_ + r0, n_));
-                SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], r2c_stream_));
-            }
-        }
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, r2c_stream_));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
-        const double tge = wall_ms();
-        gather_ms += tge - tg - waited;
-        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   group %2u: %u columns, waited %.3f ms for slots, gather + enqueue %.3f ms (%.1f GB/s)\n", g, w, waited,
-                                           tge - tg - waited, (double)n_ * w * 32 / (tge - tg - waited) * 1e-6);
-        // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
-        SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
-    }
-    const double host_ms = wall_ms() - t0;
-    SP_TIMEPOINT("  upload + transforms of the groups");
-    if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
-    SP_TIMEPOINT("  aux presort queued (+ its workspace)");
-    SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
-    SP_TIMEPOINT("  leaf hashing + tree");
-    stage_ = segment == 0 ? 2 : 3;
-    return finish_upload_stats(groups, (uint64_t)cols * n_ * 32, gather_ms, host_ms, 1);
 }
 
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.
@@ -1796,366 +1460,6 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
         path_off += depth;
     }
     return SP_OK;
-}
-
-// ============================================================================================ whole proof (host driver)
-namespace {
-
-// DefaultTranscript of lambdaworks-crypto @ a17b951 and the sampling rules of
-// reference src/starks/transcript.rs:13-79.
-struct HostTranscript {
-    std::vector<uint8_t> buf;
-    void append(const uint8_t* d, size_t n) { buf.insert(buf.end(), d, d + n); }
-    void append_felt(const fe& x) { uint8_t b[32]; fe_to_bytes_be(x, b); append(b, 32); }
-    void challenge(uint8_t out[32]) {
-        uint8_t d[32];
-        sp_keccak256_host(buf.data(), buf.size(), d);
-        for (int i = 0; i < 32; ++i) out[i] = d[31 - i];
-        buf.assign(out, out + 32);
-    }
-    fe to_field() {
-        uint8_t r[32];
-        challenge(r);
-        r[0] &= 0x07;  // 251 random bits (transcript.rs:24-43)
-        return fe_from_bytes_be(r);
-    }
-    uint64_t to_usize() {
-        uint8_t r[32];
-        challenge(r);
-        uint64_t v = 0;
-        for (int i = 0; i < 8; ++i) v = (v << 8) | r[i];
-        return v;
-    }
-};
-
-struct ProofWriter {
-    std::vector<uint8_t> b;
-    void u64(uint64_t v) { for (int i = 7; i >= 0; --i) b.push_back((uint8_t)(v >> (8 * i))); }
-    void felt(const fe& x) { uint8_t t[32]; fe_to_bytes_be(x, t); b.insert(b.end(), t, t + 32); }
-    void digest(const digest32& d) { const uint8_t* p = reinterpret_cast<const uint8_t*>(d.w); b.insert(b.end(), p, p + 32); }
-    void raw(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
-    void path(const digest32* p, uint32_t depth) { u64(depth); for (uint32_t i = 0; i < depth; ++i) digest(p[i]); }
-    void bytes(const std::vector<uint8_t>& v) { b.insert(b.end(), v.begin(), v.end()); }
-};
-
-bool z_in_domains(const fe& z, const fe& hinv, uint32_t logn, uint32_t logN) {  // transcript.rs:53-69
-    fe a = fe_mul(z, hinv), b = z;
-    for (uint32_t i = 0; i < logN; ++i) a = fe_sqr(a);
-    for (uint32_t i = 0; i < logn; ++i) b = fe_sqr(b);
-    return fe_eq(a, fe_one()) || fe_eq(b, fe_one());
-}
-
-}  // namespace
-
-// StarkProof serialization (reference proof/stark.rs:161-218, fri/fri_decommit.rs:24-45, frame.rs:86-106).
-// roots: the trace-segment roots (one or two); ood: frame rows x C evaluations.
-static void serialize_proof(uint64_t n, const std::vector<std::array<uint8_t, 32>>& roots, uint32_t C, const std::vector<fe>& ood,
-                            const uint8_t comp_root[32], const fe& h1z, const fe& h2z, const std::vector<std::vector<uint8_t>>& fri_roots,
-                            const fe& last_value, const std::vector<uint64_t>& iotas, const Openings& o, uint64_t nonce,
-                            std::vector<uint8_t>& proof_out) {
-    const uint32_t L = o.n_layers, d0 = o.depth0;
-    ProofWriter w;
-    w.u64(n);
-    w.u64(roots.size());
-    for (auto& r : roots) w.raw(r.data(), 32);
-    {
-        ProofWriter f;
-        f.u64(ood.size()); f.u64(32);
-        for (auto& e : ood) f.felt(e);
-        f.u64(C);
-        w.u64(f.b.size()); w.bytes(f.b);
-    }
-    w.raw(comp_root, 32);
-    w.u64(32); w.felt(h1z); w.felt(h2z);
-    w.u64(fri_roots.size());
-    for (auto& r : fri_roots) w.raw(r.data(), 32);
-    w.felt(last_value);
-    size_t path_total = 0;
-    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
-    w.u64(iotas.size());
-    for (size_t s = 0; s < iotas.size(); ++s) {
-        ProofWriter qw;
-        qw.u64(L);
-        size_t po = 0;
-        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
-        qw.u64(32);
-        qw.u64(L);
-        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals_sym[s * L + k]);
-        qw.u64(L);
-        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals[s * L + k]);
-        qw.u64(L);
-        po = 0;
-        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
-        w.u64(qw.b.size()); w.bytes(qw.b);
-    }
-    w.u64(iotas.size());
-    for (size_t s = 0; s < iotas.size(); ++s) {
-        ProofWriter ow;
-        ow.path(&o.comp_paths[s * d0], d0);
-        ow.u64(32);
-        ow.felt(o.comp_evals[s * 2]); ow.felt(o.comp_evals[s * 2 + 1]);
-        ow.u64(roots.size());
-        ow.path(&o.main_paths[s * d0], d0);
-        if (roots.size() > 1) ow.path(&o.aux_paths[s * d0], d0);
-        ow.u64(C);
-        for (uint32_t j = 0; j < C; ++j) ow.felt(o.trace_evals[s * C + j]);
-        w.u64(ow.b.size()); w.bytes(ow.b);
-    }
-    w.u64(nonce);
-    proof_out.swap(w.b);
-}
-
-ProverHolder* prover_holder(sp_ctx* c, bool create) {
-    ProverHolder* h = dynamic_cast<ProverHolder*>(c->prover_state_deleter_holder);
-    if (!h && create) {
-        delete c->prover_state_deleter_holder;
-        h = new ProverHolder(c);
-        c->prover_state_deleter_holder = h;
-    }
-    return h;
-}
-
-int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t cols, const PublicInputs& pub,
-                const ProofOptionsHost& opt, std::vector<uint8_t>& proof_out, float round_ms[5],
-                StarkProver::TraceSource src, int col_enc, uint64_t col_stride) {
-    try {
-        CairoAirInfo air = cairo_air_info(pub);
-        if (cols != air.main_columns) { sp_set_error("cairo_prove: main trace must have 34 columns (43 with the range-check builtin)"); return SP_E_INVALID_ARG; }
-        StarkProver* P = &prover_holder(ctx, true)->prover;   // kept (with its device buffers) across proofs of the same shape on this context
-        struct Events {   // released on every exit path
-            hipEvent_t e[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-            ~Events() { for (auto& x : e) if (x) (void)hipEventDestroy(x); }
-        } evs;
-        hipEvent_t* ev = evs.e;
-        for (auto& e : evs.e) SP_HIP_CHECK(hipEventCreate(&e));
-        double _tp = wall_ms();
-        SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
-        SP_TIMEPOINT("setup (alloc + tables)");
-        HostTranscript tr;
-        uint8_t root[32];
-        // ---- round 1 (reference prover.rs:187-224)
-        SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
-        P->request_aux_presort(pub);                    // the sorts of the auxiliary trace: beside round 1 too
-        if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
-            SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
-        SP_TRY(P->commit_trace(0, main_trace, cols, root, src, col_enc, col_stride));
-        uint8_t main_root[32]; std::memcpy(main_root, root, 32);
-        SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");
-        tr.append(root, 32);
-        fe rap[3] = {tr.to_field(), tr.to_field(), tr.to_field()};
-        SP_TRY(P->commit_aux_cairo(pub, rap, root));
-        SP_TIMEPOINT("r1 aux trace + commit (device)");
-        uint8_t aux_root[32]; std::memcpy(aux_root, root, 32);
-        tr.append(root, 32);
-        SP_HIP_CHECK(hipEventRecord(ev[1], ctx->stream));
-        // ---- round 2 (reference prover.rs:597-635)
-        std::vector<BoundaryConstraint> bcs = boundary_constraints(pub, rap, n, air.has_rc_builtin);
-        const uint32_t T = air.num_transition_constraints;
-        SP_TRY(P->composition_precheck(rap, bcs, T));   // runs while the challenges below are sampled
-        std::vector<fe> b_alpha(bcs.size()), b_beta(bcs.size()), t_alpha(T), t_beta(T);
-        for (auto& x : b_alpha) x = tr.to_field();
-        for (auto& x : b_beta) x = tr.to_field();
-        for (auto& x : t_alpha) x = tr.to_field();
-        for (auto& x : t_beta) x = tr.to_field();
-        SP_TRY(P->composition(rap, bcs, b_alpha, b_beta, t_alpha, t_beta, air.transition_degrees, air.transition_exemptions, root));
-        uint8_t comp_root[32]; std::memcpy(comp_root, root, 32);
-        SP_TIMEPOINT("r2 composition");
-        tr.append(root, 32);
-        SP_HIP_CHECK(hipEventRecord(ev[2], ctx->stream));
-        // ---- round 3 (reference prover.rs:652-684)
-        const uint32_t logn = (uint32_t)sp_log2_exact(n), logN = logn + (uint32_t)sp_log2_exact(opt.blowup_factor);
-        fe hinv = fe_inv(fe_from_u64(opt.coset_offset));
-        fe z;
-        do { z = tr.to_field(); } while (z_in_domains(z, hinv, logn, logN));
-        fe h1z, h2z;
-        std::vector<fe> ood;
-        SP_TRY(P->ood(z, &h1z, &h2z, ood));
-        SP_TIMEPOINT("r3 ood");
-        tr.append_felt(h1z); tr.append_felt(h2z);
-        for (auto& e : ood) tr.append_felt(e);
-        SP_HIP_CHECK(hipEventRecord(ev[3], ctx->stream));
-        // ---- round 4 (reference prover.rs:327-404)
-        fe gamma = tr.to_field(), gamma_p = tr.to_field();
-        std::vector<fe> tg(2 * (size_t)P->cols());
-        for (auto& x : tg) x = tr.to_field();
-        SP_TRY(P->deep_fri_begin(gamma, gamma_p, tg, root));
-        std::vector<std::vector<uint8_t>> fri_roots;
-        fri_roots.emplace_back(root, root + 32);
-        tr.append(root, 32);
-        fe last_value;
-        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
-            const fe zeta0 = tr.to_field();
-            std::vector<std::array<uint8_t, 32>> rest;
-            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
-            for (auto& r : rest) {
-                fri_roots.emplace_back(r.begin(), r.end());
-                tr.append(r.data(), 32);
-                (void)tr.to_field();      // zeta_k: the device sampled the same value
-            }
-        } else
-        for (;;) {
-            fe zeta = tr.to_field();
-            int is_last = 0;
-            SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
-            if (is_last) break;
-            fri_roots.emplace_back(root, root + 32);
-            tr.append(root, 32);
-        }
-        SP_TIMEPOINT("r4 deep + fri commit");
-        tr.append_felt(last_value);
-        uint8_t gch[32];
-        tr.challenge(gch);
-        uint64_t nonce = 0;
-        SP_TRY(P->grind(gch, opt.grinding_factor, &nonce));
-        {
-            uint8_t nb[8];
-            for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
-            tr.append(nb, 8);
-        }
-        SP_TIMEPOINT("r4 grinding");
-        std::vector<uint64_t> iotas(opt.fri_number_of_queries);
-        for (auto& x : iotas) x = tr.to_usize() % P->N();
-        Openings o;
-        SP_TRY(P->open(iotas, o));
-        SP_TIMEPOINT("r4 openings");
-        SP_HIP_CHECK(hipEventRecord(ev[4], ctx->stream));
-        SP_HIP_CHECK(hipEventSynchronize(ev[4]));
-        if (round_ms) {
-            round_ms[0] = 0.f;
-            for (int r = 0; r < 4; ++r) SP_HIP_CHECK(hipEventElapsedTime(&round_ms[r + 1], ev[r], ev[r + 1]));
-        }
-        std::vector<std::array<uint8_t, 32>> roots(2);
-        std::memcpy(roots[0].data(), main_root, 32); std::memcpy(roots[1].data(), aux_root, 32);
-        serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
-        return SP_OK;
-    } catch (const std::exception& e) {
-        sp_set_error(std::string("cairo_prove: ") + e.what());
-        return SP_E_INVALID_ARG;
-    }
-}
-
-// prove::<F, A> for a program AIR (reference src/starks/prover.rs:532-766): same rounds, the AIR-specific parts come from
-// the descriptor - RAP challenges (n_rap field samples), auxiliary trace (by kind, built on the host: the example AIRs are
-// tiny), boundary constraints, transition program.
-int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, uint64_t n, const ProofOptionsHost& opt,
-              std::vector<uint8_t>& proof_out) {
-    try {
-        if (air.main_cols == 0 || air.main_cols + air.aux_cols > 64) { sp_set_error("air_prove: column count out of range"); return SP_E_INVALID_ARG; }
-        StarkProver* P = &prover_holder(ctx, true)->prover;   // kept (with its device buffers) across proofs of the same shape on this context
-        SP_TRY(P->setup(n, air.main_cols, air.aux_cols, false, opt));
-        HostTranscript tr;
-        uint8_t root[32];
-        std::vector<std::array<uint8_t, 32>> roots;
-        // ---- round 1 (reference prover.rs:187-224)
-        SP_TRY(P->commit_trace(0, main_trace, air.main_cols, root));
-        roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
-        tr.append(root, 32);
-        std::vector<fe> rap(air.n_rap);
-        for (auto& x : rap) x = tr.to_field();
-        if (air.aux_cols && air.aux_kind == 2) {
-            // build_auxiliary_trace of the caller's AIR (traits.rs:25-29): row-major n x aux_cols from the RAP challenges
-            if (!air.aux_fn) { sp_set_error("air_prove: aux_kind 2 needs aux_fn"); return SP_E_INVALID_ARG; }
-            std::vector<uint8_t> rap_bytes(std::max<size_t>(1, rap.size()) * 32), aux_rows((size_t)n * air.aux_cols * 32);
-            if (!rap.empty()) SP_TRY(sp_fe_from_device(ctx->enc, reinterpret_cast<const uint8_t*>(rap.data()), rap.size(), rap_bytes.data()));
-            if (air.aux_fn(air.aux_user, rap_bytes.data(), (uint32_t)rap.size(), aux_rows.data()) != 0) { sp_set_error("air_prove: the auxiliary-trace callback failed"); return SP_E_INVALID_ARG; }
-            SP_TRY(P->commit_trace(1, aux_rows.data(), air.aux_cols, root));
-            roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
-            tr.append(root, 32);
-        } else if (air.aux_cols) {
-            if (air.aux_kind != 1 || air.aux_cols != 1 || air.main_cols < 2 || air.n_rap < 1) {
-                sp_set_error("air_prove: unknown auxiliary-trace kind (1 = fibonacci_rap permutation column, 2 = caller-supplied)");
-                return SP_E_UNSUPPORTED;
-            }
-            // fibonacci_rap.rs:69-93: z_0 = 1, z_i = z_(i-1) (a_(i-1) + gamma) / (b_(i-1) + gamma)
-            std::vector<fe> den(n), num(n);
-            for (uint64_t i = 0; i < n; ++i) {
-                fe a, b;
-                const uint8_t* row = main_trace + (size_t)i * air.main_cols * 32;
-                if (ctx->enc == SP_FE_CANON_BE) { a = fe_from_bytes_be(row); b = fe_from_bytes_be(row + 32); }
-                else { uint64_t l[4]; std::memcpy(l, row, 32); a = fe_from_lw_limbs(l); std::memcpy(l, row + 32, 32); b = fe_from_lw_limbs(l); }
-                num[i] = fe_add(a, rap[0]); den[i] = fe_add(b, rap[0]);
-            }
-            for (auto& d : den) if (fe_is_zero(d)) { sp_set_error("air_prove: zero denominator in the permutation column"); return SP_E_ZERO_INVERSE; }
-            host_batch_inverse(den);
-            std::vector<uint8_t> aux_rows((size_t)n * 32);
-            fe zacc = fe_one();
-            for (uint64_t i = 0; i < n; ++i) {
-                if (i > 0) zacc = fe_mul(zacc, fe_mul(num[i - 1], den[i - 1]));
-                if (ctx->enc == SP_FE_CANON_BE) fe_to_bytes_be(zacc, &aux_rows[(size_t)i * 32]);
-                else { uint64_t l[4]; fe_to_lw_limbs(zacc, l); std::memcpy(&aux_rows[(size_t)i * 32], l, 32); }
-            }
-            SP_TRY(P->commit_trace(1, aux_rows.data(), 1, root));
-            roots.emplace_back(); std::memcpy(roots.back().data(), root, 32);
-            tr.append(root, 32);
-        }
-        // ---- round 2 (reference prover.rs:597-635)
-        const size_t B = air.boundary.size(), T = air.degrees.size();
-        std::vector<fe> b_alpha(B), b_beta(B), t_alpha(T), t_beta(T);
-        for (auto& x : b_alpha) x = tr.to_field();
-        for (auto& x : b_beta) x = tr.to_field();
-        for (auto& x : t_alpha) x = tr.to_field();
-        for (auto& x : t_beta) x = tr.to_field();
-        SP_TRY(P->composition_air(air, rap, b_alpha, b_beta, t_alpha, t_beta, root));
-        uint8_t comp_root[32]; std::memcpy(comp_root, root, 32);
-        tr.append(root, 32);
-        // ---- round 3 (reference prover.rs:652-684)
-        const uint32_t logn = (uint32_t)sp_log2_exact(n), logN = logn + (uint32_t)sp_log2_exact(opt.blowup_factor);
-        fe hinv = fe_inv(fe_from_u64(opt.coset_offset));
-        fe z;
-        do { z = tr.to_field(); } while (z_in_domains(z, hinv, logn, logN));
-        fe h1z, h2z;
-        std::vector<fe> ood;
-        SP_TRY(P->ood(z, &h1z, &h2z, ood));
-        tr.append_felt(h1z); tr.append_felt(h2z);
-        for (auto& e : ood) tr.append_felt(e);
-        // ---- round 4 (reference prover.rs:327-404)
-        fe gamma = tr.to_field(), gamma_p = tr.to_field();
-        std::vector<fe> tg((size_t)P->frame_rows() * P->cols());
-        for (auto& x : tg) x = tr.to_field();
-        SP_TRY(P->deep_fri_begin(gamma, gamma_p, tg, root));
-        std::vector<std::vector<uint8_t>> fri_roots;
-        fri_roots.emplace_back(root, root + 32);
-        tr.append(root, 32);
-        fe last_value;
-        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
-            const fe zeta0 = tr.to_field();
-            std::vector<std::array<uint8_t, 32>> rest;
-            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
-            for (auto& r : rest) {
-                fri_roots.emplace_back(r.begin(), r.end());
-                tr.append(r.data(), 32);
-                (void)tr.to_field();      // zeta_k: the device sampled the same value
-            }
-        } else
-        for (;;) {
-            fe zeta = tr.to_field();
-            int is_last = 0;
-            SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
-            if (is_last) break;
-            fri_roots.emplace_back(root, root + 32);
-            tr.append(root, 32);
-        }
-        tr.append_felt(last_value);
-        uint8_t gch[32];
-        tr.challenge(gch);
-        uint64_t nonce = 0;
-        SP_TRY(P->grind(gch, opt.grinding_factor, &nonce));
-        {
-            uint8_t nb[8];
-            for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
-            tr.append(nb, 8);
-        }
-        std::vector<uint64_t> iotas(opt.fri_number_of_queries);
-        for (auto& x : iotas) x = tr.to_usize() % P->N();
-        Openings o;
-        SP_TRY(P->open(iotas, o));
-        SP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
-        return SP_OK;
-    } catch (const std::exception& e) {
-        sp_set_error(std::string("air_prove: ") + e.what());
-        return SP_E_INVALID_ARG;
-    }
 }
 
 }  // namespace sp
