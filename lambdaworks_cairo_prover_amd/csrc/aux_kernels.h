@@ -51,6 +51,16 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
 int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
                       uint64_t pm, int* flag_dev, int* wide_flag_dev);
 
+// The pieces of cairo_aux_trace_device after the sorts, for callers that run them on streams of their own (prover.cpp: the sorted
+// columns and their transforms on the compute stream beside the two permutation chains):
+//   sorted columns 0-10 of the auxiliary trace (no challenge needed);
+//   memory permutation -> w.num (4n prefix products), range-check permutation -> w.rc_terms (3n);  *flag_dev: zero denominator;
+//   permutation columns 11-17 from those.
+int cairo_aux_sorted_columns(hipStream_t st, AuxWorkspace& w, uint64_t n, fe* aux_cols_out);
+int cairo_aux_memory_permutation(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe rap[3], int* flag_dev);
+int cairo_aux_rc_permutation(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe rap[3], int* flag_dev);
+int cairo_aux_permutation_columns(hipStream_t st, AuxWorkspace& w, uint64_t n, fe* aux_cols_out);
+
 // In-place inclusive prefix product of M elements (block_tot: workspace of >= M/2048 + 2 elements).
 int prefix_product(hipStream_t st, fe* data, uint64_t M, fe* block_tot);
 

@@ -23,38 +23,7 @@ __device__ __forceinline__ void ax_st(fe* p, const fe& a) {
 struct AuxConsts { fe z, alpha, zrc; };
 
 // ---- memory part -------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) aux_prepare_kernel(const fe* mem_cols, uint64_t n, const fe* pm_addr, const fe* pm_val, uint64_t pm,
-                                                          AuxConsts K, fe* a_aux, fe* v_aux, fe* num, uint64_t* keys, uint32_t* idx, int* flag) {
-    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= 4 * n) return;
-    uint64_t i = e >> 2; uint32_t k = (uint32_t)e & 3;
-    fe a = ax_ld(mem_cols + (uint64_t)k * n + i);
-    fe v = ax_ld(mem_cols + (uint64_t)(4 + k) * n + i);
-    // numerators use the ORIGINAL accesses (air.rs:543-550)
-    ax_st(num + e, fe_sub(K.z, fe_add(a, fe_mul(K.alpha, v))));
-    if (e >= 4 * n - pm) {  // last |pm| accesses are replaced by the public memory (air.rs:475-494)
-        uint64_t j = e - (4 * n - pm);
-        a = ax_ld(pm_addr + j); v = ax_ld(pm_val + j);
-    }
-    ax_st(a_aux + e, a); ax_st(v_aux + e, v);
-    fe raw = fe_from_mont(a);
-    if (raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 2);
-    keys[e] = (uint64_t)raw.v[0] | ((uint64_t)raw.v[1] << 32);
-    idx[e] = (uint32_t)e;
-}
-
-__global__ void __launch_bounds__(256) aux_gather_kernel(const fe* a_aux, const fe* v_aux, const uint32_t* idx, uint64_t M, AuxConsts K,
-                                                         fe* a_s, fe* v_s, fe* den) {
-    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= M) return;
-    uint32_t s = idx[e];
-    fe a = ax_ld(a_aux + s), v = ax_ld(v_aux + s);
-    ax_st(a_s + e, a); ax_st(v_s + e, v);
-    ax_st(den + e, fe_sub(K.z, fe_add(a, fe_mul(K.alpha, v))));
-}
-
-// ---- the same two steps split at the challenges: keys / sorted pairs first (cairo_aux_presort), numerators and
-// denominators once alpha and z are known
+// keys / sorted pairs first (they need no challenge: cairo_aux_presort), numerators and denominators once alpha and z are known
 __global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint64_t n, const fe* pm_addr, const fe* pm_val, uint64_t pm,
                                                        fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag, uint32_t key_bits, int* wide_flag) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -200,20 +169,25 @@ __global__ void __launch_bounds__(256) rc_terms_kernel(const fe* off_cols, uint6
 }
 
 // ---- wide format (air.rs:705-728), straight into natural-order columns -------------------------------------
-__global__ void __launch_bounds__(256) aux_interleave_kernel(uint64_t n, const uint16_t* rc_sorted, const fe* a_s, const fe* v_s, const fe* perm,
-                                                             const fe* rperm, fe* out) {
+// columns 0-2 sorted offsets, 3-6 sorted addresses, 7-10 sorted values: they need the sorts only, no challenge
+__global__ void __launch_bounds__(256) aux_sorted_columns_kernel(uint64_t n, const uint16_t* rc_sorted, const fe* a_s, const fe* v_s, fe* out) {
     uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     for (uint32_t k = 0; k < 3; ++k) {
         fe raw = fe_zero(); raw.v[0] = rc_sorted[3 * i + k];
         ax_st(out + (uint64_t)k * n + i, fe_to_mont(raw));
-        ax_st(out + (uint64_t)(15 + k) * n + i, ax_ld(rperm + 3 * i + k));
     }
     for (uint32_t k = 0; k < 4; ++k) {
         ax_st(out + (uint64_t)(3 + k) * n + i, ax_ld(a_s + 4 * i + k));
         ax_st(out + (uint64_t)(7 + k) * n + i, ax_ld(v_s + 4 * i + k));
-        ax_st(out + (uint64_t)(11 + k) * n + i, ax_ld(perm + 4 * i + k));
     }
+}
+// columns 11-14 memory permutation, 15-17 range-check permutation (the two prefix products)
+__global__ void __launch_bounds__(256) aux_permutation_columns_kernel(uint64_t n, const fe* perm, const fe* rperm, fe* out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    for (uint32_t k = 0; k < 4; ++k) ax_st(out + (uint64_t)(11 + k) * n + i, ax_ld(perm + 4 * i + k));
+    for (uint32_t k = 0; k < 3; ++k) ax_st(out + (uint64_t)(15 + k) * n + i, ax_ld(rperm + 3 * i + k));
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------
@@ -282,50 +256,74 @@ int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint6
     return SP_OK;
 }
 
+static dim3 ax_blocks(uint64_t x) { return dim3((unsigned)((x + 255) / 256)); }
+
+int cairo_aux_sorted_columns(hipStream_t st, AuxWorkspace& w, uint64_t n, fe* out) {
+    hipLaunchKernelGGL(aux_sorted_columns_kernel, ax_blocks(n), dim3(256), 0, st, n, w.rc_sorted, w.a_s, w.v_s, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int cairo_aux_memory_permutation(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe rap[3], int* flag) {
+    AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
+    const uint64_t M = 4 * n;
+    hipLaunchKernelGGL(aux_num_den_kernel, ax_blocks(M), dim3(256), 0, st, mem_cols, n, w.a_s, w.v_s, K, w.num, w.den);
+    SP_TRY(batch_inverse(st, w.den, w.inv_scratch, M, flag));
+    hipLaunchKernelGGL(mul_inplace_kernel, ax_blocks(M), dim3(256), 0, st, w.num, w.den, M);
+    SP_TRY(prefix_product(st, w.num, M, w.block_tot));
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int cairo_aux_rc_permutation(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe rap[3], int* flag) {
+    AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
+    const uint64_t M3 = 3 * n;
+    const fe* off_cols = mem_cols + 8 * n;
+    hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, st, w.rc_den, K);
+    SP_TRY(batch_inverse(st, w.rc_den, w.rc_den_scratch, 65536, flag));
+    hipLaunchKernelGGL(rc_terms_kernel, ax_blocks(M3), dim3(256), 0, st, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);
+    SP_TRY(prefix_product(st, w.rc_terms, M3, w.block_tot_rc));
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int cairo_aux_permutation_columns(hipStream_t st, AuxWorkspace& w, uint64_t n, fe* out) {
+    hipLaunchKernelGGL(aux_permutation_columns_kernel, ax_blocks(n), dim3(256), 0, st, n, w.num, w.rc_terms, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
                            uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool presorted) {
     if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
     AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
     const uint64_t M = 4 * n, M3 = 3 * n;
-    auto blocks = [](uint64_t x) { return dim3((unsigned)((x + 255) / 256)); };
     const bool fork = side && ev_fork && ev_join;
     hipStream_t rs = fork ? side : st;            // stream of the range-check half
-    if (fork) {
-        SP_HIP_CHECK(hipEventRecord(ev_fork, st));   // the trace columns and the cleared flag are behind this point
-        SP_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
-    }
-    if (presorted) {   // cairo_aux_presort left the sorted pairs (and the sorted offsets) in the workspace
-        hipLaunchKernelGGL(aux_num_den_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.a_s, w.v_s, K, w.num, w.den);
-    } else {
+    if (!presorted) {
         if (pm) {
             SP_HIP_CHECK(hipMemcpyAsync(w.pm_addr, pm_addr_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
             SP_HIP_CHECK(hipMemcpyAsync(w.pm_val, pm_val_host, sizeof(fe) * pm, hipMemcpyHostToDevice, st));
         }
-        // memory: substitute, sort (stable, by address), permutation column
-        hipLaunchKernelGGL(aux_prepare_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, K, w.a_aux, w.v_aux, w.num,
-                           w.keys_in, w.idx_in, flag);
+        // memory: substitute, sort (stable, by address); range check: counting sort of the 3n 16-bit offsets
+        int* no_wide = nullptr;
+        hipLaunchKernelGGL(aux_keys_kernel, ax_blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag, 64u, no_wide);
         SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, 64, w.sort_tmp));
-        hipLaunchKernelGGL(aux_gather_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, K, w.a_s, w.v_s, w.den);
+        hipLaunchKernelGGL(aux_gather_pairs_kernel, ax_blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
+        hipLaunchKernelGGL(rc_keys_kernel, ax_blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
+        SP_TRY(counting_sort_u16(st, w.rc_keys, w.rc_sorted, M3, w.hist));
     }
-    SP_TRY(batch_inverse(st, w.den, w.inv_scratch, M, flag));
-    hipLaunchKernelGGL(mul_inplace_kernel, blocks(M), dim3(256), 0, st, w.num, w.den, M);
-    SP_TRY(prefix_product(st, w.num, M, w.block_tot));
-    // range check: counting sort of the 3n 16-bit offsets, permutation column
-    const fe* off_cols = mem_cols + 8 * n;
-    if (!presorted) {
-        hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_keys, flag);
-        SP_TRY(counting_sort_u16(rs, w.rc_keys, w.rc_sorted, M3, w.hist));
+    if (fork) {
+        SP_HIP_CHECK(hipEventRecord(ev_fork, st));   // the trace columns, the sorts and the cleared flag are behind this point
+        SP_HIP_CHECK(hipStreamWaitEvent(side, ev_fork, 0));
     }
-    hipLaunchKernelGGL(rc_den_kernel, dim3(256), dim3(256), 0, rs, w.rc_den, K);
-    SP_TRY(batch_inverse(rs, w.rc_den, w.rc_den_scratch, 65536, flag));
-    hipLaunchKernelGGL(rc_terms_kernel, blocks(M3), dim3(256), 0, rs, off_cols, n, w.rc_sorted, w.rc_den, K, w.rc_terms);
-    SP_TRY(prefix_product(rs, w.rc_terms, M3, w.block_tot_rc));
+    // the two permutation arguments: two chains of dependent latencies (a batch inversion and a scan each) side by side
+    SP_TRY(cairo_aux_memory_permutation(st, w, mem_cols, n, rap, flag));
+    SP_TRY(cairo_aux_rc_permutation(rs, w, mem_cols, n, rap, flag));
     if (fork) {
         SP_HIP_CHECK(hipEventRecord(ev_join, side));
         SP_HIP_CHECK(hipStreamWaitEvent(st, ev_join, 0));
     }
-    hipLaunchKernelGGL(aux_interleave_kernel, blocks(n), dim3(256), 0, st, n, w.rc_sorted, w.a_s, w.v_s, w.num, w.rc_terms, out);
-    SP_HIP_CHECK(hipGetLastError());
+    SP_TRY(cairo_aux_sorted_columns(st, w, n, out));
+    SP_TRY(cairo_aux_permutation_columns(st, w, n, out));
+    (void)K;
     return SP_OK;
 }
 
