@@ -153,7 +153,7 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
 #pragma unroll 1
         for (int k = 14; k >= 0; --k) {
             fe f = cur(k);
-            acc(S0, k, f * f - f);
+            acc(S0, k, fe_sqr(f) - f);      // (the dedicated square: 36 + 8 multiply-adds)
             f0s = f + (f0s + f0s);
         }
         acc(S0, 15, cur(15));
