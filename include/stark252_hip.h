@@ -114,8 +114,17 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *   SP_OPT_SHARD_INTERPOLATION (1) 1: the size-n inverse transforms of a trace segment are split by column over the ranks and the
  *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns.
  *   SP_OPT_UPLOAD_THREADS (24)     host threads that gather the column groups of a row-major host trace into pinned memory
- *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB). */
-enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3 };
+ *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB).
+ *   SP_OPT_MERKLE_BACKEND (SP_MERKLE_KECCAK256)  the hash of every commitment of the context (trace, composition and FRI trees,
+ *                                  sp_merkle_build*).  SP_MERKLE_KECCAK256 is the reference's configuration (src/starks/config.rs:10-20)
+ *                                  and the only one whose proofs the reference verifies.  SP_MERKLE_POSEIDON (BASELINE.json configs[4]; NO
+ *                                  reference counterpart at the pinned revision) is Starknet's Poseidon over Stark252 as later lambdaworks
+ *                                  versions configure it: digest = the canonical 32-byte big-endian element, node = hash(left, right),
+ *                                  leaf of a row of columns = hash_many(row), leaf of a single-element tree (FRI layers) =
+ *                                  hash_single(x).  Transcript and grinding stay Keccak; the proof layout does not change.
+ *                                  Such proofs are checked with sp_cairo_verify_backend / sp_air_verify_backend. */
+enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4 };
+enum { SP_MERKLE_KECCAK256 = 0, SP_MERKLE_POSEIDON = 1 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 
 /* ---- fine-grained layer: the lambdaworks seam the reference calls ------------------------ */
@@ -141,7 +150,9 @@ int sp_lde(sp_ctx* ctx, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32
 /* MerkleTree::<BatchKeccak256Tree|Keccak256Tree>::build (prover.rs:96-104, fri_commitment.rs:39; backends
  * config.rs:10-20): n_leaves rows of fe_per_leaf elements (row-major); leaf = Keccak256(row as 32-byte BE
  * elements), parent = Keccak256(left || right). nodes_out (nullable) receives all 2n-1 nodes, root first,
- * children of i at 2i+1 and 2i+2 (the lambdaworks node order). */
+ * children of i at 2i+1 and 2i+2 (the lambdaworks node order).
+ * With SP_OPT_MERKLE_BACKEND = SP_MERKLE_POSEIDON: fe_per_leaf = 1 builds the single-element tree (leaf = hash_single),
+ * fe_per_leaf > 1 the tree over rows (leaf = hash_many); the same holds for sp_merkle_build_dev. */
 int sp_merkle_build(sp_ctx* ctx, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf,
                     uint8_t root_out[32], uint8_t* nodes_out);
 
@@ -360,6 +371,15 @@ int sp_cairo_prove_run(sp_ctx* ctx, const sp_cairo_run* run, const sp_proof_opti
  * proof is accepted, 0 when it is rejected or malformed. Ships with the library so that proofs of shapes without a golden
  * file can be checked where they are produced. */
 int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* pub, const sp_proof_options* opt);
+/* The same two verifiers for proofs whose commitments use another hash (SP_OPT_MERKLE_BACKEND): merkle_backend = SP_MERKLE_*.
+ * With SP_MERKLE_KECCAK256 they are sp_cairo_verify / sp_air_verify. */
+int sp_cairo_verify_backend(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* pub, const sp_proof_options* opt,
+                            int merkle_backend);
+int sp_air_verify_backend(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* air, const sp_proof_options* opt, int merkle_backend);
+/* Starknet Poseidon over Stark252 on the host (csrc/poseidon.h), for known-answer tests of the Poseidon backend: in = n elements in
+ * the given encoding; mode 0: hash_many(in[0..n)), 1: hash(in[0], in[1]) (n = 2), 2: hash_single(in[0]) (n = 1),
+ * 3: the Hades permutation of in[0..3) (n = 3; out receives three elements).  out: 32 bytes (96 for mode 3), same encoding. */
+int sp_poseidon_host(int fe_encoding, int mode, const uint8_t* in, uint64_t n, uint8_t* out);
 /* CLI proof file of the reference (src/main.rs:98-102): u64_be(len(proof)) || proof || PublicInputs::serialize
  * (src/cairo/air.rs:223-276). *out is malloc'd; release with sp_free. */
 int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cairo_run* run, uint8_t** out, uint64_t* out_len);

@@ -327,18 +327,29 @@ class CairoRun:
             pass
 
 
-def cairo_verify(proof, public_inputs_c, options):
-    """verify_cairo_proof (reference src/cairo/air.rs:1176-1182) on the host CPU through the library (no GPU needed)."""
+def cairo_verify(proof, public_inputs_c, options, merkle_backend=0):
+    """verify_cairo_proof (reference src/cairo/air.rs:1176-1182) on the host CPU through the library (no GPU needed).
+    merkle_backend: SP_MERKLE_KECCAK256 (the reference's trees) or SP_MERKLE_POSEIDON (sp_cairo_verify_backend)."""
     lib = _lib.load()
     opt = options.to_c()
-    return lib.sp_cairo_verify(proof, ctypes.c_uint64(len(proof)), ctypes.byref(public_inputs_c), ctypes.byref(opt)) == 1
+    return lib.sp_cairo_verify_backend(proof, ctypes.c_uint64(len(proof)), ctypes.byref(public_inputs_c), ctypes.byref(opt), int(merkle_backend)) == 1
 
 
-def air_verify(proof, desc, options):
-    """sp_air_verify: the library's CPU verifier for an AIR given as a constraint program."""
+def air_verify(proof, desc, options, merkle_backend=0):
+    """sp_air_verify(_backend): the library's CPU verifier for an AIR given as a constraint program."""
     lib = _lib.load()
     opt = options.to_c()
-    return lib.sp_air_verify(proof, ctypes.c_uint64(len(proof)), ctypes.byref(desc), ctypes.byref(opt)) == 1
+    return lib.sp_air_verify_backend(proof, ctypes.c_uint64(len(proof)), ctypes.byref(desc), ctypes.byref(opt), int(merkle_backend)) == 1
+
+
+def poseidon_host(mode, values):
+    """sp_poseidon_host on canonical integers: mode 0 hash_many, 1 hash(x, y), 2 hash_single(x), 3 the Hades permutation (three outputs)."""
+    lib = _lib.load()
+    buf = b"".join(int(v).to_bytes(32, "big") for v in values)
+    out = ctypes.create_string_buffer(96)
+    check(lib.sp_poseidon_host(SP_FE_CANON_BE, int(mode), buf, ctypes.c_uint64(len(values)), out))
+    r = [int.from_bytes(out.raw[32 * k:32 * k + 32], "big") for k in range(3)]
+    return r if mode == 3 else r[0]
 
 
 def proof_file_bytes(proof, run):
@@ -529,7 +540,8 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS = 1, 2, 3
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND = 1, 2, 3, 4
+SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
 
 
 def _ctx_set_option(self, key, value):
@@ -557,4 +569,5 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS"]
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND",
+            "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host"]

@@ -106,6 +106,10 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             if (value < 1 || value > 128) return SP_E_INVALID_ARG;
             c->opt_upload_threads = (uint32_t)value;
             break;
+        case SP_OPT_MERKLE_BACKEND:
+            if (value != SP_MERKLE_KECCAK256 && value != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
+            c->opt_merkle_backend = (int)value;
+            break;
         default: sp_set_error("sp_set_option: unknown key"); return SP_E_INVALID_ARG;
     }
     delete c->prover_state_deleter_holder;   // the options shape the prover's buffers: start from a fresh one
@@ -396,6 +400,10 @@ int sp_lde(sp_ctx* c, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32_t
     return SP_OK;
 }
 
+static sp::MerkleHash ctx_merkle_hash(const sp_ctx* c, uint32_t fe_per_leaf) {
+    if (c->opt_merkle_backend != SP_MERKLE_POSEIDON) return sp::MerkleHash::KECCAK256;
+    return fe_per_leaf == 1 ? sp::MerkleHash::POSEIDON_SINGLE : sp::MerkleHash::POSEIDON_BATCH;
+}
 int sp_merkle_build(sp_ctx* c, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf, uint8_t root_out[32], uint8_t* nodes_out) {
     if (!c || !leaves || !root_out || fe_per_leaf == 0) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c->device));
@@ -407,8 +415,9 @@ int sp_merkle_build(sp_ctx* c, const uint8_t* leaves, uint64_t n_leaves, uint32_
     SP_TRY(nodes.alloc((2 * n_leaves - 1) * sizeof(digest32)));
     SP_HIP_CHECK(hipMemcpyAsync(raw.p, leaves, total * 32, hipMemcpyHostToDevice, c->stream));
     SP_TRY(rows_to_columns(c->stream, c->enc, raw.as<uint8_t>(), n_leaves, fe_per_leaf, cols.as<fe>(), n_leaves));
-    SP_TRY(merkle_hash_leaves(c->stream, cols.as<fe>(), n_leaves, fe_per_leaf, n_leaves, nodes.as<digest32>()));
-    SP_TRY(merkle_reduce(c->stream, nodes.as<digest32>(), n_leaves));
+    const MerkleHash mh = ctx_merkle_hash(c, fe_per_leaf);
+    SP_TRY(merkle_hash_leaves(c->stream, cols.as<fe>(), n_leaves, fe_per_leaf, n_leaves, nodes.as<digest32>(), LdeOrder{0, 0, 0}, mh));
+    SP_TRY(merkle_reduce(c->stream, nodes.as<digest32>(), n_leaves, nullptr, mh));
     SP_HIP_CHECK(hipMemcpyAsync(root_out, nodes.p, 32, hipMemcpyDeviceToHost, c->stream));
     if (nodes_out) SP_HIP_CHECK(hipMemcpyAsync(nodes_out, nodes.p, (2 * n_leaves - 1) * 32, hipMemcpyDeviceToHost, c->stream));
     SP_HIP_CHECK(hipStreamSynchronize(c->stream));
@@ -420,8 +429,9 @@ int sp_merkle_build_dev(sp_ctx* c, const void* cols_dev, uint64_t n_leaves, uint
     SP_HIP_CHECK(hipSetDevice(c->device));
     if (sp_log2_exact(n_leaves) < 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
     SP_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
-    int rc = merkle_hash_leaves(c->stream, reinterpret_cast<const fe*>(cols_dev), col_stride, fe_per_leaf, n_leaves, reinterpret_cast<digest32*>(nodes_dev));
-    if (rc == SP_OK) rc = merkle_reduce(c->stream, reinterpret_cast<digest32*>(nodes_dev), n_leaves);
+    const MerkleHash mh = ctx_merkle_hash(c, fe_per_leaf);
+    int rc = merkle_hash_leaves(c->stream, reinterpret_cast<const fe*>(cols_dev), col_stride, fe_per_leaf, n_leaves, reinterpret_cast<digest32*>(nodes_dev), LdeOrder{0, 0, 0}, mh);
+    if (rc == SP_OK) rc = merkle_reduce(c->stream, reinterpret_cast<digest32*>(nodes_dev), n_leaves, nullptr, mh);
     SP_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
     if (rc != SP_OK) return rc;
     c->last_pending = true;

@@ -2,6 +2,7 @@
 #include "../../include/stark252_hip.h"
 #include "cairo_host.h"
 #include "cairo_air_host.h"
+#include "poseidon.h"
 #include <array>
 #include "common.h"
 #include <cstring>
@@ -33,6 +34,7 @@ int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, 
                     const std::vector<std::array<uint16_t, 3>>& ops, const std::vector<fe>& consts, uint32_t n_rap,
                     const std::vector<BoundaryConstraint>& boundary, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding);
 }
+namespace sp { void set_verify_merkle_backend(int backend); }
 namespace sp { int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding); }
 
 namespace sp {
@@ -228,6 +230,18 @@ int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_pub
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }
 
+namespace {
+struct VerifyBackendScope {
+    explicit VerifyBackendScope(int b) { sp::set_verify_merkle_backend(b); }
+    ~VerifyBackendScope() { sp::set_verify_merkle_backend(SP_MERKLE_KECCAK256); }
+};
+}
+int sp_cairo_verify_backend(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* p, const sp_proof_options* opt, int merkle_backend) {
+    if (merkle_backend != SP_MERKLE_KECCAK256 && merkle_backend != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
+    VerifyBackendScope scope(merkle_backend);
+    return sp_cairo_verify(proof, proof_len, p, opt);
+}
+
 // verify::<Stark252PrimeField, A> (reference src/starks/verifier.rs:559-657) for a program AIR: 1 = accept, 0 = reject
 // (also for malformed proofs or descriptors).
 int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d, const sp_proof_options* opt) {
@@ -260,6 +274,31 @@ int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cair
     std::memcpy(b + 8, proof, proof_len);
     std::memcpy(b + 8 + proof_len, pi.data(), pi.size());
     *out = b; *out_len = total;
+    return SP_OK;
+}
+
+int sp_air_verify_backend(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d, const sp_proof_options* opt, int merkle_backend) {
+    if (merkle_backend != SP_MERKLE_KECCAK256 && merkle_backend != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
+    VerifyBackendScope scope(merkle_backend);
+    return sp_air_verify(proof, proof_len, d, opt);
+}
+
+// Host-side Poseidon (csrc/poseidon.h) for known-answer tests of the optional Merkle backend.
+int sp_poseidon_host(int enc, int mode, const uint8_t* in, uint64_t n, uint8_t* out) {
+    if (!in || !out || (enc != SP_FE_MONT_LIMBS && enc != SP_FE_CANON_BE) || mode < 0 || mode > 3) return SP_E_INVALID_ARG;
+    if ((mode == 1 && n != 2) || (mode == 2 && n != 1) || (mode == 3 && n != 3) || n > (1u << 24)) return SP_E_INVALID_ARG;
+    std::vector<fe> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = enc == SP_FE_CANON_BE ? fe_from_bytes_be(in + 32 * i) : fe_from_lw_limbs(reinterpret_cast<const uint64_t*>(in + 32 * i));
+    fe r[3];
+    int n_out = 1;
+    if (mode == 0) r[0] = sp::poseidon_hash_many(v.data(), 1, (uint32_t)n);
+    else if (mode == 1) r[0] = sp::poseidon_hash2(v[0], v[1]);
+    else if (mode == 2) r[0] = sp::poseidon_hash1(v[0]);
+    else { r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; sp::poseidon_permute(r[0], r[1], r[2]); for (int k = 0; k < 3; ++k) r[k] = fe_reduce_once(r[k]); n_out = 3; }
+    for (int k = 0; k < n_out; ++k) {
+        if (enc == SP_FE_CANON_BE) fe_to_bytes_be(r[k], out + 32 * k);
+        else fe_to_lw_limbs(r[k], reinterpret_cast<uint64_t*>(out + 32 * k));
+    }
     return SP_OK;
 }
 

@@ -36,5 +36,6 @@ struct sp_ctx {
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
     bool opt_shard_interpolation = true;
     uint32_t opt_upload_threads = 24;
+    int opt_merkle_backend = SP_MERKLE_KECCAK256;
     sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

@@ -5,6 +5,7 @@
 // per-thread LDS block buffer so that arbitrary row widths need no run-time indexing of registers.
 #include "merkle.h"
 #include "keccak.h"
+#include "poseidon.h"
 #include <cstdlib>
 
 namespace sp {
@@ -295,8 +296,63 @@ __global__ void __launch_bounds__(256) node_hash_lanes_kernel(digest32* nodes, u
     }
 }
 
-int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes, LdeOrder order) {
+// ---- Poseidon backend (poseidon.h) -------------------------------------------------------------------------------------
+// One lane per hash: a permutation is ~214 dependent-ish field products (68 k issue slots), so a leaf of 34 columns is 18 of them
+// against the 9 Keccak-f (4.5 k slots each) of the reference's hash - the commitment is bound by the multiplier like the transforms.
+constexpr int PS_THREADS = 128;
+__global__ void __launch_bounds__(PS_THREADS) poseidon_leaf_kernel(const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves,
+                                                                   digest32* leaves_out, LdeOrder order, int single) {
+    const uint64_t i = (uint64_t)blockIdx.x * PS_THREADS + threadIdx.x;
+    if (i >= n_leaves) return;
+    const fe* p = cols + order.at(i);
+    const fe h = single ? poseidon_hash1(*p) : poseidon_hash_many(p, col_stride, ncols);
+    digest32 d;
+    poseidon_digest_from_fe(h, d.w);
+    leaves_out[i] = d;
+}
+__global__ void __launch_bounds__(PS_THREADS) poseidon_node_kernel(digest32* nodes, uint64_t first, uint64_t count) {
+    const uint64_t i = (uint64_t)blockIdx.x * PS_THREADS + threadIdx.x;
+    if (i >= count) return;
+    const uint64_t p = first + i;
+    const digest32 l = nodes[2 * p + 1], r = nodes[2 * p + 2];
+    const fe h = poseidon_hash2(poseidon_fe_from_digest(l.w), poseidon_fe_from_digest(r.w));
+    digest32 d;
+    poseidon_digest_from_fe(h, d.w);
+    nodes[p] = d;
+}
+// The transcript step of FriChallenge for a tree whose root was not produced by the Keccak lanes kernel: one lane, one Keccak-f.
+__global__ void fri_challenge_kernel(const digest32* root, FriChallenge ch) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const digest32 rt = *root;
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { s[k] = ch.state[k]; s[4 + k] = rt.w[k]; ch.root_copy[k] = rt.w[k]; }
+    s[8] = 0x01ULL;
+    s[16] = 0x8000000000000000ULL;
+    sp_keccak_f1600_dev(s);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ch.state[k] = sp_bswap64(s[3 - k]);          // reverse(d) as little-endian words
+    fe z;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { z.v[2 * k] = (uint32_t)s[k]; z.v[2 * k + 1] = (uint32_t)(s[k] >> 32); }
+    z.v[7] &= 0x07ffffffu;                                                    // 251 bits (transcript.rs:24-43): below p
+    *ch.cst_out = fe_mul(fe_to_mont(z), *ch.mul_in);
+}
+
+static int poseidon_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* out, LdeOrder order, MerkleHash mh) {
+    if (mh == MerkleHash::POSEIDON_SINGLE && ncols != 1) { sp_set_error("merkle: a single-element Poseidon tree has one column"); return SP_E_INVALID_ARG; }
+    const unsigned blocks = (unsigned)((n_leaves + PS_THREADS - 1) / PS_THREADS);
+    hipLaunchKernelGGL(poseidon_leaf_kernel, dim3(blocks), dim3(PS_THREADS), 0, st, cols, col_stride, ncols, n_leaves, out, order,
+                       mh == MerkleHash::POSEIDON_SINGLE ? 1 : 0);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* nodes, LdeOrder order, MerkleHash mh) {
     if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || ncols == 0) { sp_set_error("merkle: leaf count must be a power of two"); return SP_E_INVALID_ARG; }
+    if (mh != MerkleHash::KECCAK256) return poseidon_leaves(st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order, mh);
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
     if (!launch_leaf_hash(st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order))
         hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order);
@@ -304,8 +360,9 @@ int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint
     return SP_OK;
 }
 
-int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out, LdeOrder order) {
+int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out, LdeOrder order, MerkleHash mh) {
     if (n_leaves == 0 || ncols == 0) return SP_E_INVALID_ARG;
+    if (mh != MerkleHash::KECCAK256) return poseidon_leaves(st, cols, col_stride, ncols, n_leaves, leaves_out, order, mh);
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
     if (!launch_leaf_hash(st, cols, col_stride, ncols, n_leaves, leaves_out, order))
         hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, leaves_out, order);
@@ -313,9 +370,20 @@ int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride,
     return SP_OK;
 }
 
-int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch) {
+int merkle_reduce(hipStream_t st, digest32* nodes, uint64_t n_leaves, const FriChallenge* ch, MerkleHash mh) {
     if (ch && n_leaves < 2) return SP_E_INVALID_ARG;
     uint64_t count = n_leaves >> 1;
+    if (mh != MerkleHash::KECCAK256) {
+        for (; count >= 1; count >>= 1) {
+            hipLaunchKernelGGL(poseidon_node_kernel, dim3((unsigned)((count + PS_THREADS - 1) / PS_THREADS)), dim3(PS_THREADS), 0, st, nodes, count - 1, count);
+            SP_HIP_CHECK(hipGetLastError());
+        }
+        if (ch) {
+            hipLaunchKernelGGL(fri_challenge_kernel, dim3(1), dim3(64), 0, st, nodes, *ch);
+            SP_HIP_CHECK(hipGetLastError());
+        }
+        return SP_OK;
+    }
     // throughput-bound levels in pairs: the level of `count` nodes and the one above it, while the upper one still fills the chip
     // (2^17 threads = two waves per SIMD)
     static const bool pairs = std::getenv("SP_MK_NO_PAIRS") == nullptr;   // (A/B switch of tools/merkle_pair_ab.py)

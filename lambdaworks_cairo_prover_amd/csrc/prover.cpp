@@ -400,20 +400,22 @@ int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t 
 // natural order.  Several ranks: the 32-byte leaf digests are exchanged so that rank d owns the contiguous leaves
 // [d N/G, (d+1) N/G) - block d of the local digest array is exactly this rank's share of that range - then every rank reduces
 // its subtree, the G subtree roots are all-gathered and the top log2 G levels finished everywhere.
-int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32]) {
+int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32],
+                              bool single_element_tree) {
+    const MerkleHash mh = merkle_hash(single_element_tree);
     if (tree.top == tree.sub) {   // the whole tree on this rank
-        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, L, tree.sub, order));
-        SP_TRY(merkle_reduce(c_->stream, tree.sub, L));
+        SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, L, tree.sub, order, mh));
+        SP_TRY(merkle_reduce(c_->stream, tree.sub, L, nullptr, mh));
     } else {
         if (L != tree.sub_leaves || L > Nl_) return SP_E_STATE;
-        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<digest32*>(d_local_), order));
+        SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<digest32*>(d_local_), order, mh));
         SP_TRY(exchange_blocks(d_local_, d_recv_, (L >> logG_) * sizeof(digest32)));
         // recv[s][j] = leaf (first + j) G + s of the global order = leaf j G + s of this rank's range
         SP_TRY(interleave_shards(c_->stream, d_recv_, tree.sub + (L - 1), L >> logG_, ShardMap{logG_, logG_, 0}));
-        SP_TRY(merkle_reduce(c_->stream, tree.sub, L));
+        SP_TRY(merkle_reduce(c_->stream, tree.sub, L, nullptr, mh));
         SP_TRY(all_gather(tree.sub, d_roots_, sizeof(digest32)));
         SP_HIP_CHECK(hipMemcpyAsync(tree.top + (G_ - 1), d_roots_, G_ * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
-        SP_TRY(merkle_reduce(c_->stream, tree.top, G_));
+        SP_TRY(merkle_reduce(c_->stream, tree.top, G_, nullptr, mh));
     }
     return readback(root_out, tree.top, 32);
 }
@@ -1201,7 +1203,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
     if (used_pref) SP_HIP_CHECK(hipMemcpyAsync(&flag_pref, d_flag_side_, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
     deep_pref_ = false;
-    SP_TRY(commit_local(d_fri_evals_[0], 0, 1, fri_trees_[0].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[0], root0_out));   // synchronises
+    SP_TRY(commit_local(d_fri_evals_[0], 0, 1, fri_trees_[0].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[0], root0_out, true));   // synchronises
     flag |= flag_pref;
     if (flag) { sp_set_error("deep composition: z lies on the LDE coset"); return SP_E_ZERO_INVERSE; }
     fri_layer_ = 1;
@@ -1233,7 +1235,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
     }
     fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_);
     if (k + 1 < logn_) {
-        SP_TRY(commit_local(d_fri_evals_[k + 1], 0, 1, fri_trees_[k + 1].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[k + 1], root_out));
+        SP_TRY(commit_local(d_fri_evals_[k + 1], 0, 1, fri_trees_[k + 1].sub_leaves, LdeOrder{0, 0, 0}, fri_trees_[k + 1], root_out, true));
         fri_layer_ += 1;
         *is_last = 0;
     } else {
@@ -1279,9 +1281,9 @@ int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], st
         SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, k == 0 ? nullptr : d_cst + k));
         if (k + 1 < L) {
             TreeBuf& t = fri_trees_[k + 1];
-            SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}));
+            SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}, merkle_hash(true)));
             const FriChallenge ch{d_state, d_cmul + (k + 1), d_cst + (k + 1), d_roots + 4 * (size_t)(k + 1)};
-            SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch));
+            SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch, merkle_hash(true)));
         }
     }
     for (uint32_t k = 0; k < L; ++k) { fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_); }

@@ -108,7 +108,13 @@ class StarkProver : public sp_deletable {
     bool ready_ = false;   // setup() completed: every buffer below exists
     // Commitment over `L` leaves this rank holds in local natural order (leaf l = global leaf (l << logG) | rank): hash,
     // exchange the digests so that every rank owns a contiguous range, reduce the subtree, combine the G roots.
-    int commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32]);
+    int commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32],
+                     bool single_element_tree = false);
+    // the hash of the commitments (sp_set_option SP_OPT_MERKLE_BACKEND): rows of columns, or the single elements of a FRI layer
+    MerkleHash merkle_hash(bool single_element_tree) const {
+        return c_->opt_merkle_backend == SP_MERKLE_POSEIDON ? (single_element_tree ? MerkleHash::POSEIDON_SINGLE : MerkleHash::POSEIDON_BATCH)
+                                                            : MerkleHash::KECCAK256;
+    }
     int commit_columns(const fe* cols_dev, uint64_t stride, uint32_t ncols, TreeBuf& tree, uint8_t root_out[32]) {
         return commit_local(cols_dev, stride, ncols, Nl_, lde_order(), tree, root_out);
     }

@@ -5,6 +5,7 @@
 #include "cairo_air_host.h"
 #include "common.h"
 #include "keccak.h"
+#include "poseidon.h"
 #include <algorithm>
 #include <array>
 #include <cstring>
@@ -149,14 +150,33 @@ struct Tr {
     fe field() { uint8_t r[32]; challenge(r); r[0] &= 0x07; return fe_from_bytes_be(r); }
     uint64_t usize() { uint8_t r[32]; challenge(r); uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | r[i]; return v; }
 };
-Dig hash_felts(const fe* v, size_t k) {
+// the hash of the commitments being checked (sp_*_verify_backend; thread-local: the entry points are context-free)
+thread_local int t_merkle_backend = SP_MERKLE_KECCAK256;
+Dig poseidon_dig(const fe& h) {
+    Dig d; uint64_t w[4];
+    poseidon_digest_from_fe(h, w);
+    std::memcpy(d.data(), w, 32);
+    return d;
+}
+fe poseidon_fe(const Dig& d) {
+    uint64_t w[4];
+    std::memcpy(w, d.data(), 32);
+    return poseidon_fe_from_digest(w);
+}
+Dig hash_felts(const fe* v, size_t k, bool single_element_tree) {
+    if (t_merkle_backend == SP_MERKLE_POSEIDON) return poseidon_dig(single_element_tree ? poseidon_hash1(v[0]) : poseidon_hash_many(v, 1, (uint32_t)k));
     std::vector<uint8_t> b(32 * k);
     for (size_t i = 0; i < k; ++i) fe_to_bytes_be(v[i], &b[32 * i]);
     Dig d; sp_keccak256_host(b.data(), b.size(), d.data()); return d;
 }
-bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, const fe* v, size_t k) {
-    Dig h = hash_felts(v, k);
+bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, const fe* v, size_t k, bool single_element_tree = false) {
+    Dig h = hash_felts(v, k, single_element_tree);
     for (const Dig& s : path) {
+        if (t_merkle_backend == SP_MERKLE_POSEIDON) {
+            h = poseidon_dig((index & 1) ? poseidon_hash2(poseidon_fe(s), poseidon_fe(h)) : poseidon_hash2(poseidon_fe(h), poseidon_fe(s)));
+            index >>= 1;
+            continue;
+        }
         uint8_t b[64];
         if (index & 1) { std::memcpy(b, s.data(), 32); std::memcpy(b + 32, h.data(), 32); } else { std::memcpy(b, h.data(), 32); std::memcpy(b + 32, s.data(), 32); }
         sp_keccak256_host(b, 64, h.data());
@@ -165,6 +185,8 @@ bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, co
     return h == root;
 }
 }  // namespace
+
+void set_verify_merkle_backend(int backend) { t_merkle_backend = backend; }
 
 // What `verify` needs from an AIR (reference src/starks/traits.rs:15-119).
 struct VerifySpec {
@@ -280,8 +302,8 @@ static int verify_host(const uint8_t* proof_bytes, size_t len, const VerifySpec&
         fe v = q.evals[0];
         for (size_t l = 0; l < L; ++l) {
             uint64_t dl = N >> l, isym = (iotas[s] + dl / 2) % dl;
-            ok &= merkle_ok(q.paths_sym[l], pr.fri_roots[l], isym, &q.evals_sym[l], 1);
-            ok &= merkle_ok(q.paths[l], pr.fri_roots[l], iotas[s], &q.evals[l], 1);
+            ok &= merkle_ok(q.paths_sym[l], pr.fri_roots[l], isym, &q.evals_sym[l], 1, true);
+            ok &= merkle_ok(q.paths[l], pr.fri_roots[l], iotas[s], &q.evals[l], 1, true);
             const fe& es = q.evals_sym[l];
             v = fe_add(fe_mul(fe_add(v, es), half), fe_mul(fe_mul(fe_mul(zetas[l], fe_sub(v, es)), half), xinv));
             xinv = fe_sqr(xinv);

@@ -116,7 +116,7 @@ int oracle_lde(const uint8_t* coeffs, uint64_t n, uint32_t blowup, const uint8_t
 int oracle_merkle_build(const uint8_t* rows, uint64_t n_leaves, uint32_t fe_per_leaf, uint8_t root_out[32], uint8_t* nodes_out) {
     try {
         std::vector<Fp> v = load_felts(rows, n_leaves * fe_per_leaf);
-        MerkleTree t = MerkleTree::build_batched(v.data(), n_leaves, fe_per_leaf);
+        MerkleTree t = MerkleTree::build_batched(v.data(), n_leaves, fe_per_leaf, fe_per_leaf == 1);
         std::memcpy(root_out, t.root.data(), 32);
         if (nodes_out) for (size_t i = 0; i < t.nodes.size(); ++i) std::memcpy(nodes_out + 32 * i, t.nodes[i].data(), 32);
         return 0;
@@ -126,6 +126,25 @@ int oracle_merkle_build(const uint8_t* rows, uint64_t n_leaves, uint32_t fe_per_
 // Transcript replay helper: feed `n_ops` operations; op kinds: 0 append(bytes), 1 challenge -> 32 bytes,
 // 2 to_field -> 32 bytes, 3 to_usize -> 8 bytes BE.
 struct OracleTranscript { Transcript t; };
+// Merkle backend of every later call: 0 Keccak256 (reference), 1 Starknet Poseidon (merkle.hpp)
+int oracle_set_merkle_backend(int backend) {
+    if (backend != 0 && backend != 1) return -1;
+    merkle_backend() = backend;
+    return 0;
+}
+// Poseidon known answers: mode 0 hash_many(in[0..n)), 1 hash(in[0], in[1]), 2 hash_single(in[0]), 3 permutation of in[0..3) (96 bytes out)
+int oracle_poseidon(int mode, const uint8_t* in, uint64_t n, uint8_t* out) {
+    std::vector<Fp> v(n);
+    for (uint64_t i = 0; i < n; ++i) v[i] = Fp::from_bytes_be(in + 32 * i);
+    const Poseidon& ps = Poseidon::get();
+    if (mode == 0) ps.hash_many(v.data(), n).to_bytes_be(out);
+    else if (mode == 1 && n == 2) ps.hash(v[0], v[1]).to_bytes_be(out);
+    else if (mode == 2 && n == 1) ps.hash_single(v[0]).to_bytes_be(out);
+    else if (mode == 3 && n == 3) { Fp s[3] = {v[0], v[1], v[2]}; ps.permute(s); for (int k = 0; k < 3; ++k) s[k].to_bytes_be(out + 32 * k); }
+    else return -1;
+    return 0;
+}
+
 void* oracle_transcript_new() { return new OracleTranscript(); }
 void oracle_transcript_free(void* h) { delete (OracleTranscript*)h; }
 void oracle_transcript_append(void* h, const uint8_t* d, uint64_t n) { ((OracleTranscript*)h)->t.append(d, n); }

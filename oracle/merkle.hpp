@@ -9,6 +9,7 @@
 #pragma once
 #include "fp.hpp"
 #include "keccak.hpp"
+#include "poseidon.hpp"
 #include <array>
 #include <vector>
 
@@ -16,7 +17,14 @@ namespace oracle {
 
 typedef std::array<uint8_t, 32> Digest;
 
-inline Digest hash_felts(const Fp* row, size_t cols) {
+// The hash of the trees: 0 = Keccak256 (the reference, config.rs:10-20), 1 = Starknet Poseidon (poseidon.hpp - the optional backend of
+// BASELINE.json configs[4], NO reference counterpart: leaf of a row = hash_many, leaf of a single-element tree = hash_single,
+// node = hash(left, right), digest = canonical big-endian element).  A process-wide switch: the oracle is test infrastructure.
+inline int& merkle_backend() { static int b = 0; return b; }
+inline Digest poseidon_digest(const Fp& x) { Digest d; x.to_bytes_be(d.data()); return d; }
+
+inline Digest hash_felts(const Fp* row, size_t cols, bool single_element_tree = false) {
+    if (merkle_backend() == 1) return poseidon_digest(single_element_tree ? Poseidon::get().hash_single(row[0]) : Poseidon::get().hash_many(row, cols));
     Keccak256 k;
     uint8_t b[32];
     for (size_t j = 0; j < cols; ++j) { row[j].to_bytes_be(b); k.update(b, 32); }
@@ -24,6 +32,7 @@ inline Digest hash_felts(const Fp* row, size_t cols) {
     return d;
 }
 inline Digest hash_pair(const Digest& l, const Digest& r) {
+    if (merkle_backend() == 1) return poseidon_digest(Poseidon::get().hash(Fp::from_bytes_be(l.data()), Fp::from_bytes_be(r.data())));
     uint8_t buf[64];
     std::memcpy(buf, l.data(), 32); std::memcpy(buf + 32, r.data(), 32);
     Digest d; keccak256(buf, 64, d.data());
@@ -41,18 +50,21 @@ struct MerkleTree {
         if (n_leaves == 0 || (n_leaves & (n_leaves - 1))) throw std::runtime_error("leaf count must be a power of two");
         nodes.assign(2 * n_leaves - 1, Digest());
         for (size_t i = 0; i < n_leaves; ++i) nodes[n_leaves - 1 + i] = leaves[i];
-        for (size_t i = n_leaves - 1; i-- > 0;) nodes[i] = hash_pair(nodes[2 * i + 1], nodes[2 * i + 2]);
+        for (size_t lo = n_leaves / 2; lo >= 1; lo /= 2) {   // level by level (independent nodes: threads help the Poseidon backend)
+#pragma omp parallel for schedule(static) if (lo >= 64)
+            for (long i = (long)lo - 1; i < (long)(2 * lo - 1); ++i) nodes[i] = hash_pair(nodes[2 * i + 1], nodes[2 * i + 2]);
+        }
         root = nodes[0];
     }
     // rows: row-major n x cols
-    static MerkleTree build_batched(const Fp* rows, size_t n, size_t cols) {
+    static MerkleTree build_batched(const Fp* rows, size_t n, size_t cols, bool single_element_tree = false) {
         std::vector<Digest> leaves(n);
 #pragma omp parallel for schedule(static)
-        for (long i = 0; i < (long)n; ++i) leaves[i] = hash_felts(rows + (size_t)i * cols, cols);
+        for (long i = 0; i < (long)n; ++i) leaves[i] = hash_felts(rows + (size_t)i * cols, cols, single_element_tree);
         MerkleTree t; t.build_from_leaves(std::move(leaves));
         return t;
     }
-    static MerkleTree build_single(const Fp* vals, size_t n) { return build_batched(vals, n, 1); }
+    static MerkleTree build_single(const Fp* vals, size_t n) { return build_batched(vals, n, 1, true); }
 
     std::vector<Digest> proof(size_t pos) const {
         std::vector<Digest> path;
@@ -67,8 +79,9 @@ struct MerkleTree {
 };
 
 // lambdaworks `Proof::verify::<Backend>(root, index, value)`
-inline bool merkle_verify(const std::vector<Digest>& path, const Digest& root, size_t index, const Fp* value, size_t cols) {
-    Digest h = hash_felts(value, cols);
+inline bool merkle_verify(const std::vector<Digest>& path, const Digest& root, size_t index, const Fp* value, size_t cols,
+                          bool single_element_tree = false) {
+    Digest h = hash_felts(value, cols, single_element_tree);
     for (const Digest& sib : path) {
         h = (index & 1) ? hash_pair(sib, h) : hash_pair(h, sib);
         index >>= 1;

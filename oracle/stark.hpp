@@ -642,8 +642,8 @@ inline bool verify(const Air& air, const StarkProof& proof) {
         for (size_t k = 0; k < L; ++k) {
             size_t dl = size_t(1) << (domain.lde_root_order - k);
             size_t isym = (iota + dl / 2) % dl;
-            ok &= merkle_verify(q.layers_auth_paths_sym[k], proof.fri_layers_merkle_roots[k], isym, &q.layers_evaluations_sym[k], 1);
-            ok &= merkle_verify(q.layers_auth_paths[k], proof.fri_layers_merkle_roots[k], iota, &q.layers_evaluations[k], 1);
+            ok &= merkle_verify(q.layers_auth_paths_sym[k], proof.fri_layers_merkle_roots[k], isym, &q.layers_evaluations_sym[k], 1, true);
+            ok &= merkle_verify(q.layers_auth_paths[k], proof.fri_layers_merkle_roots[k], iota, &q.layers_evaluations[k], 1, true);
             const Fp& es = q.layers_evaluations_sym[k];
             v = (v + es) * two_inv + zetas[k] * (v - es) * two_inv * ep_inv;
             ep_inv = ep_inv.square();

@@ -104,6 +104,20 @@ def merkle_build(rows, want_nodes=False):
     return (root.raw, nodes) if want_nodes else root.raw
 
 
+def set_merkle_backend(backend):
+    """0 = Keccak256 trees (the reference), 1 = Starknet Poseidon trees (oracle/poseidon.hpp); process-wide, reset it after use."""
+    assert load().oracle_set_merkle_backend(int(backend)) == 0
+
+
+def poseidon(mode, values):
+    """mode 0 hash_many, 1 hash(x, y), 2 hash_single(x), 3 the Hades permutation (three outputs); canonical integers."""
+    buf = b"".join(fe(v) for v in values)
+    out = ctypes.create_string_buffer(96)
+    assert load().oracle_poseidon(int(mode), buf, ctypes.c_uint64(len(values)), out) == 0
+    r = [int.from_bytes(out.raw[32 * k:32 * k + 32], "big") for k in range(3)]
+    return r if mode == 3 else r[0]
+
+
 def batch_inverse(arr):
     a = np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1, 32).copy()
     rc = load().oracle_batch_inverse(_u8p(a), ctypes.c_uint64(a.shape[0]))

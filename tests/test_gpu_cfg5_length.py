@@ -76,6 +76,18 @@ def test_whole_proof_of_a_2_24_row_trace_on_one_gpu(hip_lib):
         want = hashlib.sha256(proof).hexdigest()
         print(f"\n2^24 rows, blowup {blowup}: {sum(rounds):.0f} ms of device time (rounds {[round(r) for r in rounds[1:]]}), "
               f"{dev_bytes / 1e9:.0f} GB held by the prover, upload {up['dma_gbs']} GB/s, exposed {up['exposed_ms']} ms")
+        # configs[4] names Poseidon Merkle trees: the optional backend at this length (2^26-leaf trees of field-element digests)
+        ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
+        pproof = ctx.cairo_prove_run(run, opt)
+        prounds = ctx.last_round_ms()
+        assert len(pproof) == len(proof) and pproof != proof
+        assert api.cairo_verify(pproof, run.public_inputs_c, opt, api.SP_MERKLE_POSEIDON)
+        assert not api.cairo_verify(pproof, run.public_inputs_c, opt)
+        bad = bytearray(pproof)
+        bad[len(bad) // 3] ^= 0x10
+        assert not api.cairo_verify(bytes(bad), run.public_inputs_c, opt, api.SP_MERKLE_POSEIDON)
+        print(f"the same with Poseidon trees: {sum(prounds):.0f} ms of device time (rounds {[round(r) for r in prounds[1:]]})")
+        ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_KECCAK256)
         trace = run.main_trace()                         # the reference's row-major TraceTable: 18 GB of pageable memory
         assert hashlib.sha256(ctx.cairo_prove(trace, run.public_inputs_c, opt)).hexdigest() == want
         if _free_device_bytes() >= trace.nbytes + (2 << 30):

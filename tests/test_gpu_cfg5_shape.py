@@ -27,7 +27,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, backend, q):
     import sys
     import torch.distributed as dist
     here = os.path.dirname(os.path.abspath(__file__))
@@ -39,6 +39,7 @@ def _worker(rank, world, port, q):
         run = api.CairoRun.fibonacci(FIB_INDEX)
         ctx = api.Context(device=0)
         ctx.set_collective(world, rank, api.StagedAllGather())
+        ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
         proof = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*OPTIONS))
         q.put((rank, hashlib.sha256(proof).hexdigest(), ctx.prover_device_bytes(), ctx.last_proof_info(), ctx.comm_stats()))
         ctx.close()
@@ -49,7 +50,9 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib):
+@pytest.mark.parametrize("backend", [0, 1], ids=["keccak256", "poseidon"])
+def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib, backend):
+    """backend 1: configs[4] names Poseidon Merkle trees - the optional backend (SP_OPT_MERKLE_BACKEND, no reference counterpart)."""
     import ctypes
     from lambdaworks_cairo_prover_amd import api
     hip = ctypes.CDLL("libamdhip64.so")          # the runtime the library itself uses (no second HIP runtime in this process)
@@ -61,14 +64,17 @@ def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib):
     run = api.CairoRun.fibonacci(FIB_INDEX)
     assert run.n_rows == 1 << 21
     with api.Context(device=0) as ctx:                      # single rank: the reference bytes, then free its 80 GB
+        ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
         single = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*OPTIONS))
         single_bytes = ctx.prover_device_bytes()
-    assert api.cairo_verify(single, run.public_inputs_c, api.ProofOptions(*OPTIONS))
+        single_ms = sum(ctx.last_round_ms())
+    assert api.cairo_verify(single, run.public_inputs_c, api.ProofOptions(*OPTIONS), backend)
+    assert not api.cairo_verify(single, run.public_inputs_c, api.ProofOptions(*OPTIONS), 1 - backend)
     want = hashlib.sha256(single).hexdigest()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
     port = _free_port()
-    procs = [mpc.Process(target=_worker, args=(r, WORLD, port, q)) for r in range(WORLD)]
+    procs = [mpc.Process(target=_worker, args=(r, WORLD, port, backend, q)) for r in range(WORLD)]
     for p in procs:
         p.start()
     got = [q.get(timeout=3000) for _ in procs]
@@ -83,7 +89,8 @@ def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib):
         per_rank.append(dev_bytes)
     peak = max(per_rank)
     at_cfg5 = peak * 8                                  # n = 2^24 instead of 2^21: every buffer is linear in n
-    print(f"\nper-rank device bytes at n = 2^21, blowup 16, world 8: {peak / 1e9:.1f} GB (single rank: {single_bytes / 1e9:.1f} GB); "
+    print(f"\n[{'poseidon' if backend else 'keccak256'} trees, single-rank proof {single_ms:.0f} ms of device time] "
+          f"per-rank device bytes at n = 2^21, blowup 16, world 8: {peak / 1e9:.1f} GB (single rank: {single_bytes / 1e9:.1f} GB); "
           f"extrapolated to configs[4] (n = 2^24): {at_cfg5 / 1e9:.0f} GB of {HBM_BYTES / 1e9:.0f} GB")
     assert at_cfg5 < 0.9 * HBM_BYTES
     assert peak < single_bytes / 3                      # sharding really divides the footprint

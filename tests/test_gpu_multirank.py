@@ -69,6 +69,8 @@ def _worker(rank, world, port, case, options, knobs, q):
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
             ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, knobs["shard_interp"])
+        if knobs.get("poseidon"):
+            ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
         proof = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
         proof2 = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))  # buffer reuse path
         stats = ctx.comm_stats()
@@ -121,6 +123,10 @@ CASES = [
     (2, {"kind": "fib_flip", "fib": 100, "row": 700, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
     (4, {"kind": "fib_flip", "fib": 100, "row": 3, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
     (2, RND(1024, 16), (4, 3, 3, 1), {"fri_min_log": 6}),
+    # Poseidon commitments (the optional backend of configs[4]): subtrees, digest all-to-all and top tree over field-element digests
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "poseidon": True}),
+    (8, FIB(60), (16, 3, 3, 1), {"fri_min_log": 8, "poseidon": True}),
+    (4, RND(256, 17), (8, 4, 3, 2), {"fri_min_log": 6, "poseidon": True, "async": True}),
 ]
 
 
@@ -128,8 +134,15 @@ CASES = [
 def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_ctx):
     from lambdaworks_cairo_prover_amd import api
     trace, pub, keep = _inputs(case)
-    want = oracle.cairo_prove(trace, pub, options)
-    single = hip_ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+    backend = 1 if knobs.get("poseidon") else 0
+    oracle.set_merkle_backend(backend)
+    hip_ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
+    try:
+        want = oracle.cairo_prove(trace, pub, options)
+        single = hip_ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+    finally:
+        oracle.set_merkle_backend(0)
+        hip_ctx.set_option(api.SP_OPT_MERKLE_BACKEND, 0)
     assert single == want
     results = _run_world(world, case, options, knobs)
     for r in range(world):
