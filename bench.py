@@ -351,6 +351,52 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
                     "fastest of those calls - exposed_ms is how long the compute stream waited for column groups"}
 
 
+def poseidon_benchmark(api, torch, fib, blowup):
+    """configs[4] names Poseidon Merkle trees: the optional backend (SP_OPT_MERKLE_BACKEND; NO reference counterpart, so no bit-exactness
+    claim against the reference - the bytes equal the CPU oracle's under the same backend, tests/test_gpu_poseidon.py).  A context of
+    its own (the option re-shapes the prover); the proof is checked by the library's host verifier under that backend."""
+    run = api.CairoRun.fibonacci(fib)
+    trace = run.main_trace()
+    opt = api.ProofOptions(blowup, 80, 3, 20)
+    dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))
+    torch.cuda.synchronize()
+    n, cols = trace.shape[0], trace.shape[1]
+    with api.Context(device=torch.cuda.current_device()) as ctx:
+        ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
+        proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+            times.append((time.perf_counter() - t0) * 1e3)
+        rounds = ctx.last_round_ms()
+        # the rate of the commitment kernel alone: 2^20 rows of 34 columns -> 18 Hades permutations per leaf + one per node
+        leaves, width = 1 << 20, 34
+        data = torch.randint(0, 2**31 - 1, (width, leaves, 8), dtype=torch.int32, device=dev_trace.device)
+        data[..., 7] &= 0x07FFFFFF
+        nodes = torch.empty((2 * leaves - 1, 32), dtype=torch.uint8, device=dev_trace.device)
+        ctx.merkle_build_dev(data.data_ptr(), leaves, width, leaves, nodes.data_ptr())
+        ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            ctx.merkle_build_dev(data.data_ptr(), leaves, width, leaves, nodes.data_ptr())
+        ctx.sync()
+        tree_ms = (time.perf_counter() - t0) * 1e3 / 3
+    perms = leaves * ((width + 2) // 2) + leaves - 1
+    t0 = time.perf_counter()
+    ok = api.cairo_verify(proof, run.public_inputs_c, opt, api.SP_MERKLE_POSEIDON)
+    verify_ms = (time.perf_counter() - t0) * 1e3
+    return {"merkle_backend": "poseidon (Starknet Hades over Stark252, csrc/poseidon.h)", "proof_gen_ms": min(times), "proof_gen_ms_all": times,
+            "device_round_ms": rounds, "trace_rows": run.n_rows, "trace_cols": 52, "blowup": blowup, "fri_queries": 80, "grinding": 20,
+            "proof_bytes": len(proof), "proof_sha256": hashlib.sha256(proof).hexdigest(), "verified_by_host_verifier": bool(ok),
+            "host_verify_ms": verify_ms,
+            "commitment_kernel": {"workload": "2^20 leaves x 34 columns, whole tree", "ms": tree_ms, "hades_permutations_per_s": perms / (tree_ms * 1e-3),
+                                  "field_products_per_s": 214 * perms / (tree_ms * 1e-3),
+                                  "note": "214 Montgomery products (83 + 24 squarings, 83 + 24 products) per permutation: the kernel runs at the "
+                                          "multiplier-bound rate of the NTT butterflies (roofline.mulmod_per_s)"},
+            "note": "not the reference's configuration (config.rs:10-20 fixes Keccak256 trees): reported beside `proof`, never instead of it"}
+
+
 XGMI_LINK_GBS_PER_DIRECTION = 76.8   # /opt/skills/guides/MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU
 XGMI_LINK_EFFICIENCY = 0.6           # what RCCL's point-to-point and ring kernels are assumed to reach of a link (not measured here)
 COLLECTIVE_LATENCY_MS = 0.03
@@ -543,6 +589,7 @@ def main():
     ap.add_argument("--cold-child", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cold-shape", type=int, nargs=2, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--cold-path", type=str, default="rows", help=argparse.SUPPRESS)
+    ap.add_argument("--no-poseidon", action="store_true", help="skip the proof with Poseidon Merkle trees (the optional backend of configs[4])")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the first-proof-of-a-fresh-process measurements")
     ap.add_argument("--project-ranks", type=int, default=8, help="N = 1 only: also PROJECT (not measure) an N-rank sharded proof from rank 0's share on this GPU (0: off)")
     args = ap.parse_args()
@@ -651,6 +698,11 @@ def main():
             if world == 1:
                 out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
                 out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
+                if not args.no_poseidon:
+                    try:
+                        out["proof_poseidon"] = poseidon_benchmark(api, torch, args.proof_fib, args.proof_blowup)
+                    except Exception as e:
+                        out["proof_poseidon"] = {"error": repr(e)}
                 if args.project_ranks > 1:
                     out["projected"] = {}
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):

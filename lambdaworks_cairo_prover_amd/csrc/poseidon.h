@@ -12,9 +12,9 @@
 // oracle's, this one); a digest is the canonical 32-byte big-endian encoding of the resulting element.
 //
 // Arithmetic: the state stays lazily reduced (every lane in [0, 2p)) between rounds.  A partial round is
-//   lane 2 += constant (< 3p < 2^253);  square (36 + 8 multiply-adds) and product (72) -> [0, 2p);  the mix in raw 256-bit adds
-//   (3 s0 + s1 + s2 < 10p, s0 - s1 + s2 + 4p < 10p, s0 + s1 - 2 s2 + 8p < 14p: all below 32p < 2^256) and one quotient-estimate
-//   reduction per lane (fe_reduce_lazy_2p) - about 650 issue slots of which the two products are 500.
+//   lane 2 += constant (< 3p < 2^253);  square (36 + 8 multiply-adds) and product (72) -> [0, 2p);  the linear layer in raw 256-bit
+//   adds and shifts (everything stays below 32p < 2^256) with two quotient-estimate reductions (fe_reduce_lazy_2p) - see
+//   poseidon_partial_rounds: 116 multiply-adds and ~420 other vector instructions per round.
 #pragma once
 #include "fp.h"
 #include "poseidon_constants.h"
@@ -45,6 +45,36 @@ SP_HD void poseidon_mix(fe& s0, fe& s1, fe& s2) {
     s2 = fe_reduce_lazy_2p(a2);
 }
 
+// a * 2^K as a 256-bit integer (caller guarantees no overflow)
+template <int K>
+SP_HD fe poseidon_shl(const fe& a) {
+    fe r;
+    r.v[0] = a.v[0] << K;
+#pragma unroll
+    for (int i = 1; i < 8; ++i) r.v[i] = (a.v[i] << K) | (a.v[i - 1] >> (32 - K));
+    return r;
+}
+
+// The partial rounds touch lanes 0 and 1 only linearly, and the next round needs of them only their sum: with v = s0 and
+// u = s0 + s1 a round is
+//     c = (s2 + k)^3;   s2 <- u - 2c;   (u, v) <- (4v + 2c, 2v + u + c)
+// (from s0' = t + 2 s0, s1' = t - 2 s1, s2' = t - 3c with t = u + c).  u is recomputed from v and c every round, so it never
+// needs a reduction (u < 12p); v and s2 take one each - 98 instructions of linear work per round instead of 151.
+SP_HD void poseidon_partial_rounds(fe& s0, fe& s1, fe& s2, const fe* rc) {
+    fe v = s0, u = fe_add_raw(s0, s1);                                         // u < 4p
+#pragma unroll 1
+    for (int r = 0; r < POSEIDON_PARTIAL; ++r) {
+        const fe c = poseidon_cube(fe_add_raw(s2, rc[r]));                    // [0, 2p)
+        const fe c2 = fe_add_raw(c, c);                                        // < 4p
+        s2 = fe_reduce_lazy_2p(fe_sub_add_kp(u, c2, 4u));                      // u - 2c + 4p < 16p
+        const fe vn = fe_add_raw(fe_add_raw(poseidon_shl<1>(v), u), c);        // 2v + u + c < 18p
+        u = fe_add_raw(poseidon_shl<2>(v), c2);                                // 4v + 2c < 12p
+        v = fe_reduce_lazy_2p(vn);
+    }
+    s0 = v;
+    s1 = fe_reduce_lazy_2p(fe_sub_add_kp(u, v, 2u));                           // u - v + 2p < 14p
+}
+
 // The Hades permutation on Montgomery-form lanes in [0, 2p); the lanes come back in [0, 2p).
 SP_HD void poseidon_permute(fe& s0, fe& s1, fe& s2) {
     const fe* rc = SP_POSEIDON_RC;
@@ -55,11 +85,8 @@ SP_HD void poseidon_permute(fe& s0, fe& s1, fe& s2) {
         s2 = poseidon_cube(fe_add_raw(s2, rc[2]));
         poseidon_mix(s0, s1, s2);
     }
-#pragma unroll 1
-    for (int r = 0; r < POSEIDON_PARTIAL; ++r, ++rc) {
-        s2 = poseidon_cube(fe_add_raw(s2, rc[0]));
-        poseidon_mix(s0, s1, s2);
-    }
+    poseidon_partial_rounds(s0, s1, s2, rc);
+    rc += POSEIDON_PARTIAL;
 #pragma unroll 1
     for (int r = 0; r < POSEIDON_FULL_HALF; ++r, rc += 3) {
         s0 = poseidon_cube(fe_add_raw(s0, rc[0]));
