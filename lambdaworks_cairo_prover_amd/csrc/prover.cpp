@@ -22,11 +22,9 @@ StarkProver::~StarkProver() {
     arena_ = nullptr; arena_cap_ = 0;
     c_->prover_device_bytes = 0;
     for (auto& e : ev_dma_) if (e) (void)hipEventDestroy(e);
-    for (auto& e : ev_r2c_) if (e) (void)hipEventDestroy(e);
     for (auto& u : up_ev_) for (hipEvent_t e : {u.dma0, u.dma1, u.ready, u.done}) if (e) (void)hipEventDestroy(e);
     if (up_start_) (void)hipEventDestroy(up_start_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
-    if (r2c_stream_) (void)hipStreamDestroy(r2c_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
@@ -61,7 +59,6 @@ void StarkProver::free_all() {
     (void)hipSetDevice(c_->device);
     (void)hipStreamSynchronize(c_->stream);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
-    if (r2c_stream_) (void)hipStreamSynchronize(r2c_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
@@ -193,8 +190,8 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     measuring_ = false;
     SP_TRY(rc_measure);
     {
-        // room for what a Cairo proof allocates on first use (auxiliary-trace workspace, side-stream inverses, upload landing
-        // ring is part of the scratch): those allocations find their place in the arena too instead of costing a hipMalloc each
+        // room for what a Cairo proof allocates on first use (auxiliary-trace workspace, side-stream inverses): those allocations find
+        // their place in the arena too instead of costing a hipMalloc each
         size_t sort_tmp = 0;
         const uint64_t lazy = (Ca_ == 18 ? aux_workspace_bytes(n_, 4096, &sort_tmp) : 0) + sizeof(fe) * 19 * n_ + (4u << 20);
         const uint64_t need = measured_ + lazy;
@@ -254,7 +251,6 @@ void StarkProver::release(void* p, size_t bytes) {
     (void)hipStreamSynchronize(c_->stream);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
-    if (r2c_stream_) (void)hipStreamSynchronize(r2c_stream_);
     auto it = std::find(allocs_.begin(), allocs_.end(), p);
     if (it == allocs_.end()) return;     // carved out of the arena: the space comes back with the next setup()
     allocs_.erase(it);
@@ -435,7 +431,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
     if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20))
-        return commit_trace_pipelined(segment, rows_host, cols, root_out);   // (the landing ring of the chunks lives in the scratch area)
+        return commit_trace_pipelined(segment, rows_host, cols, root_out);
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));

@@ -130,9 +130,8 @@ class StarkProver : public sp_deletable {
     int ensure_upload(uint32_t groups);
     int finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind);
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
-    hipStream_t r2c_stream_ = nullptr;                        // rows -> columns of the landed chunks (keeps the DMAs back to back)
     static constexpr int UPLOAD_SLOTS = 4;                    // ring of chunk slots: the gather may run three chunks ahead of the DMA
-    hipEvent_t ev_dma_[UPLOAD_SLOTS] = {}, ev_r2c_[UPLOAD_SLOTS] = {};
+    hipEvent_t ev_dma_[UPLOAD_SLOTS] = {};
     void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging ring, one chunk (<= 32 MB) each
     HostPool* pool_ = nullptr;
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the

@@ -14,21 +14,20 @@ namespace sp {
 int StarkProver::ensure_upload(uint32_t groups) {
     if (groups > (uint32_t)UPLOAD_MAX_GROUPS) { sp_set_error("commit_trace: too many column groups"); return SP_E_UNSUPPORTED; }
     if (!copy_stream_) {
-        // highest priority: the little kernels of the upload (rows -> columns, decode, the pull copy) must not queue behind the
-        // thousands of work-groups of the transforms they feed (a kernel after every copy on an ordinary stream: 24 GB/s
-        // instead of 56, tools/experiments/dma_pattern_probe.hip)
+        // A stream for the DMAs alone (highest priority; the optional pull copy of SP_UPLOAD_PULL is the only kernel it ever sees).
+        // Kernels do NOT belong here: rows -> columns / decode kernels on a highest-priority stream made the transforms running beside
+        // them 1.3 - 2.2 x slower for as long as the upload lasted (far more than their own run time; tools/upload_interference.py),
+        // and on an ordinary second stream they queued behind the transforms and stalled the ring (24 GB/s).
         int prio_lo = 0, prio_hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         SP_HIP_CHECK(hipStreamCreateWithPriority(&copy_stream_, hipStreamNonBlocking, prio_hi));
-        SP_HIP_CHECK(hipStreamCreateWithPriority(&r2c_stream_, hipStreamNonBlocking, prio_hi));
-        for (int i = 0; i < UPLOAD_SLOTS; ++i) { SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming)); SP_HIP_CHECK(hipEventCreateWithFlags(&ev_r2c_[i], hipEventDisableTiming)); }
+        for (int i = 0; i < UPLOAD_SLOTS; ++i) SP_HIP_CHECK(hipEventCreateWithFlags(&ev_dma_[i], hipEventDisableTiming));
     }
     if (!up_start_) SP_HIP_CHECK(hipEventCreate(&up_start_));
     for (uint32_t g = 0; g < groups; ++g)
         for (hipEvent_t* e : {&up_ev_[g].dma0, &up_ev_[g].dma1, &up_ev_[g].ready, &up_ev_[g].done})
             if (!*e) SP_HIP_CHECK(hipEventCreate(e));
     SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));   // (nothing pending unless an earlier call failed half-way)
-    if (r2c_stream_) SP_HIP_CHECK(hipStreamSynchronize(r2c_stream_));
     return SP_OK;
 }
 
@@ -102,9 +101,11 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
             for (uint32_t j = 0; j < w; ++j) SP_TRY(h2d(dst + (uint64_t)j * n_, cols_host + (size_t)(c0 + j) * col_stride * 32, (size_t)n_ * 32));
         }
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        if (col_enc >= 0) SP_TRY(decode_elements(copy_stream_, col_enc, reinterpret_cast<const uint8_t*>(dst), (uint64_t)w * n_, dst));   // element-wise, in place
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
         SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
+        // element-wise, in place, on the compute stream in front of the group's transforms (kernels on the highest-priority copy stream
+        // slow the transforms running beside them far more than their own run time: tools/upload_interference.py)
+        if (col_enc >= 0) SP_TRY(decode_elements(c_->stream, col_enc, reinterpret_cast<const uint8_t*>(dst), (uint64_t)w * n_, dst));
         if (!sharded_interp) {
             // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
             SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, dst));
@@ -198,23 +199,29 @@ void host_pool_delete(HostPool* p) { delete p; }
 // dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace.  The rows are handed
 // out in blocks through a shared counter, so a thread that is slow (a busy core, a remote NUMA node, a throttled container)
 // takes fewer blocks instead of holding the whole group back.
-static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, size_t width, uint8_t* dst) {
-    const uint64_t block = std::max<uint64_t>(256, (256u << 10) / width);   // ~256 KB written per block
-    std::atomic<uint64_t> next{0};
-    pool.run([&](unsigned, unsigned) {
-        for (;;) {
-            const uint64_t r0 = next.fetch_add(block, std::memory_order_relaxed);
-            if (r0 >= n) return;
-            const uint64_t r1 = std::min<uint64_t>(n, r0 + block);
-            const uint8_t* s = src + r0 * row_bytes + off;
-            uint8_t* d = dst + r0 * width;
-            // fixed-size 32-byte copies inline as vector moves (a libc memcpy call per row costs more than the bytes it moves on
-            // narrow groups)
-            const size_t units = width / 32;
-            for (uint64_t i = r0; i < r1; ++i, s += row_bytes, d += width)
-                for (size_t u = 0; u < units; ++u) __builtin_memcpy(d + 32 * u, s + 32 * u, 32);
+// One block of a chunk: rows [r0, r1) of the chunk (src points at the chunk's first row), columns [off/32, off/32 + cw) of the table,
+// written column-major into the chunk's ring slot (column j at dst + j * n * 32: every column of a chunk is one contiguous DMA
+// straight into the trace area).
+// The reads are one or two cache lines out of every row (a stride of cols x 32 bytes: beyond what the hardware prefetchers follow),
+// so the rows PF_ROWS ahead are requested by hand - 16 -> 31-34 GB/s on eight threads of the build container; two rows at a time,
+// so that every store run is one whole 64-byte line (+5-10 %; gather microbenchmark, tools/experiments/README.md).
+static void host_gather_block(const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, uint32_t cw, uint8_t* dst, uint64_t r0, uint64_t r1) {
+    constexpr size_t PF_ROWS = 24;
+    const uint8_t* s = src + r0 * row_bytes + off;
+    uint64_t i = r0;
+    for (; i + 2 <= r1; i += 2, s += 2 * row_bytes) {
+        for (uint32_t l = 0; l < cw * 32; l += 64) {
+            __builtin_prefetch(s + PF_ROWS * row_bytes + l, 0, 0);
+            __builtin_prefetch(s + (PF_ROWS + 1) * row_bytes + l, 0, 0);
         }
-    });
+        for (uint32_t u = 0; u < cw; ++u) {
+            uint8_t* d = dst + ((size_t)u * n + i) * 32;
+            __builtin_memcpy(d, s + 32 * (size_t)u, 32);              // (fixed-size copies inline as vector moves)
+            __builtin_memcpy(d + 32, s + row_bytes + 32 * (size_t)u, 32);
+        }
+    }
+    for (; i < r1; ++i, s += row_bytes)
+        for (uint32_t u = 0; u < cw; ++u) __builtin_memcpy(dst + ((size_t)u * n + i) * 32, s + 32 * (size_t)u, 32);
 }
 
 // interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
@@ -225,18 +232,13 @@ static void host_gather_columns(HostPool& pool, const uint8_t* src, uint64_t n, 
 // first proof at 2^20 rows).
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
-    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything
-    // behind it still has to be transformed (~0.7 ms per column; 0.2 ms at blowup 4, where the upload is the bound): two single
-    // columns start the pipeline, then groups of two or four columns, always from an even column on (two columns share a 64-byte
-    // line of a row).
-    // How wide may a group get?  A group is usable when all of it has landed, so with the transforms as the bound (blowup 8: 0.70
-    // ms per column against 0.65 ms of upload) narrow groups keep the compute stream fed - two columns: 75.0 ms where eight-column
-    // groups gave 80 - and with the upload as the bound (blowup 4: 0.18 ms of transforms per column) the gather's throughput
-    // decides, which grows with the width (two columns ~40 GB/s, four ~55, eight ~60): four columns.
-    const double transform_ms_per_col = (1.0 + (double)(1u << logb_)) * (double)n_ * logn_ / 2 / 1.35e11 * 1e3;
-    const double upload_ms_per_col = (double)n_ * 32 / 50e9 * 1e3;
+    // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything behind
+    // it still has to be transformed (~0.7 ms per column at blowup 8, 0.2 ms at blowup 4, where the upload is the bound): two single
+    // columns start the pipeline, then pairs, always from an even column on (two columns share a 64-byte line of a row).  A group is
+    // usable when all of it has landed, so narrow groups keep the compute stream fed; and since the gather writes a chunk column by
+    // column (host_gather_block) wider groups no longer stream better either - four-column groups: 30.1 ms at config #4, pairs 29.3.
     static const uint32_t maxw_env = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 0u; }();
-    const uint32_t maxw = maxw_env ? maxw_env : (transform_ms_per_col >= 0.9 * upload_ms_per_col ? 2u : 4u);
+    const uint32_t maxw = maxw_env ? maxw_env : 2u;
     std::vector<uint32_t> gsize;
     for (uint32_t done = 0; done < cols;) {
         uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done + 1) / 2)));
@@ -245,9 +247,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         done += w;
     }
     const uint32_t groups = (uint32_t)gsize.size();
-    // chunk size: 32 MB, less when the scratch area (the landing ring on the device) is small
-    size_t chunk = std::min<size_t>((size_t)32 << 20, (scratch_elems() * sizeof(fe) / UPLOAD_SLOTS) & ~(size_t)4095);
-    if (chunk < (size_t)64 * 256) { sp_set_error("commit_trace: scratch too small for the upload pipeline"); return SP_E_ALLOC; }
+    const size_t chunk = (size_t)32 << 20;   // bytes per ring slot
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
     // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
@@ -262,66 +262,111 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
         stage_bytes_ = chunk;
     }
-    uint8_t* landing[UPLOAD_SLOTS];
-    for (int i = 0; i < UPLOAD_SLOTS; ++i) landing[i] = reinterpret_cast<uint8_t*>(d_scratch_) + (size_t)i * chunk;
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     SP_TIMEPOINT("  upload: threads, streams, pinned slots");
-    const double t0 = wall_ms();
-    double gather_ms = 0;
-    struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
-    pool_->begin_burst();
-    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the scratch and trace areas' previous users are behind this point
-    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
-    SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, up_start_, 0));
-    uint64_t chunk_no = 0;
-    uint32_t c0 = 0;
-    for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
-        const uint32_t w = gsize[g];
-        const double tg = wall_ms();
-        double waited = 0;
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma0, copy_stream_));
-        {   // the group in blocks of rows: whole rows of the group (w x 32 contiguous bytes each: the wider, the better the gather
-            // streams - 2 columns move ~40 GB/s, 8 columns ~58) and at most one ring slot of them at a time
-            const uint32_t cw = w, c = c0;
+    // The chunks of the whole segment, in upload order: a block of rows of one column group, one ring slot (32 MB) at most; the
+    // gather reads w x 32 contiguous bytes of every row (the wider the group, the better it streams).
+    struct Chunk { uint32_t g, c, cw, slot; uint64_t r0, rows, first_block, blocks; bool last_of_group; };
+    std::vector<Chunk> chunks;
+    uint64_t n_blocks = 0;
+    {
+        uint32_t c = 0;
+        for (uint32_t g = 0; g < groups; c += gsize[g], ++g) {
+            const uint32_t cw = gsize[g];
             const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk / ((size_t)cw * 32)) & ~(uint64_t)255);
-            for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk, ++chunk_no) {
+            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)cw * 32)) & ~(uint64_t)1;   // ~256 KB written per block
+            for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
-                const uint32_t slot = (uint32_t)(chunk_no % UPLOAD_SLOTS);
-                const double tw = wall_ms();
-                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipEventSynchronize(ev_dma_[slot]));   // the pinned slot has crossed PCIe
-                waited += wall_ms() - tw;
-                host_gather_columns(*pool_, rows_host + r0 * (size_t)cols * 32, rows, (size_t)cols * 32, (size_t)c * 32, (size_t)cw * 32,
-                                    static_cast<uint8_t*>(h_stage_[slot]));
-                // copy and rows -> columns both on the copy stream: the landing slot is free again as soon as the chunk has been
-                // turned into columns, whatever the compute stream is busy with (queued behind the previous group's LDE the
-                // upload stalled for ~3 ms twice per proof: profiles/r02_host_path_timeline.txt)
-                if (chunk_no >= UPLOAD_SLOTS) SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, ev_r2c_[slot], 0));   // the landing slot has been turned into columns
-                // (no "one copy in flight" wait here, unlike commit_trace_columns: a chunk's DMA is enqueued after a gather that took
-                // about as long as the previous DMA, so the engine is mostly idle by then, and blocking this thread delays the next
-                // gather - 38.5 against 35 ms at config #4 on a slow host)
-                SP_HIP_CHECK(hipMemcpyAsync(landing[slot], h_stage_[slot], (size_t)rows * cw * 32, hipMemcpyHostToDevice, copy_stream_));
-                SP_HIP_CHECK(hipEventRecord(ev_dma_[slot], copy_stream_));
-                // rows -> columns on a stream of its own: on the copy stream the DMA engine sat idle through every one of these
-                // kernels (~50 us x 34 chunks per proof); on the compute stream they queued behind the previous group's LDE
-                SP_HIP_CHECK(hipStreamWaitEvent(r2c_stream_, ev_dma_[slot], 0));
-                SP_TRY(rows_to_columns(r2c_stream_, c_->enc, landing[slot], rows, cw, trace + (uint64_t)c * n_ + r0, n_));
-                SP_HIP_CHECK(hipEventRecord(ev_r2c_[slot], r2c_stream_));
+                const uint64_t blocks = (rows + block_rows - 1) / block_rows;
+                chunks.push_back(Chunk{g, c, cw, (uint32_t)(chunks.size() % UPLOAD_SLOTS), r0, rows, n_blocks, blocks, r0 + rows >= n_});
+                n_blocks += blocks;
             }
         }
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, r2c_stream_));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
-        const double tge = wall_ms();
-        gather_ms += tge - tg - waited;
-        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   group %2u: %u columns, waited %.3f ms for slots, gather + enqueue %.3f ms (%.1f GB/s)\n", g, w, waited,
-                                           tge - tg - waited, (double)n_ * w * 32 / (tge - tg - waited) * 1e-6);
-        // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)c0 * n_));
-        SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
-        SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
     }
+    const size_t n_chunks = chunks.size();
+    std::vector<std::atomic<uint32_t>> blocks_done(n_chunks);
+    for (auto& b : blocks_done) b.store(0, std::memory_order_relaxed);
+    std::atomic<uint64_t> next_block{0};
+    std::atomic<uint64_t> writable{UPLOAD_SLOTS};     // chunks [0, writable) may be gathered: the slot of chunk k is free once chunk k - SLOTS has crossed PCIe
+    std::atomic<bool> abort_upload{false};
+    const double t0 = wall_ms();
+    double gather_end = t0;
+    int rc_upload = SP_OK;
+    struct Burst { HostPool* p; ~Burst() { p->end_burst(); } } burst{pool_};   // (also on the error paths)
+    pool_->begin_burst();
+    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the trace area's previous users are behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma0, copy_stream_));
+    // ONE job for the whole upload, no barrier per chunk: the workers take 256 KB blocks off a shared counter across chunk
+    // boundaries (up to the ring's four slots ahead of the DMA), so a thread that loses its core for a scheduler quantum delays the
+    // one chunk its block belongs to instead of stopping everybody at the end of every chunk - on the shared hosts of the test
+    // boxes a barrier every 0.7 ms met a descheduled thread most of the time.  The calling thread does not gather: it enqueues
+    // the DMAs of a chunk when its last block is in, the group's transforms behind the last chunk of a group, and hands slots
+    // back when their DMA has completed.
+    auto orchestrate = [&]() -> int {
+        size_t k = 0, d = 0;   // next chunk to send, next chunk whose DMA completion is awaited
+        while (k < n_chunks) {
+            bool progress = false;
+            if (d < k && hipEventQuery(ev_dma_[chunks[d].slot]) == hipSuccess) {
+                ++d;
+                writable.store(d + UPLOAD_SLOTS, std::memory_order_release);
+                progress = true;
+            }
+            const Chunk& ck = chunks[k];
+            if (blocks_done[k].load(std::memory_order_acquire) == ck.blocks) {
+                uint8_t* slot = static_cast<uint8_t*>(h_stage_[ck.slot]);
+                for (uint32_t j = 0; j < ck.cw; ++j)   // column by column, straight into the trace area (host encoding; decoded in place below)
+                    SP_HIP_CHECK(hipMemcpyAsync(trace + (uint64_t)(ck.c + j) * n_ + ck.r0, slot + (size_t)j * ck.rows * 32, (size_t)ck.rows * 32, hipMemcpyHostToDevice, copy_stream_));
+                SP_HIP_CHECK(hipEventRecord(ev_dma_[ck.slot], copy_stream_));
+                if (ck.last_of_group) {
+                    const uint32_t g = ck.g, w = ck.cw, gc0 = ck.c;
+                    SP_HIP_CHECK(hipEventRecord(up_ev_[g].dma1, copy_stream_));
+                    SP_HIP_CHECK(hipEventRecord(up_ev_[g].ready, copy_stream_));
+                    if (g + 1 < groups) SP_HIP_CHECK(hipEventRecord(up_ev_[g + 1].dma0, copy_stream_));
+                    SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[g].ready, 0));
+                    // host encoding -> device layout, in place, in front of the group's transforms on the compute stream (an ordinary
+                    // kernel of the proof: the rows -> columns kernels this replaces ran on a highest-priority stream beside the
+                    // transforms and made those 1.3 - 2.2 x slower for as long as the upload lasted - tools/upload_interference.py)
+                    SP_TRY(decode_elements(c_->stream, c_->enc, reinterpret_cast<const uint8_t*>(trace + (uint64_t)gc0 * n_), (uint64_t)w * n_, trace + (uint64_t)gc0 * n_));
+                    // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
+                    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)gc0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)gc0 * n_));
+                    SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)gc0 * n_, lde + (uint64_t)gc0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
+                    SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
+                }
+                if (++k == n_chunks) gather_end = wall_ms();
+                progress = true;
+            }
+            if (!progress) __builtin_ia32_pause();
+        }
+        return SP_OK;
+    };
+    pool_->run([&](unsigned part, unsigned) {
+        if (part == 0) {
+            rc_upload = orchestrate();
+            if (rc_upload != SP_OK) abort_upload.store(true, std::memory_order_release);
+            return;
+        }
+        size_t k = 0;
+        for (;;) {
+            const uint64_t b = next_block.fetch_add(1, std::memory_order_relaxed);
+            if (b >= n_blocks) return;
+            while (b >= chunks[k].first_block + chunks[k].blocks) ++k;
+            const Chunk& ck = chunks[k];
+            for (unsigned spin = 0; k >= writable.load(std::memory_order_acquire); ++spin) {   // the slot is still crossing PCIe
+                if (abort_upload.load(std::memory_order_acquire)) return;
+                if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
+            }
+            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)ck.cw * 32)) & ~(uint64_t)1;
+            const uint64_t br0 = (b - ck.first_block) * block_rows;
+            host_gather_block(rows_host + ck.r0 * (size_t)cols * 32, ck.rows, (size_t)cols * 32, (size_t)ck.c * 32, ck.cw, static_cast<uint8_t*>(h_stage_[ck.slot]),
+                              br0, std::min<uint64_t>(ck.rows, br0 + block_rows));
+            blocks_done[k].fetch_add(1, std::memory_order_acq_rel);
+        }
+    });
+    if (rc_upload != SP_OK) return rc_upload;
+    const double gather_ms = gather_end - t0;
     const double host_ms = wall_ms() - t0;
     SP_TIMEPOINT("  upload + transforms of the groups");
     if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream

@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""Where a proof from the reference's row-major host table (sp_cairo_prove) loses time against the resident one: per call the wall
+time, the device time of each round and the upload statistics, resident and row-major calls interleaved.
+usage: rows_path_rounds.py [fib=149000] [blowup=8] [iterations=6]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+torch.cuda.init()
+from lambdaworks_cairo_prover_amd import api
+fib = int(sys.argv[1]) if len(sys.argv) > 1 else 149000
+b = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+iters = int(sys.argv[3]) if len(sys.argv) > 3 else 6
+ctx = api.Context()
+run = api.CairoRun.fibonacci(fib); tr = run.main_trace()
+opt = api.ProofOptions(b, 80, 3, 20)
+dev = torch.from_numpy(tr).cuda(); torch.cuda.synchronize()
+for _ in range(3):
+    ctx.cairo_prove(tr, run.public_inputs_c, opt)
+    ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt)
+la = os.getloadavg()
+print(f"host: {api.host_cpus()} usable CPUs, load average {la[0]:.1f} {la[1]:.1f} (of {os.cpu_count()} hardware threads)")
+for it in range(iters):
+    t0 = time.perf_counter(); ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt); td = 1e3 * (time.perf_counter() - t0)
+    rd = ctx.last_round_ms()
+    t0 = time.perf_counter(); ctx.cairo_prove(tr, run.public_inputs_c, opt); th = 1e3 * (time.perf_counter() - t0)
+    rh = ctx.last_round_ms(); s = ctx.last_upload_stats()
+    print(f"[{it}] resident {td:6.1f} ms rounds {['%.1f' % x for x in rd[1:]]}   rows {th:6.1f} ms rounds {['%.1f' % x for x in rh[1:]]}   "
+          f"gather {s['gather_gbs']} GB/s dma {s['dma_gbs']} exposed {s['exposed_ms']} max stall {s['max_stall_ms']} host loop {s['host_ms']} ms", flush=True)
