@@ -344,22 +344,24 @@ SP_HD fe fe_pow_u64(const fe& a, uint64_t e) {
 // p - 2 = 2^251 + 2^196 + (2^192 - 1): a^(2^192 - 1) by the doubling chain 1, 2, 3, 6, 12, 24, 48, 96, 192 (191 squarings,
 // 8 products), then a^(2^192) = that * a, squared 4 times -> a^(2^196), 55 more times -> a^(2^251): 250 squarings and 11
 // products instead of the 251 + 193 of square-and-multiply.
+// (the whole chain runs on lazily reduced values: squares and products of operands below 2p stay below 2p, so the 261 conditional
+// subtractions of the canonical forms are not on the dependent chain - one at the end)
 SP_HD fe fe_sqr_n(fe x, int n) {
-    for (int i = 0; i < n; ++i) x = fe_sqr(x);
+    for (int i = 0; i < n; ++i) x = fe_sqr_lazy(x);
     return x;
 }
 SP_HD fe fe_inv(const fe& a) {
-    const fe x2 = fe_mul(fe_sqr(a), a);                 // a^(2^2 - 1)
-    const fe x3 = fe_mul(fe_sqr(x2), a);                // a^(2^3 - 1)
-    const fe x6 = fe_mul(fe_sqr_n(x3, 3), x3);
-    const fe x12 = fe_mul(fe_sqr_n(x6, 6), x6);
-    const fe x24 = fe_mul(fe_sqr_n(x12, 12), x12);
-    const fe x48 = fe_mul(fe_sqr_n(x24, 24), x24);
-    const fe x96 = fe_mul(fe_sqr_n(x48, 48), x48);
-    const fe x192 = fe_mul(fe_sqr_n(x96, 96), x96);     // a^(2^192 - 1)
-    const fe b = fe_sqr_n(fe_mul(x192, a), 4);          // a^(2^196)
-    const fe c = fe_sqr_n(b, 55);                       // a^(2^251)
-    return fe_mul(fe_mul(c, b), x192);
+    const fe x2 = fe_mul_lazy(fe_sqr_lazy(a), a);           // a^(2^2 - 1)
+    const fe x3 = fe_mul_lazy(fe_sqr_lazy(x2), a);          // a^(2^3 - 1)
+    const fe x6 = fe_mul_lazy(fe_sqr_n(x3, 3), x3);
+    const fe x12 = fe_mul_lazy(fe_sqr_n(x6, 6), x6);
+    const fe x24 = fe_mul_lazy(fe_sqr_n(x12, 12), x12);
+    const fe x48 = fe_mul_lazy(fe_sqr_n(x24, 24), x24);
+    const fe x96 = fe_mul_lazy(fe_sqr_n(x48, 48), x48);
+    const fe x192 = fe_mul_lazy(fe_sqr_n(x96, 96), x96);    // a^(2^192 - 1)
+    const fe b = fe_sqr_n(fe_mul_lazy(x192, a), 4);         // a^(2^196)
+    const fe c = fe_sqr_n(b, 55);                           // a^(2^251)
+    return fe_reduce_once(fe_mul_lazy(fe_mul_lazy(c, b), x192));
 }
 
 // ---- byte codecs ---------------------------------------------------------------------------------------

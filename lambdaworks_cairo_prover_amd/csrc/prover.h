@@ -132,6 +132,7 @@ class StarkProver : public sp_deletable {
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
     static constexpr int UPLOAD_SLOTS = 4;                    // ring of chunk slots: the gather may run three chunks ahead of the DMA
     hipEvent_t ev_dma_[UPLOAD_SLOTS] = {};
+    bool pool_bound_ = false;                                 // the gather workers have been placed (prover_upload.cpp)
     void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging ring, one chunk (<= 32 MB) each
     HostPool* pool_ = nullptr;
     // elements of d_scratch_: inverse arrays and their scratch (<= 7 local LDE columns), OOD folds (>= 4n and the

@@ -8,6 +8,12 @@
 #include <functional>
 #include <mutex>
 #include <thread>
+#include <cctype>
+#include <cstdio>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 namespace sp {
 
@@ -127,6 +133,59 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
     return rc;
 }
 
+// ---- NUMA placement of the gather (two-socket hosts: the table of the caller lives on the node its threads ran on, the page-locked
+// ring always on the GPU's node, so on half of the boxes every byte crosses the socket link inside the gather)
+static std::vector<int> numa_node_cpus(int node) {
+    std::vector<int> cpus;
+    char path[96];
+    std::snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return cpus;
+    char buf[4096] = {0};
+    const bool ok = std::fgets(buf, sizeof(buf), f) != nullptr;
+    std::fclose(f);
+    if (!ok) return cpus;
+    for (char* p = buf; *p;) {   // "0-63,128-191"
+        char* e;
+        const long a = std::strtol(p, &e, 10);
+        if (e == p) break;
+        long b = a;
+        if (*e == '-') { p = e + 1; b = std::strtol(p, &e, 10); }
+        for (long c = a; c <= b && c < 4096; ++c) cpus.push_back((int)c);
+        p = (*e == ',') ? e + 1 : e;
+        if (*e != ',' ) break;
+    }
+    return cpus;
+}
+// the node that holds most of a few sampled pages of [p, p + bytes): move_pages(2) with nodes = NULL only queries; -1 when unknown
+static int numa_node_of_memory(const void* p, size_t bytes) {
+    constexpr int SAMPLES = 16;
+    void* pages[SAMPLES];
+    int status[SAMPLES];
+    const size_t step = std::max<size_t>(4096, (bytes / SAMPLES) & ~(size_t)4095);
+    int count = 0;
+    for (int i = 0; i < SAMPLES && (size_t)i * step < bytes; ++i) pages[count++] = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(p) & ~(uintptr_t)4095) + (size_t)i * step);
+    if (count == 0 || syscall(SYS_move_pages, 0, (unsigned long)count, pages, nullptr, status, 0) != 0) return -1;
+    int votes[8] = {0};
+    for (int i = 0; i < count; ++i) if (status[i] >= 0 && status[i] < 8) ++votes[status[i]];
+    int best = -1, bv = 0;
+    for (int n = 0; n < 8; ++n) if (votes[n] > bv) { bv = votes[n]; best = n; }
+    return best;
+}
+static int numa_node_of_device(int device) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof(bus), device) != hipSuccess) { (void)hipGetLastError(); return -1; }
+    for (char* c = bus; *c; ++c) *c = (char)std::tolower((unsigned char)*c);
+    char path[160];
+    std::snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
 // A few parked host threads for the column gathers of the upload pipeline (creating them per group would put ~5 ms of
 // pthread_create on the critical path of a proof).
 class HostPool {
@@ -140,6 +199,14 @@ class HostPool {
         for (auto& t : threads_) t.join();
     }
     unsigned size() const { return (unsigned)threads_.size() + 1; }
+    // restricts the workers to a set of CPUs (the NUMA node of the upload's source or of the GPU); an empty set lifts the restriction
+    void bind(const std::vector<int>& cpus) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        if (cpus.empty()) { for (int c = 0; c < CPU_SETSIZE; ++c) CPU_SET(c, &set); }
+        else for (int c : cpus) if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+        for (auto& t : threads_) (void)pthread_setaffinity_np(t.native_handle(), sizeof(set), &set);
+    }
     // Between begin_burst() and end_burst() idle workers spin on the generation counter instead of sleeping on the condition
     // variable: the groups of one upload follow each other within a millisecond and a futex wake-up of 30-60 threads costs
     // 50-100 us each time.
@@ -255,6 +322,30 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
     // proofs of a 64-thread gather in a 16-CPU container.
     if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
+    if (!pool_bound_) {
+        // Where the workers run.  The ring is page-locked memory and lives on the GPU's NUMA node; the caller's table lives where
+        // the caller's threads ran.  On the two-socket hosts of the pool half of the boxes have the two on different nodes, and a
+        // gather by threads of the table's node (where the scheduler keeps the process) then moves 35 - 40 GB/s - remote stores -
+        // where threads of the GPU's node move 51 (remote loads, which the software prefetch covers; local stores): 80 against 76.5 ms at
+        // config #3 (tools/rows_path_rounds.py ... far).  With both on one node the binding changes nothing (52 - 56 GB/s).
+        // SP_UPLOAD_BIND=none|table|gpu overrides (default gpu).
+        pool_bound_ = true;
+        const char* bind_env = std::getenv("SP_UPLOAD_BIND");
+        const char mode = bind_env ? bind_env[0] : 'g';
+        const int node_table = numa_node_of_memory(rows_host, (size_t)n_ * cols * 32), node_gpu = numa_node_of_device(c_->device);
+        const int node = mode == 't' ? node_table : (mode == 'g' ? node_gpu : -1);
+        std::vector<int> cpus;
+        if (node >= 0) {
+            cpu_set_t allowed;
+            CPU_ZERO(&allowed);
+            if (sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+                for (int c : numa_node_cpus(node)) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) cpus.push_back(c);
+            if (cpus.size() < pool_->size()) cpus.clear();   // (a cpuset that leaves the node too few CPUs: do not squeeze the workers onto them)
+        }
+        if (timing_enabled()) std::fprintf(stderr, "[sp_timing]   upload: table on NUMA node %d, GPU on node %d, %zu CPUs for the workers%s\n", node_table, node_gpu,
+                                           cpus.size(), cpus.empty() ? " (unbound)" : "");
+        if (!cpus.empty()) pool_->bind(cpus);
+    }
     SP_TRY(ensure_upload(groups));
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
