@@ -620,6 +620,14 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
 
+    # one process per GPU, kept on the CPUs of its GPU's NUMA node (what `numactl --cpunodebind` does for a deployment on these
+    # two-socket hosts): the tables this process builds are then first-touched beside the page-locked staging of the library
+    numa_node = -1
+    if os.environ.get("SP_BENCH_NO_NUMA_BIND") is None:
+        try:
+            numa_node = api.host_bind_to_device(dev_index)
+        except Exception:
+            numa_node = -1
     n = 1 << args.log_n
     # synthetic input: uniformly random residues < 2^251 (< p), written directly in the device layout
     # (8 x u32 little-endian Montgomery limbs) so that the timed region starts with the data resident in HBM.
@@ -677,7 +685,8 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
         "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
                    "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)",
-                   "self_warmup_steps": self_warm, "devices_shared": shared},
+                   "self_warmup_steps": self_warm, "devices_shared": shared,
+                   "host_numa_node": numa_node},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_note,
                      "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,

@@ -70,6 +70,13 @@ int sp_device_count(int* count_out);      /* number of visible HIP devices (0 wi
 /* CPUs the host side of the library may really use: hardware threads cut down by the affinity mask and the cgroup CPU quota
  * (what sizes the gather threads of sp_cairo_prove and the front-end's trace builder). */
 int sp_host_cpus(int* count_out);
+/* NUMA placement on multi-socket hosts: restricts the CALLING THREAD - and every thread it creates afterwards - to the CPUs of the
+ * NUMA node the device hangs off (within the affinity mask it already has), so that the tables a prover process builds are
+ * first-touched on that node: the page-locked staging of the host-buffer entry points lives there, and a table on the other node
+ * crosses the socket link on its way in (sp_cairo_prove from a far table: 37 - 43 GB/s instead of 52 - 56).  The equivalent of
+ * `numactl --cpunodebind=<node of the GPU>`; call it first thing in a one-process-per-GPU prover.  *node_out (nullable): the node,
+ * -1 when it is unknown (single-node host, no sysfs) - nothing is changed then.  Does not initialise a context. */
+int sp_host_bind_to_device(int device, int* node_out);
 
 int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
 void sp_ctx_destroy(sp_ctx* ctx);

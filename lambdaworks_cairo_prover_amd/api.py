@@ -232,6 +232,14 @@ def host_cpus():
     return n.value
 
 
+def host_bind_to_device(device=0):
+    """sp_host_bind_to_device: keep this thread (and the threads it creates from now on) on the CPUs of the GPU's NUMA node; returns
+    the node or -1 when unknown (nothing changed)."""
+    node = ctypes.c_int(-1)
+    check(_lib.load().sp_host_bind_to_device(int(device), ctypes.byref(node)))
+    return node.value
+
+
 def fe_to_device(values_be, fe_encoding=SP_FE_CANON_BE):
     """ABI-encoded (n, 32) array -> device layout bytes (8 x u32 little-endian Montgomery), on the host."""
     a = np.ascontiguousarray(values_be, dtype=np.uint8).reshape(-1, 32)
@@ -570,4 +578,4 @@ Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND",
-            "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host"]
+            "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device"]

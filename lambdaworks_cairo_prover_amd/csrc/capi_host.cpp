@@ -34,7 +34,7 @@ int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, 
                     const std::vector<std::array<uint16_t, 3>>& ops, const std::vector<fe>& consts, uint32_t n_rap,
                     const std::vector<BoundaryConstraint>& boundary, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding);
 }
-namespace sp { void set_verify_merkle_backend(int backend); }
+namespace sp { void set_verify_merkle_backend(int backend); int host_bind_calling_thread_to_device_node(int device, int* node_out); }
 namespace sp { int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding); }
 
 namespace sp {
@@ -63,6 +63,10 @@ const char* sp_version(void) { return "stark252-hip 0.3 (gfx950)"; }
 int sp_abi_version(void) { return SP_ABI_VERSION; }
 uint64_t sp_air_desc_size(void) { return sizeof(sp_air_desc); }
 const char* sp_last_error(void) { return g_last_error.c_str(); }
+int sp_host_bind_to_device(int device, int* node_out) {
+    if (device < 0) return SP_E_INVALID_ARG;
+    return sp::host_bind_calling_thread_to_device_node(device, node_out);
+}
 int sp_host_cpus(int* count_out) {
     if (!count_out) return SP_E_INVALID_ARG;
     *count_out = (int)sp::host_effective_cpus();

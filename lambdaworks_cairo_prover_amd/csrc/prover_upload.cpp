@@ -186,6 +186,21 @@ static int numa_node_of_device(int device) {
     return node;
 }
 
+// sp_host_bind_to_device (include/stark252_hip.h)
+int host_bind_calling_thread_to_device_node(int device, int* node_out) {
+    const int node = numa_node_of_device(device);
+    if (node_out) *node_out = -1;
+    if (node < 0) return SP_OK;
+    cpu_set_t allowed, want;
+    CPU_ZERO(&allowed); CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0) return SP_OK;
+    int count = 0;
+    for (int c : numa_node_cpus(node)) if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed)) { CPU_SET(c, &want); ++count; }
+    if (count == 0 || sched_setaffinity(0, sizeof(want), &want) != 0) return SP_OK;
+    if (node_out) *node_out = node;
+    return SP_OK;
+}
+
 // A few parked host threads for the column gathers of the upload pipeline (creating them per group would put ~5 ms of
 // pthread_create on the critical path of a proof).
 class HostPool {

@@ -112,3 +112,8 @@ def test_host_side_helpers_of_round_3(hip_lib):
     hip_lib.sp_device_count(ctypes.byref(count))
     if count.value == 0:
         assert not pinned
+        # no device: the NUMA helper changes nothing and says so
+        before = os.sched_getaffinity(0)
+        assert api.host_bind_to_device(0) == -1 and os.sched_getaffinity(0) == before
+    assert hip_lib.sp_host_bind_to_device(-1, None) == _lib.SP_E_INVALID_ARG
+    assert api.poseidon_host(2, [0]) == api.poseidon_host(3, [0, 0, 1])[0]     # hash_single(x) = permute(x, 0, 1)[0]
