@@ -158,6 +158,23 @@ def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
     assert hip_ctx.cairo_prove_columns(wide, n, c, run.public_inputs_c, opt, col_stride=n + 64, device_layout=True) == want
 
 
+def test_lambdaworks_limbs_through_the_upload_pipeline(hip_lib, oracle):
+    """A context in the SP_FE_MONT_LIMBS encoding (the in-memory layout of lambdaworks' FieldElement - what a Rust shim passes): the
+    row-major table through the upload pipeline (host threads transpose the raw limbs, the device decodes each column pair in place)
+    and host columns in that encoding give the oracle's bytes."""
+    run = api.CairoRun.fibonacci(9000)          # 2^16 rows: above the threshold of the pipeline
+    opt = api.ProofOptions(4, 5, 3, 8)
+    want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, (4, 5, 3, 8))
+    trace_lw = run.main_trace(fe_encoding=api.SP_FE_MONT_LIMBS)
+    with api.Context(device=0, fe_encoding=api.SP_FE_MONT_LIMBS) as ctx:
+        assert ctx.cairo_prove(trace_lw, run.public_inputs_c, opt) == want
+        st = ctx.last_upload_stats()
+        assert st["kind"].startswith("row-major") and st["groups"] > 3
+        cols_lw = np.ascontiguousarray(trace_lw.transpose(1, 0, 2))
+        assert ctx.cairo_prove_columns(cols_lw, run.n_rows, run.n_cols, run.public_inputs_c, opt) == want
+        assert ctx.cairo_prove_run(run, opt) == want
+
+
 def test_dropin_golden_on_device(hip_ctx):
     """The device prover on every reference-generated proof file of tests/golden/dropin/ (README there): same bytes."""
     from test_oracle_golden import dropin_files, parse_proof_file, run_from_proof_file
