@@ -25,6 +25,15 @@ int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint
 // Same, but the n_leaves digests go to a plain array (coset-sharded commitment: leaves are exchanged before the tree is built).
 int merkle_hash_leaves_flat(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* leaves_out,
                             LdeOrder order = LdeOrder{0, 0, 0}, MerkleHash mh = MerkleHash::KECCAK256);
+// Keccak leaf hashing in two launches, for commitments whose columns arrive over PCIe: the head absorbs the first MK_HEAD_COLS = 17
+// columns - 4 x 136 bytes, whole blocks of the sponge - as soon as they exist and leaves every leaf's 25-word state in `state`
+// (word k of leaf i at state[k * n_leaves + i]); the tail continues with the other ncols - 17 columns, pads and writes the leaf
+// digests where merkle_hash_leaves would.  Same digests as the one-launch form; supported for the row widths merkle_split_supported says.
+constexpr uint32_t MK_HEAD_COLS = 17;
+inline bool merkle_split_supported(uint32_t ncols) { return ncols == 34 || ncols == 43; }
+int merkle_hash_leaves_head(hipStream_t st, const fe* cols, uint64_t col_stride, uint64_t n_leaves, uint64_t* state, LdeOrder order);
+int merkle_hash_leaves_tail(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, const uint64_t* state, digest32* nodes,
+                            LdeOrder order);
 // The Fiat-Shamir step that follows a FRI layer's commitment (fri/mod.rs:45-50: append the root, sample zeta), done by the
 // launch that produces the root so that the layers of the commit phase follow each other without a host round trip.
 // DefaultTranscript after a challenge holds the 32 reversed digest bytes r; append(root) makes it r || root, one 64-byte

@@ -96,6 +96,35 @@ __global__ void __launch_bounds__(MK_THREADS) leaf_hash_fixed_kernel(const fe* c
     leaves_out[i] = d;
 }
 
+// the two-launch form (merkle.h): 17 columns are exactly four blocks, so the tail starts at sponge position 0 like a fresh row
+__global__ void __launch_bounds__(MK_THREADS) leaf_hash_head_kernel(const fe* cols, uint64_t col_stride, uint64_t n_leaves, uint64_t* state, LdeOrder order) {
+    uint64_t i = (uint64_t)blockIdx.x * MK_THREADS + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = 0;
+    absorb_columns<0, MK_HEAD_COLS>(s, cols + order.at(i), col_stride);
+#pragma unroll
+    for (int k = 0; k < 25; ++k) state[(uint64_t)k * n_leaves + i] = s[k];
+}
+template <uint32_t NREST>
+__global__ void __launch_bounds__(MK_THREADS) leaf_hash_tail_kernel(const fe* cols_rest, uint64_t col_stride, uint64_t n_leaves, const uint64_t* state,
+                                                                    digest32* leaves_out, LdeOrder order) {
+    uint64_t i = (uint64_t)blockIdx.x * MK_THREADS + threadIdx.x;
+    if (i >= n_leaves) return;
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = state[(uint64_t)k * n_leaves + i];
+    absorb_columns<0, NREST>(s, cols_rest + order.at(i), col_stride);
+    constexpr uint32_t tail = (4u * NREST) % 17u;
+    s[tail] ^= 0x01ULL;
+    s[16] ^= 0x8000000000000000ULL;
+    sp_keccak_f1600_dev(s);
+    digest32 d;
+    d.w[0] = s[0]; d.w[1] = s[1]; d.w[2] = s[2]; d.w[3] = s[3];
+    leaves_out[i] = d;
+}
+
 static bool launch_leaf_hash(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, digest32* out, LdeOrder order) {
     const dim3 grid((unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS)), block(MK_THREADS);
     switch (ncols) {
@@ -356,6 +385,24 @@ int merkle_hash_leaves(hipStream_t st, const fe* cols, uint64_t col_stride, uint
     unsigned blocks = (unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS);
     if (!launch_leaf_hash(st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order))
         hipLaunchKernelGGL(leaf_hash_kernel, dim3(blocks), dim3(MK_THREADS), 0, st, cols, col_stride, ncols, n_leaves, nodes + (n_leaves - 1), order);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
+int merkle_hash_leaves_head(hipStream_t st, const fe* cols, uint64_t col_stride, uint64_t n_leaves, uint64_t* state, LdeOrder order) {
+    if (n_leaves == 0 || !state) return SP_E_INVALID_ARG;
+    hipLaunchKernelGGL(leaf_hash_head_kernel, dim3((unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS)), dim3(MK_THREADS), 0, st, cols, col_stride, n_leaves, state, order);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int merkle_hash_leaves_tail(hipStream_t st, const fe* cols, uint64_t col_stride, uint32_t ncols, uint64_t n_leaves, const uint64_t* state, digest32* nodes,
+                            LdeOrder order) {
+    if (n_leaves == 0 || (n_leaves & (n_leaves - 1)) || !state || !merkle_split_supported(ncols)) return SP_E_INVALID_ARG;
+    const dim3 grid((unsigned)((n_leaves + MK_THREADS - 1) / MK_THREADS)), block(MK_THREADS);
+    const fe* rest = cols + (uint64_t)MK_HEAD_COLS * col_stride;
+    digest32* out = nodes + (n_leaves - 1);
+    if (ncols == 34) hipLaunchKernelGGL(leaf_hash_tail_kernel<17>, grid, block, 0, st, rest, col_stride, n_leaves, state, out, order);
+    else hipLaunchKernelGGL(leaf_hash_tail_kernel<26>, grid, block, 0, st, rest, col_stride, n_leaves, state, out, order);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
 }

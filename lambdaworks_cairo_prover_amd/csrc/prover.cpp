@@ -399,7 +399,12 @@ int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t 
 int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32],
                               bool single_element_tree) {
     const MerkleHash mh = merkle_hash(single_element_tree);
+    const bool head_done = leaf_head_done_;
+    leaf_head_done_ = false;
     if (tree.top == tree.sub) {   // the whole tree on this rank
+        if (head_done && mh == MerkleHash::KECCAK256 && merkle_split_supported(ncols))   // the first 17 columns were absorbed while the rest uploaded
+            SP_TRY(merkle_hash_leaves_tail(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<const uint64_t*>(d_scratch_), tree.sub, order));
+        else
         SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, L, tree.sub, order, mh));
         SP_TRY(merkle_reduce(c_->stream, tree.sub, L, nullptr, mh));
     } else {
@@ -424,6 +429,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     for (double& x : c_->upload_stats) x = 0.0;
+    leaf_head_done_ = false;
     if (src == TRACE_HOST_COLUMNS) {
         if (col_enc >= 0 && col_enc != SP_FE_MONT_LIMBS && col_enc != SP_FE_CANON_BE) return SP_E_INVALID_ARG;
         if (col_stride && col_stride < n_) return SP_E_INVALID_ARG;

@@ -132,6 +132,10 @@ class StarkProver : public sp_deletable {
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
     static constexpr int UPLOAD_SLOTS = 4;                    // ring of chunk slots: the gather may run three chunks ahead of the DMA
     hipEvent_t ev_dma_[UPLOAD_SLOTS] = {};
+    // Two-launch leaf hashing of an uploaded segment (merkle.h): the head over the first 17 columns has run (state in d_scratch_)
+    bool leaf_head_done_ = false;
+    // decides it for a segment of `cols` columns that arrives over PCIe and launches the head once `cols_extended` >= 17 of them exist
+    int maybe_leaf_head(uint32_t cols, uint32_t cols_extended, const fe* lde);
     bool pool_bound_ = false;                                 // the gather workers have been placed (prover_upload.cpp)
     void* h_stage_[UPLOAD_SLOTS] = {}; size_t stage_bytes_ = 0;   // pinned staging ring, one chunk (<= 32 MB) each
     HostPool* pool_ = nullptr;

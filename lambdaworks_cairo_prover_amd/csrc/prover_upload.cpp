@@ -37,6 +37,25 @@ int StarkProver::ensure_upload(uint32_t groups) {
     return SP_OK;
 }
 
+// Leaf hashing beside an upload that bounds round 1.  When the columns arrive slower than they are transformed (blowup 2 and 4: 0.34
+// ms of PCIe per column of 2^19 rows against 0.18 ms of transforms), everything after the last column - its transforms, then ALL of
+// the leaf hashing - is exposed.  The first 17 columns are whole blocks of the Keccak sponge: their 4 of the 9 permutations per leaf
+// run as soon as those columns are extended, in the gaps the compute stream has anyway, and the commitment continues from the
+// saved states (25 words per leaf in the scratch area, free in round 1).  Not when the transforms are the bound (blowup 8 and up):
+// the GPU is busy throughout and the 400 bytes per leaf of state traffic would only add to it.
+int StarkProver::maybe_leaf_head(uint32_t cols, uint32_t cols_extended, const fe* lde) {
+    if (leaf_head_done_ || cols_extended < MK_HEAD_COLS || G_ != 1 || !merkle_split_supported(cols)) return SP_OK;
+    if (c_->opt_merkle_backend != SP_MERKLE_KECCAK256) return SP_OK;
+    static const bool off = std::getenv("SP_NO_SPLIT_HASH") != nullptr;
+    const double transform_ms_per_col = (1.0 + (double)(1u << logb_)) * (double)n_ * logn_ / 2 / 1.35e11 * 1e3;
+    const double upload_ms_per_col = (double)n_ * 32 / 50e9 * 1e3;
+    if (off || transform_ms_per_col >= 0.9 * upload_ms_per_col) return SP_OK;
+    if ((uint64_t)Nl_ * 25 * sizeof(uint64_t) > scratch_elems() * sizeof(fe)) return SP_OK;
+    SP_TRY(merkle_hash_leaves_head(c_->stream, lde, Nl_, Nl_, reinterpret_cast<uint64_t*>(d_scratch_), lde_order()));
+    leaf_head_done_ = true;
+    return SP_OK;
+}
+
 // After the commitment's read-back (every event has completed): what the upload cost and how long the compute stream waited
 // for it.  kind 1: gathered from a row-major host buffer, 2: DMA of host columns.
 int StarkProver::finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind) {
@@ -116,6 +135,7 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
             // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
             SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)c0 * n_, (int)logn_, w, n_, d_t1_, dst));
             SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)c0 * n_, lde + (uint64_t)c0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, (int)logG_, (int)rank_));
+            if (segment == 0) SP_TRY(maybe_leaf_head(cols, c0 + w, lde));
         }
         SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
     }
@@ -439,6 +459,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                     // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
                     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)gc0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)gc0 * n_));
                     SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)gc0 * n_, lde + (uint64_t)gc0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
+                    if (segment == 0) SP_TRY(maybe_leaf_head(cols, gc0 + w, lde));
                     SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
                 }
                 if (++k == n_chunks) gather_end = wall_ms();
