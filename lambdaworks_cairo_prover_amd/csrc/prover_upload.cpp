@@ -433,12 +433,20 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // back when their DMA has completed.
     auto orchestrate = [&]() -> int {
         size_t k = 0, d = 0;   // next chunk to send, next chunk whose DMA completion is awaited
+        uint64_t idle_spins = 0;
+        double idle_since = 0.0;
         while (k < n_chunks) {
             bool progress = false;
-            if (d < k && hipEventQuery(ev_dma_[chunks[d].slot]) == hipSuccess) {
-                ++d;
-                writable.store(d + UPLOAD_SLOTS, std::memory_order_release);
-                progress = true;
+            if (d < k) {
+                const hipError_t q = hipEventQuery(ev_dma_[chunks[d].slot]);
+                if (q == hipSuccess) {
+                    ++d;
+                    writable.store(d + UPLOAD_SLOTS, std::memory_order_release);
+                    progress = true;
+                } else if (q != hipErrorNotReady) {   // a failed copy must end the loop, not spin in it
+                    sp_set_error(std::string("commit_trace: upload DMA failed: ") + hipGetErrorString(q));
+                    return SP_E_HIP;
+                }
             }
             const Chunk& ck = chunks[k];
             if (blocks_done[k].load(std::memory_order_acquire) == ck.blocks) {
@@ -465,7 +473,13 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                 if (++k == n_chunks) gather_end = wall_ms();
                 progress = true;
             }
-            if (!progress) __builtin_ia32_pause();
+            if (progress) { idle_since = 0.0; continue; }
+            __builtin_ia32_pause();
+            if ((++idle_spins & 0xfffffu) == 0) {   // (~every few ms) a watchdog: neither a block gathered nor a DMA completed for 60 s
+                const double now = wall_ms();
+                if (idle_since == 0.0) idle_since = now;
+                else if (now - idle_since > 60e3) { sp_set_error("commit_trace: the upload pipeline made no progress for 60 s"); return SP_E_HIP; }
+            }
         }
         return SP_OK;
     };
