@@ -401,7 +401,10 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         uint32_t c = 0;
         for (uint32_t g = 0; g < groups; c += gsize[g], ++g) {
             const uint32_t cw = gsize[g];
-            const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk / ((size_t)cw * 32)) & ~(uint64_t)255);
+            // (the two single columns that start the pipeline in quarter-size chunks: the first DMA leaves after 0.16 ms of gathering
+            // instead of 0.65, and the compute stream gets its first column that much earlier)
+            const size_t chunk_g = g < 2 ? chunk / 4 : chunk;
+            const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk_g / ((size_t)cw * 32)) & ~(uint64_t)255);
             const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)cw * 32)) & ~(uint64_t)1;   // ~256 KB written per block
             for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
