@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Host-side code of the product library (Cairo front-end, verifier with both Merkle backends on valid, tampered, truncated and random inputs, host Poseidon, NUMA helper) under AddressSanitizer - no GPU needed (tools/sanitize_host.sh)."""
+import sys, os, random, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from lambdaworks_cairo_prover_amd import _lib
+_lib.LIB_PATH = os.environ.get('SP_SANITIZE_DIR', '/tmp/sp_sanitize') + '/libstark252_hip.so'
+from lambdaworks_cairo_prover_amd import api
+import oracle_lib as O
+import poseidon_ref as pr
+lib = _lib.load()
+rnd = random.Random(2)
+for n in (1, 2, 5, 34, 43):
+    v = [rnd.randrange(pr.P) for _ in range(n)]
+    assert api.poseidon_host(0, v) == pr.hash_many(v)
+assert api.poseidon_host(3, [1, 2, 3]) == pr.hades([1, 2, 3])
+# front-end: runs, traces, columns, builtins
+for idx in (1, 10, 100, 1000):
+    run = api.CairoRun.fibonacci(idx)
+    t = run.main_trace(); t2 = run.main_trace(api.SP_FE_MONT_LIMBS); run.columns(); run.public_memory()
+opts = (4, 3, 3, 1); OPT = api.ProofOptions(*opts)
+run = api.CairoRun.fibonacci(20)
+for backend in (0, 1):
+    O.set_merkle_backend(backend)
+    p = O.cairo_prove(run.main_trace(), run.public_inputs_c, opts)
+    O.set_merkle_backend(0)
+    assert api.cairo_verify(p, run.public_inputs_c, OPT, backend)
+    assert not api.cairo_verify(p, run.public_inputs_c, OPT, 1 - backend)
+    for _ in range(60):
+        bad = bytearray(p); i = rnd.randrange(len(bad)); bad[i] ^= 1 << rnd.randrange(8)
+        api.cairo_verify(bytes(bad), run.public_inputs_c, OPT, backend)
+    for cut in (0, 1, 7, 8, 9, 100, 1000, len(p) - 1):
+        api.cairo_verify(p[:cut] or b'\0', run.public_inputs_c, OPT, backend)
+    for _ in range(40):
+        junk = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 600)))
+        api.cairo_verify(junk, run.public_inputs_c, OPT, backend)
+blob = api.proof_file_bytes(p, run)
+n = ctypes.c_int(); lib.sp_host_cpus(ctypes.byref(n)); api.host_bind_to_device(0)
+print("product host code under ASan: ok")
