@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256) batch_inverse_kernel(fe* data, fe* scratc
 // The prefixes of positions 0 and 1 of a chunk are 1 and the element itself, so scratch[0 .. T) holds the chunk products and
 // scratch[T .. 2T) is the scratch of the second level: no memory beyond the caller's n elements.
 constexpr uint32_t BI_CHUNK = 16;
+constexpr uint32_t BI_TOP = 8;
 __global__ void __launch_bounds__(256) batch_inverse_prefix_kernel(const fe* data, fe* scratch, uint64_t T) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= T) return;
@@ -82,8 +83,11 @@ int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_f
         const unsigned blocks = (unsigned)((T + 255) / 256);
         hipLaunchKernelGGL(batch_inverse_prefix_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, T);
         SP_HIP_CHECK(hipGetLastError());
-        // a zero element makes its chunk product zero: the second level raises the flag
-        uint64_t threads2 = (T + 63) / 64;
+        // a zero element makes its chunk product zero: the second level raises the flag.
+        // Second level: BI_TOP elements per thread.  With the Fermat chain (261 dependent products) 64 elements per inversion were the
+        // balance; the division-step inversion of fp.h costs about 45 products' worth of instructions, so a thread now takes 8 - a chain
+        // of 24 products + one inversion instead of 192 + one (config #4: 283 -> 214 us with the new inversion alone, -> ~70 with this)
+        uint64_t threads2 = (T + BI_TOP - 1) / BI_TOP;
         unsigned blocks2 = (unsigned)((threads2 + 255) / 256);
         hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks2), dim3(256), 0, st, scratch, scratch + T, T, zero_flag_dev);
         SP_HIP_CHECK(hipGetLastError());
@@ -91,8 +95,8 @@ int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_f
         SP_HIP_CHECK(hipGetLastError());
         return SP_OK;
     }
-    // chunk of ~64 elements per thread amortises the Fermat inversion (~300 mulmods) to < 5 mulmods/element
-    uint64_t threads = (n + 63) / 64;
+    // a few elements per thread: the inversion costs about 45 products' worth of instructions (fp.h), the chain per thread stays short
+    uint64_t threads = (n + BI_TOP - 1) / BI_TOP;
     unsigned blocks = (unsigned)((threads + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(batch_inverse_kernel, dim3(blocks), dim3(256), 0, st, data, scratch, n, zero_flag_dev);

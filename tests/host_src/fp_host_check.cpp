@@ -24,6 +24,7 @@ int main() {
         else if (!strcmp(op, "negone")) show(fe_neg_one());
         else if (!strcmp(op, "sub2p")) show(fe_sub_add_2p(a, b));
         else if (!strcmp(op, "inv")) show(fe_inv(a));
+        else if (!strcmp(op, "invfermat")) show(fe_inv_fermat(a));
         else if (!strcmp(op, "frommont")) show(fe_from_mont(a));
         else return 2;
     }

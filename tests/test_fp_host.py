@@ -94,11 +94,20 @@ def test_minus_one(probe):
 
 
 def test_inverse_addition_chain(probe):
-    """fe_inv (Montgomery in, Montgomery out): a^(p-2) through the 2^192 - 1 doubling chain."""
+    """fe_inv (Montgomery in, Montgomery out): the division-step inversion (600 Bernstein-Yang steps on nine 30-bit limbs) and the
+    Fermat chain it replaced (a^(p-2) through the 2^192 - 1 doubling chain) against Python integers, on edge values - powers of two,
+    small values, values next to p, operands in [p, 2p) - and random ones; zero maps to zero."""
     rng = random.Random(14)
-    vals = [1, 2, P - 1, R % P, 3 * R % P] + [rng.randrange(1, P) for _ in range(300)]
-    for a, g in zip(vals, probe([("inv", a, 0, 0) for a in vals])):
-        # a = x R, result = x^-1 R  ->  a * g = R^2 (mod p)
+    vals = [1, 2, 3, P - 1, P - 2, R % P, 3 * R % P, (P + 1) // 2, 2**251, 2**250, 2**30 - 1, 2**30, 2**60, 2**240 + 1]
+    vals += [2**k for k in range(0, 251, 7)] + [P - 2**k for k in range(0, 251, 11)] + list(range(1, 60))
+    vals += [rng.randrange(1, P) for _ in range(3000)]
+    for op in ("inv", "invfermat"):
+        for a, g in zip(vals, probe([(op, a, 0, 0) for a in vals])):
+            # a = x R, result = x^-1 R  ->  a * g = R^2 (mod p)
+            assert g < P and a * g % P == R * R % P, (op, hex(a))
+    assert probe([("inv", 0, 0, 0)]) == [0]
+    lazy = [P + 5, 2 * P - 1, P + rng.randrange(P)]          # lazily reduced operands are accepted
+    for a, g in zip(lazy, probe([("inv", a, 0, 0) for a in lazy])):
         assert g < P and a * g % P == R * R % P
 
 
