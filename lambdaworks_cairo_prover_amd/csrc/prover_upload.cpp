@@ -298,9 +298,6 @@ class HostPool {
 };
 void host_pool_delete(HostPool* p) { delete p; }
 
-// dst[i][0..width) = src[i][off..off+width) for n rows of row_bytes: the column group of a row-major trace.  The rows are handed
-// out in blocks through a shared counter, so a thread that is slow (a busy core, a remote NUMA node, a throttled container)
-// takes fewer blocks instead of holding the whole group back.
 // One block of a chunk: rows [r0, r1) of the chunk (src points at the chunk's first row), columns [off/32, off/32 + cw) of the table,
 // written column-major into the chunk's ring slot (column j at dst + j * n * 32: every column of a chunk is one contiguous DMA
 // straight into the trace area).
@@ -328,10 +325,11 @@ static void host_gather_block(const uint8_t* src, uint64_t n, size_t row_bytes, 
 
 // interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
 // in column groups: while group g is interpolated and extended on the compute stream, the chunks of the groups behind it are
-// gathered out of the table into a small ring of page-locked slots by a few host threads and cross PCIe on a second stream.
-// A chunk is a block of rows of one group, 32 MB at most: the DMA of one chunk runs beside the gather of the next whatever the
-// size of the group, and the ring (4 x 32 MB) takes a sixth of the time to pin that three group-sized slots did (56 ms of a
-// first proof at 2^20 rows).
+// transposed out of the table into a small ring of page-locked slots by a few host threads (256 KB blocks off a shared counter: a
+// thread that is slow - a busy core, a throttled container - takes fewer blocks) and cross PCIe on a second stream, column by column
+// straight into the trace area.  A chunk is a block of rows of one group, 32 MB at most: the DMA of one chunk runs beside the gather
+// of the next whatever the size of the group, and the ring (4 x 32 MB) takes a sixth of the time to pin that three group-sized slots
+// did (56 ms of a first proof at 2^20 rows).
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything behind
