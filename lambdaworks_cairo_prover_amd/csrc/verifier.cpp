@@ -294,52 +294,69 @@ static int verify_host(const uint8_t* proof_bytes, size_t len, const VerifySpec&
     // ---- step 3: FRI (verifier.rs:319-356, :443-523)
     const fe half = fe_inv(fe_from_u64(2));
     const size_t L = pr.fri_roots.size();
-    bool ok = true;
-    for (size_t s = 0; s < queries; ++s) {
-        const FriDecommitment& q = pr.queries[s];
-        if (q.paths.size() != L || q.paths_sym.size() != L || q.evals.size() != L || q.evals_sym.size() != L) return 0;
-        fe xinv = fe_inv(fe_mul(h, fe_pow_u64(w, iotas[s])));
-        fe v = q.evals[0];
-        for (size_t l = 0; l < L; ++l) {
-            uint64_t dl = N >> l, isym = (iotas[s] + dl / 2) % dl;
-            ok &= merkle_ok(q.paths_sym[l], pr.fri_roots[l], isym, &q.evals_sym[l], 1, true);
-            ok &= merkle_ok(q.paths[l], pr.fri_roots[l], iotas[s], &q.evals[l], 1, true);
-            const fe& es = q.evals_sym[l];
-            v = fe_add(fe_mul(fe_add(v, es), half), fe_mul(fe_mul(fe_mul(zetas[l], fe_sub(v, es)), half), xinv));
-            xinv = fe_sqr(xinv);
-            ok &= fe_eq(v, l + 1 < L ? q.evals[l + 1] : pr.fri_last);
+    // The queries are independent: checked on the host's threads (80 queries of a 2^20-row proof are ~10^5 hashes - 15 ms of Keccak
+    // or 250 ms of Poseidon on one thread).  status per query: 1 accepted, 0 a check failed, -1 malformed (the verdict is reject
+    // either way; the counts keep the single-threaded order of the decisions irrelevant).
+    const int backend = t_merkle_backend;
+    std::vector<int8_t> st_fri(queries, 1), st_deep(queries, 1);
+    host_parallel_for(queries, 1, [&](size_t b, size_t e) {
+        t_merkle_backend = backend;   // (thread-local: the workers of this call take the caller's setting)
+        for (size_t s = b; s < e; ++s) {
+            const FriDecommitment& q = pr.queries[s];
+            if (q.paths.size() != L || q.paths_sym.size() != L || q.evals.size() != L || q.evals_sym.size() != L) { st_fri[s] = -1; continue; }
+            bool ok = true;
+            fe xinv = fe_inv(fe_mul(h, fe_pow_u64(w, iotas[s])));
+            fe v = q.evals[0];
+            for (size_t l = 0; l < L; ++l) {
+                uint64_t dl = N >> l, isym = (iotas[s] + dl / 2) % dl;
+                ok &= merkle_ok(q.paths_sym[l], pr.fri_roots[l], isym, &q.evals_sym[l], 1, true);
+                ok &= merkle_ok(q.paths[l], pr.fri_roots[l], iotas[s], &q.evals[l], 1, true);
+                const fe& es = q.evals_sym[l];
+                v = fe_add(fe_mul(fe_add(v, es), half), fe_mul(fe_mul(fe_mul(zetas[l], fe_sub(v, es)), half), xinv));
+                xinv = fe_sqr(xinv);
+                ok &= fe_eq(v, l + 1 < L ? q.evals[l + 1] : pr.fri_last);
+            }
+            st_fri[s] = ok ? 1 : 0;
         }
-    }
-    if (!ok) return 0;
+    });
+    for (int8_t v : st_fri) if (v != 1) return 0;
     // ---- step 4: DEEP consistency and openings (verifier.rs:358-441, :525-557)
     if (pr.openings.size() < queries) return 0;
     const fe z2 = fe_sqr(z);
     std::vector<fe> zk(R);
     for (uint32_t r = 0; r < R; ++r) zk[r] = fe_mul(z, fe_pow_u64(g, air.offsets[r]));
-    for (size_t s = 0; s < queries; ++s) {
-        const Opening& o = pr.openings[s];
-        if (o.trace_evals.size() != C || o.trace_paths.size() != n_roots) return 0;
-        fe hh[2] = {o.h1, o.h2};
-        ok &= merkle_ok(o.comp_path, pr.comp_root, iotas[s], hh, 2);
-        ok &= merkle_ok(o.trace_paths[0], pr.trace_roots[0], iotas[s], o.trace_evals.data(), air.main_cols);
-        if (n_roots > 1) ok &= merkle_ok(o.trace_paths[1], pr.trace_roots[1], iotas[s], o.trace_evals.data() + air.main_cols, air.aux_cols);
-        fe x = fe_mul(h, fe_pow_u64(w, iotas[s]));
-        fe d2 = fe_sub(x, z2);
-        if (fe_is_zero(d2)) return 0;
-        fe i2 = fe_inv(d2);
-        fe acc = fe_zero();
-        for (uint32_t r = 0; r < R; ++r) {
-            fe d = fe_sub(x, zk[r]);
-            if (fe_is_zero(d)) return 0;
-            fe ir = fe_inv(d);
-            for (uint32_t j = 0; j < C; ++j)
-                acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[(size_t)r * C + j]), ir), tg[(size_t)R * j + r]));
+    host_parallel_for(queries, 1, [&](size_t b, size_t e) {
+        t_merkle_backend = backend;
+        for (size_t s = b; s < e; ++s) {
+            const Opening& o = pr.openings[s];
+            if (o.trace_evals.size() != C || o.trace_paths.size() != n_roots) { st_deep[s] = -1; continue; }
+            bool ok = true;
+            fe hh[2] = {o.h1, o.h2};
+            ok &= merkle_ok(o.comp_path, pr.comp_root, iotas[s], hh, 2);
+            ok &= merkle_ok(o.trace_paths[0], pr.trace_roots[0], iotas[s], o.trace_evals.data(), air.main_cols);
+            if (n_roots > 1) ok &= merkle_ok(o.trace_paths[1], pr.trace_roots[1], iotas[s], o.trace_evals.data() + air.main_cols, air.aux_cols);
+            fe x = fe_mul(h, fe_pow_u64(w, iotas[s]));
+            fe d2 = fe_sub(x, z2);
+            if (fe_is_zero(d2)) { st_deep[s] = -1; continue; }
+            fe i2 = fe_inv(d2);
+            fe acc = fe_zero();
+            bool zero_den = false;
+            for (uint32_t r = 0; r < R && !zero_den; ++r) {
+                fe d = fe_sub(x, zk[r]);
+                if (fe_is_zero(d)) { zero_den = true; break; }
+                fe ir = fe_inv(d);
+                for (uint32_t j = 0; j < C; ++j)
+                    acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.trace_evals[j], pr.ood[(size_t)r * C + j]), ir), tg[(size_t)R * j + r]));
+            }
+            if (zero_den) { st_deep[s] = -1; continue; }
+            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h1, pr.h1z), i2), gamma));
+            acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h2, pr.h2z), i2), gamma_p));
+            ok &= fe_eq(acc, pr.queries[s].evals[0]);
+            st_deep[s] = ok ? 1 : 0;
         }
-        acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h1, pr.h1z), i2), gamma));
-        acc = fe_add(acc, fe_mul(fe_mul(fe_sub(o.h2, pr.h2z), i2), gamma_p));
-        ok &= fe_eq(acc, pr.queries[s].evals[0]);
-    }
-    return ok ? 1 : 0;
+    });
+    for (int8_t v : st_deep) if (v != 1) return 0;
+    return 1;
 }
 
 int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs& pub, uint8_t blowup, uint64_t queries, uint64_t coset_offset, uint8_t grinding) {
