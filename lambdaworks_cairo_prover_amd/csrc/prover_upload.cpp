@@ -347,7 +347,8 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         done += w;
     }
     const uint32_t groups = (uint32_t)gsize.size();
-    const size_t chunk = (size_t)32 << 20;   // bytes per ring slot
+    static const size_t chunk_mb = [] { const char* e = std::getenv("SP_UPLOAD_CHUNK_MB"); return e ? (size_t)std::min(64, std::max(1, std::atoi(e))) : (size_t)32; }();
+    const size_t chunk = chunk_mb << 20;   // bytes per ring slot
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
     // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
