@@ -75,7 +75,8 @@ int sp_host_cpus(int* count_out);
  * first-touched on that node: the page-locked staging of the host-buffer entry points lives there, and a table on the other node
  * crosses the socket link on its way in (sp_cairo_prove from a far table: 37 - 43 GB/s instead of 52 - 56).  The equivalent of
  * `numactl --cpunodebind=<node of the GPU>`; call it first thing in a one-process-per-GPU prover.  *node_out (nullable): the node,
- * -1 when it is unknown (single-node host, no sysfs) - nothing is changed then.  Does not initialise a context. */
+ * -1 when it is unknown (single-node host, no sysfs, no device) - nothing is changed then.  Touches the HIP runtime (the device's PCI
+ * address), creates no context. */
 int sp_host_bind_to_device(int device, int* node_out);
 
 int sp_ctx_create(sp_ctx** ctx_out, const sp_config* cfg);
@@ -284,7 +285,7 @@ int sp_host_alloc(uint64_t bytes, void** out);
 void sp_host_free(void* p);
 void sp_free(void* p);
 /* How the main trace of the last proof reached the device: out = {kind (0: one copy / resident, 1: row-major host buffer gathered
- * into column groups by host threads, 2: DMA of page-locked host columns, 3: host columns in pageable memory), column groups, bytes, host gather ms (sum), gather GB/s, DMA ms
+ * into column groups by host threads, 2: DMA of page-locked host columns, 3: host columns in pageable memory), column groups, bytes, host ms until the last chunk had been gathered and sent (kind 1), bytes over that time in GB/s, DMA ms
  * (sum over the groups), DMA GB/s, exposed ms (how long the compute stream waited for column groups in total), longest wait
  * for one group ms, host wall ms of the upload loop}. */
 int sp_last_upload_stats(sp_ctx* ctx, double out[10]);
