@@ -366,9 +366,13 @@ __global__ void __launch_bounds__(256) fold_eval_kernel(const fe* in, uint64_t i
     if (q >= Mq) return;
     const uint32_t v = blockIdx.y, p = blockIdx.z;
     const fe* src = in + (uint64_t)v * in_vec_stride + (in_points > 1 ? (uint64_t)p * Mq * T : 0);
+    // lazily reduced sum: products in [0, 2p), eight of them on top of an accumulator below 2p stay below 18p < 2^256
     fe acc = fe_zero();
-    for (uint32_t t = 0; t < T; ++t) acc = fe_add(acc, fe_mul(sk_ld(src + (uint64_t)t * Mq + q), yp[p * T + t]));
-    sk_st(out + ((uint64_t)v * points + p) * Mq + q, acc);
+    for (uint32_t t = 0; t < T; ++t) {
+        acc = fe_add_raw(acc, fe_mul_lazy(sk_ld(src + (uint64_t)t * Mq + q), yp[p * T + t]));
+        if ((t & 7u) == 7u) acc = fe_reduce_lazy_2p(acc);
+    }
+    sk_st(out + ((uint64_t)v * points + p) * Mq + q, fe_canonical_lazy(acc));
 }
 int fold_eval_level(hipStream_t st, const fe* in, uint64_t in_vec_stride, uint32_t in_points, uint64_t M, uint32_t l,
                     const fe* yp, uint32_t points, uint32_t vectors, fe* out) {
