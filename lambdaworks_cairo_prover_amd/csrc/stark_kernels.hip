@@ -397,12 +397,18 @@ __global__ void __launch_bounds__(256) deep_kernel(const fe* __restrict__ lde, c
     fe a[MAXR];
 #pragma unroll
     for (int k = 0; k < MAXR; ++k) a[k] = fe_zero();
+    // lazily reduced sums over the columns: products in [0, 2p), eight of them on top of an accumulator below 2p stay below 18p < 2^256
     for (uint32_t j = 0; j < C; ++j) {
         fe t = sk_ld(lde + (uint64_t)j * col_stride + i);
 #pragma unroll
         for (int k = 0; k < MAXR; ++k)
-            if ((uint32_t)k < R) a[k] = a[k] + K->gammas[k][j] * t;
+            if ((uint32_t)k < R) {
+                a[k] = fe_add_raw(a[k], fe_mul_lazy(t, K->gammas[k][j]));
+                if ((j & 7u) == 7u) a[k] = fe_reduce_lazy_2p(a[k]);
+            }
     }
+#pragma unroll
+    for (int k = 0; k < MAXR; ++k) a[k] = fe_canonical_lazy(a[k]);
     fe hh = K->gamma_h1 * sk_ld(h1 + i) + K->gamma_h2 * sk_ld(h2 + i) - K->c_h;
     fe r = hh * sk_ld(inv + (uint64_t)R * count + q);
 #pragma unroll
