@@ -27,6 +27,7 @@ StarkProver::~StarkProver() {
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
     if (h_pin_) (void)hipHostFree(h_pin_);
+    if (h_wide_) (void)hipHostFree(h_wide_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
     if (ev_comm_fork_) (void)hipEventDestroy(ev_comm_fork_);
@@ -568,6 +569,9 @@ int StarkProver::launch_aux_presort() {
     SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
     SP_HIP_CHECK(hipMemsetAsync(d_flag_side_ + 2, 0, 2 * sizeof(int), side_stream_));
     SP_TRY(cairo_aux_presort(side_stream_, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, d_flag_side_ + 2, d_flag_side_ + 3));
+    // the "address beyond the key bits" flag travels to the host behind the sorts: commit_aux_cairo reads it without a round trip of its own
+    if (!h_wide_ && hipHostMalloc(reinterpret_cast<void**>(&h_wide_), 64, hipHostMallocDefault) != hipSuccess) { h_wide_ = nullptr; sp_set_error("pinned flag slot: allocation failed"); return SP_E_ALLOC; }
+    SP_HIP_CHECK(hipMemcpyAsync(h_wide_, d_flag_side_ + 3, sizeof(int), hipMemcpyDeviceToHost, side_stream_));
     SP_HIP_CHECK(hipEventRecord(ev_side_presort_, side_stream_));
     presorted_ = true;
     return SP_OK;
@@ -579,10 +583,9 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     bool pre = presorted_;
     presorted_ = false;
     if (pre) {   // an address beyond the key bits the presort looked at (a trace with a discontinuous memory): sort again, all 64 bits
-        int wide = 0;
         SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_presort_, 0));
-        SP_TRY(readback(&wide, d_flag_side_ + 3, sizeof(int)));
-        if (wide) pre = false;
+        SP_HIP_CHECK(hipEventSynchronize(ev_side_presort_));   // (the sorts ended beside round 1's transforms: no wait in practice)
+        if (*h_wide_) pre = false;
     }
     else SP_TRY(public_memory_lists(pub));     // (the presort built them from the same public inputs)
     const uint64_t pm = pm_addr_h_.size();
