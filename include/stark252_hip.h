@@ -130,8 +130,12 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  versions configure it: digest = the canonical 32-byte big-endian element, node = hash(left, right),
  *                                  leaf of a row of columns = hash_many(row), leaf of a single-element tree (FRI layers) =
  *                                  hash_single(x).  Transcript and grinding stay Keccak; the proof layout does not change.
- *                                  Such proofs are checked with sp_cairo_verify_backend / sp_air_verify_backend. */
-enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4 };
+ *                                  Such proofs are checked with sp_cairo_verify_backend / sp_air_verify_backend.
+ *   SP_OPT_MERKLE_ONE_COLUMN_ROWS (0)  which Poseidon tree sp_merkle_build / sp_merkle_build_dev build for fe_per_leaf == 1: 0 the
+ *                                  single-element tree of a FRI layer (leaf = hash_single(x), fri_commitment.rs:39), 1 the tree over
+ *                                  rows of ONE column (leaf = hash_many over one element) - what the prover commits a one-column trace
+ *                                  segment with (prover.rs:96-104 batch_commit).  Keccak256 trees have one leaf form; no effect there. */
+enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 5 };
 enum { SP_MERKLE_KECCAK256 = 0, SP_MERKLE_POSEIDON = 1 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 

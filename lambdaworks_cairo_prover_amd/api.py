@@ -548,7 +548,7 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND = 1, 2, 3, 4
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 1, 2, 3, 4, 5
 SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
 
 
@@ -577,5 +577,5 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device"]

@@ -105,7 +105,8 @@ const fe& mem_at(const CairoMemory& m, uint64_t a) {
 
 void TraceColumns::release() {
     if (data) { if (pinned) (void)hipHostFree(data); else std::free(data); }
-    data = nullptr; n_rows = n_cols = 0; pinned = false;
+    if (retired) std::free(retired);
+    data = nullptr; retired = nullptr; n_rows = n_cols = 0; pinned = false;
 }
 static std::atomic<int> g_hip_in_use{0};
 void hip_runtime_mark_in_use() { g_hip_in_use.store(1); }
@@ -137,7 +138,7 @@ bool TraceColumns::try_pin() {
     if (!p) return false;
     const uint8_t* src = reinterpret_cast<const uint8_t*>(data);
     host_parallel_for(bytes, 1 << 22, [&](size_t b, size_t e) { std::memcpy(p + b, src + b, e - b); });
-    std::free(data);
+    retired = data;     // NOT freed: the old address was handed out and may be in use (released with the run)
     data = reinterpret_cast<fe*>(p); pinned = true;
     return true;
 }
@@ -239,7 +240,11 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
         const uint64_t codelen = pub.public_memory.size();
         uint64_t lo = ~0ULL, hi = 0;
         for (uint64_t a : addr) { lo = std::min(lo, a); hi = std::max(hi, a); }
-        if (hi - lo < (1ULL << 34)) {           // presence bitmap over [lo, hi]
+        // A run's memory is (nearly) continuous, so [lo, hi] is a small multiple of the 4 * steps accesses: presence bitmap.  A sparse
+        // range (an odd or hostile dump) takes the sorted formulation, whose cost is O(accesses) before any hole is enumerated; and a
+        // dump whose holes could never fit a trace is refused before gigabytes of them are collected.
+        constexpr uint64_t MAX_HOLES = 1ULL << 30;
+        if (hi - lo <= 64ULL * 4 * steps + 4096) {           // presence bitmap over [lo, hi]
             std::vector<uint64_t> bits(((hi - lo) >> 6) + 1, 0);
             for (uint64_t a : addr) bits[(a - lo) >> 6] |= 1ULL << ((a - lo) & 63);
             for (uint64_t h = std::max(lo + 1, codelen + 1); h < hi; ++h)
@@ -247,7 +252,14 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
         } else {                                // scattered addresses: sort (the reference's own formulation)
             std::vector<uint64_t> sorted(addr);
             std::sort(sorted.begin(), sorted.end());
-            uint64_t prev = sorted[0];
+            uint64_t prev = sorted[0], count = 0;
+            for (uint64_t a : sorted) {     // count first
+                if (a - prev > 1 && a > codelen) count += a - std::max(prev + 1, codelen + 1);
+                if (count > MAX_HOLES) throw std::runtime_error("more than 2^30 memory holes: not the memory of one run");
+                prev = a;
+            }
+            holes.reserve(count);
+            prev = sorted[0];
             for (uint64_t a : sorted) {
                 const uint64_t diff = a - prev;
                 if (diff != 1 && diff != 0 && a > codelen)

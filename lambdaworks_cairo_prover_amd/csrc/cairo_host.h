@@ -53,13 +53,21 @@ struct TraceColumns {
     fe* data = nullptr;
     size_t n_rows = 0, n_cols = 0;
     bool pinned = false;
-    std::mutex pin_mutex;                      // try_pin() from two provers at once
+    // A pageable table that try_pin() has copied into page-locked memory stays allocated until the run is freed: its address has
+    // been handed out (sp_cairo_run_columns: "lives as long as the run") and another prover may still be reading or DMA-ing from it.
+    fe* retired = nullptr;
+    mutable std::mutex pin_mutex;              // try_pin() from two provers at once; current() from readers
     TraceColumns() = default;
     TraceColumns(const TraceColumns&) = delete;
     TraceColumns& operator=(const TraceColumns&) = delete;
     ~TraceColumns() { release(); }
     void allocate(size_t rows, size_t cols);   // throws std::bad_alloc
-    bool try_pin();                            // moves a pageable table into page-locked memory (false: the runtime has none to give)
+    bool try_pin();                            // copies a pageable table into page-locked memory (false: the runtime has none to give)
+    const fe* current(bool* pinned_out = nullptr) const {   // the table to read from now on (both copies hold the same, immutable trace)
+        std::lock_guard<std::mutex> lk(pin_mutex);
+        if (pinned_out) *pinned_out = pinned;
+        return data;
+    }
     void release();
     fe& at(size_t row, size_t col) { return data[col * n_rows + row]; }
     const fe& at(size_t row, size_t col) const { return data[col * n_rows + row]; }

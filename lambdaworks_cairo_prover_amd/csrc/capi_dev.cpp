@@ -110,6 +110,9 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             if (value != SP_MERKLE_KECCAK256 && value != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
             c->opt_merkle_backend = (int)value;
             break;
+        case SP_OPT_MERKLE_ONE_COLUMN_ROWS:
+            c->opt_merkle_one_column_rows = value != 0;
+            return SP_OK;                     // (shapes no prover buffer)
         default: sp_set_error("sp_set_option: unknown key"); return SP_E_INVALID_ARG;
     }
     delete c->prover_state_deleter_holder;   // the options shape the prover's buffers: start from a fresh one
@@ -402,7 +405,9 @@ int sp_lde(sp_ctx* c, const uint8_t* coeffs, uint64_t n, uint32_t cols, uint32_t
 
 static sp::MerkleHash ctx_merkle_hash(const sp_ctx* c, uint32_t fe_per_leaf) {
     if (c->opt_merkle_backend != SP_MERKLE_POSEIDON) return sp::MerkleHash::KECCAK256;
-    return fe_per_leaf == 1 ? sp::MerkleHash::POSEIDON_SINGLE : sp::MerkleHash::POSEIDON_BATCH;
+    // one element per leaf: the single-element tree of a FRI layer (hash_single) unless the caller asked for the row tree the prover
+    // commits a one-column trace segment with (hash_many over one element): SP_OPT_MERKLE_ONE_COLUMN_ROWS
+    return (fe_per_leaf == 1 && !c->opt_merkle_one_column_rows) ? sp::MerkleHash::POSEIDON_SINGLE : sp::MerkleHash::POSEIDON_BATCH;
 }
 int sp_merkle_build(sp_ctx* c, const uint8_t* leaves, uint64_t n_leaves, uint32_t fe_per_leaf, uint8_t root_out[32], uint8_t* nodes_out) {
     if (!c || !leaves || !root_out || fe_per_leaf == 0) return SP_E_INVALID_ARG;

@@ -180,10 +180,11 @@ int sp_cairo_run_main_trace(const sp_cairo_run* run, int enc, uint8_t* out) {
 // Montgomery limbs, SP_FE_DEVICE), page-locked when *pinned comes back 1.  The pointer lives as long as the run.
 int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_t* n_rows, uint32_t* n_cols, int* pinned) {
     if (!run || !cols_out) return SP_E_INVALID_ARG;
-    *cols_out = run->main_trace.data;
+    bool is_pinned = false;
+    *cols_out = run->main_trace.current(&is_pinned);
     if (n_rows) *n_rows = run->main_trace.n_rows;
     if (n_cols) *n_cols = (uint32_t)run->main_trace.n_cols;
-    if (pinned) *pinned = run->main_trace.pinned ? 1 : 0;
+    if (pinned) *pinned = is_pinned ? 1 : 0;
     return SP_OK;
 }
 

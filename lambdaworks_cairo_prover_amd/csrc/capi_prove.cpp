@@ -165,9 +165,11 @@ int sp_cairo_prove_columns(sp_ctx* c, const uint8_t* main_trace_cols, uint64_t n
 }
 int sp_cairo_prove_run(sp_ctx* c, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
     if (!run || !c) return SP_E_INVALID_ARG;
-    const_cast<TraceColumns&>(cairo_run_columns(run)).try_pin();   // a run built before this process had a context: migrate once
+    // a run built before this process had a context keeps its trace in pageable memory: copied into page-locked memory once (the
+    // pageable copy stays valid until sp_cairo_run_free - its address may have been handed out by sp_cairo_run_columns)
+    const_cast<TraceColumns&>(cairo_run_columns(run)).try_pin();
     const TraceColumns& T = cairo_run_columns(run);
-    return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.data), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
+    return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.current()), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
                             proof_len, StarkProver::TRACE_HOST_COLUMNS, -1, T.n_rows);
 }
 

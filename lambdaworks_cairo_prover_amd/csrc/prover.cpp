@@ -431,14 +431,25 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_HIP_CHECK(hipSetDevice(c_->device));
     for (double& x : c_->upload_stats) x = 0.0;
     leaf_head_done_ = false;
+    // An upload that fails half-way must not return while copies from the caller's buffer are still in flight (the caller is free
+    // to release it): every non-OK exit of the host paths waits for the copy and the compute stream first.
+    auto drained = [this](int rc) {
+        if (rc != SP_OK) {
+            if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
+            (void)hipStreamSynchronize(c_->stream);
+            (void)hipGetLastError();
+            leaf_head_done_ = false;
+        }
+        return rc;
+    };
     if (src == TRACE_HOST_COLUMNS) {
         if (col_enc >= 0 && col_enc != SP_FE_MONT_LIMBS && col_enc != SP_FE_CANON_BE) return SP_E_INVALID_ARG;
         if (col_stride && col_stride < n_) return SP_E_INVALID_ARG;
-        return commit_trace_columns(segment, rows_host, cols, col_enc, col_stride ? col_stride : n_, root_out);
+        return drained(commit_trace_columns(segment, rows_host, cols, col_enc, col_stride ? col_stride : n_, root_out));
     }
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
     if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20))
-        return commit_trace_pipelined(segment, rows_host, cols, root_out);
+        return drained(commit_trace_pipelined(segment, rows_host, cols, root_out));
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));

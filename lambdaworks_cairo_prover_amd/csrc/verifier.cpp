@@ -163,6 +163,13 @@ fe poseidon_fe(const Dig& d) {
     std::memcpy(w, d.data(), 32);
     return poseidon_fe_from_digest(w);
 }
+// A Poseidon digest is the canonical big-endian encoding of a field element: bytes >= p (d and d + p name the same element) are
+// not a digest.  lambdaworks' Poseidon trees carry field elements, so only canonical encodings exist there; accepting the others
+// would make proofs of this backend byte-malleable, which the Keccak256 backend is not.
+bool poseidon_digest_canonical(const Dig& d) {
+    static const uint8_t P_BE[32] = {0x08, 0, 0, 0, 0, 0, 0, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x01};
+    return std::memcmp(d.data(), P_BE, 32) < 0;
+}
 Dig hash_felts(const fe* v, size_t k, bool single_element_tree) {
     if (t_merkle_backend == SP_MERKLE_POSEIDON) return poseidon_dig(single_element_tree ? poseidon_hash1(v[0]) : poseidon_hash_many(v, 1, (uint32_t)k));
     std::vector<uint8_t> b(32 * k);
@@ -173,6 +180,7 @@ bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, co
     Dig h = hash_felts(v, k, single_element_tree);
     for (const Dig& s : path) {
         if (t_merkle_backend == SP_MERKLE_POSEIDON) {
+            if (!poseidon_digest_canonical(s)) return false;
             h = poseidon_dig((index & 1) ? poseidon_hash2(poseidon_fe(s), poseidon_fe(h)) : poseidon_hash2(poseidon_fe(h), poseidon_fe(s)));
             index >>= 1;
             continue;
