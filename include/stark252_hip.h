@@ -214,6 +214,20 @@ typedef struct {
  * for a trace of n rows (power of two), main_cols + aux_cols columns. has_rc_builtin selects the 61-column Cairo layout. */
 int sp_prove_setup(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int has_rc_builtin, const sp_proof_options* opt);
 
+/* Pre-warm for the reference's one-proof-per-process shape (src/main.rs:85-108: run the VM, prove once, exit): call it - on a
+ * thread of its own, or before the VM starts - while the trace does not exist yet, with the shape the proof will have.  It does
+ * sp_prove_setup's work and everything else a first proof would otherwise pay on its critical path:
+ *   SP_PREWARM_KERNELS    three small valid Cairo proofs (2^13 rows, the three input forms) on this context: the first launch of every
+ *                         kernel family, the side streams, the auxiliary-trace workspace;
+ *   SP_PREWARM_CLOCKS     round 1's kernels once at the REAL shape on the arena's contents: the size-specific kernel variants, and the
+ *                         device at its clocks when the trace arrives;
+ *   SP_PREWARM_HOST_ROWS  the page-locked ring and the parked gather threads of the row-major entry points (sp_cairo_prove,
+ *                         sp_commit_trace from host tables above 64 MB).
+ * flags = 0 means all of them.  The proof that follows (any entry point, same n / columns / blowup / coset offset) then costs what a
+ * warm one does; its bytes are not affected.  With several ranks every rank calls it (the small proofs are sharded proofs). */
+enum { SP_PREWARM_KERNELS = 1, SP_PREWARM_CLOCKS = 2, SP_PREWARM_HOST_ROWS = 4, SP_PREWARM_ALL = 7 };
+int sp_prewarm(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int has_rc_builtin, const sp_proof_options* opt, uint32_t flags);
+
 /* interpolate_and_commit (prover.rs:126-159): rows = row-major n x cols trace segment (0 main, 1 auxiliary).
  * iNTT + LDE + batched Keccak Merkle tree; keeps polynomials, LDE and tree on the device. */
 int sp_commit_trace(sp_ctx* ctx, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]);

@@ -166,6 +166,14 @@ class Context:
         del keep
         return self._take_proof(out, ln)
 
+    def prewarm(self, n_rows, main_cols=34, aux_cols=18, has_rc_builtin=False, options=None, flags=0):
+        """sp_prewarm: everything a first proof of this shape would otherwise pay on its critical path (arena, tables, streams and
+        page-locked slots, the first launch of every kernel family, the device's clocks) - callable on a thread of its own while the
+        Cairo VM is still running (ctypes releases the GIL for the duration).  flags: SP_PREWARM_* (0 = all)."""
+        opt = (options or ProofOptions()).to_c()
+        check(self._lib.sp_prewarm(self._h, ctypes.c_uint64(n_rows), ctypes.c_uint32(main_cols), ctypes.c_uint32(aux_cols), int(bool(has_rc_builtin)),
+                                   ctypes.byref(opt), ctypes.c_uint32(flags)))
+
     def last_upload_stats(self):
         """sp_last_upload_stats of the last proof's main-trace upload."""
         v = (ctypes.c_double * 10)()
@@ -550,6 +558,7 @@ def _ctx_comm_stats(self):
 
 SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 1, 2, 3, 4, 5
 SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
+SP_PREWARM_KERNELS, SP_PREWARM_CLOCKS, SP_PREWARM_HOST_ROWS, SP_PREWARM_ALL = 1, 2, 4, 7
 
 
 def _ctx_set_option(self, key, value):
@@ -578,4 +587,5 @@ Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS",
-            "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device"]
+            "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
+            "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

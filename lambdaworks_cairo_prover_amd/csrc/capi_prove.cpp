@@ -27,6 +27,57 @@ int sp_prove_setup(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols,
     return h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o);
 }
 
+// A small VALID Cairo proof (fib(1100): 2^13 rows) through the three input forms on this context: every kernel family of the proof
+// path - transforms, hashing, sorts and scans of the auxiliary trace, constraint check and composition, out-of-domain folds, DEEP,
+// the FRI chain, grinding, openings, the decode / transpose kernels of the uploads - takes its first launch (code-object load,
+// kernel-object set-up) here instead of inside the caller's first proof.
+static int warm_small_proofs(sp_ctx* c, const ProofOptionsHost& o) {
+    try {
+        std::vector<fe> prog = fibonacci_program(1100);
+        std::vector<RegisterState> regs;
+        CairoMemory mem;
+        run_program_plain(prog, regs, mem, 1u << 20);
+        PublicInputs pub = public_inputs_from_regs_and_mem(regs, mem, prog.size(), {});
+        TraceColumns T;
+        build_main_trace(regs, mem, pub, T);
+        const uint64_t n = T.n_rows;
+        const uint32_t cols = (uint32_t)T.n_cols;
+        std::vector<uint8_t> bytes;
+        float ms[5];
+        // (1) host columns in the device layout: DMA per column group on the copy stream
+        SP_TRY(cairo_prove(c, reinterpret_cast<const uint8_t*>(T.data), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_COLUMNS, -1, n));
+        // (2) host columns in the context encoding: the in-place decode in front of the transforms (what the row-major pipeline runs too)
+        std::vector<uint8_t> enc_cols((size_t)n * cols * 32);
+        SP_TRY(sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(T.data), n * cols, enc_cols.data()));
+        SP_TRY(cairo_prove(c, enc_cols.data(), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_COLUMNS, c->enc, n));
+        // (3) a row-major table (below the pipeline's threshold: one copy + rows -> columns, the kernel of sp_cairo_prove_dev)
+        std::vector<uint8_t> rows((size_t)n * cols * 32);
+        for (uint64_t i = 0; i < n; ++i)
+            for (uint32_t j = 0; j < cols; ++j) std::memcpy(&rows[(i * cols + j) * 32], &enc_cols[((size_t)j * n + i) * 32], 32);
+        SP_TRY(cairo_prove(c, rows.data(), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_ROWS));
+        return SP_OK;
+    } catch (const std::exception& e) { sp_set_error(std::string("sp_prewarm: ") + e.what()); return SP_E_INVALID_ARG; }
+}
+
+int sp_prewarm(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int has_rc, const sp_proof_options* opt, uint32_t flags) {
+    if (!c || !opt) return SP_E_INVALID_ARG;
+    if (flags == 0) flags = SP_PREWARM_ALL;
+    ProverHolder* h = holder(c, true);
+    ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
+    // the shape first: ONE arena allocation of the real size (the small proofs below are carved out of it, nothing is re-allocated)
+    SP_TRY(h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o));
+    SP_TRY(h->prover.warm_plumbing((flags & SP_PREWARM_HOST_ROWS) != 0));
+    if (flags & SP_PREWARM_KERNELS) {
+        ProofOptionsHost small = o;
+        small.fri_number_of_queries = std::min<uint64_t>(std::max<uint64_t>(o.fri_number_of_queries, 1), 64);
+        small.grinding_factor = std::min<uint8_t>(o.grinding_factor, 16);
+        SP_TRY(warm_small_proofs(c, small));
+        SP_TRY(h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o));
+    }
+    if (flags & SP_PREWARM_CLOCKS) SP_TRY(h->prover.warm_round1());
+    return SP_OK;
+}
+
 int sp_commit_trace(sp_ctx* c, int segment, const uint8_t* rows, uint64_t n, uint32_t cols, uint8_t root_out[32]) {
     if (!c) return SP_E_INVALID_ARG;
     ProverHolder* h = holder(c, false);

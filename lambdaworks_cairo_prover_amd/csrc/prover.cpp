@@ -26,6 +26,7 @@ StarkProver::~StarkProver() {
     if (up_start_) (void)hipEventDestroy(up_start_);
     if (copy_stream_) (void)hipStreamDestroy(copy_stream_);
     if (pool_) host_pool_delete(pool_);
+    for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     if (h_pin_) (void)hipHostFree(h_pin_);
     if (h_wide_) (void)hipHostFree(h_wide_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
@@ -64,8 +65,7 @@ void StarkProver::free_all() {
     if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
     d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
-    for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
-    stage_bytes_ = 0;
+    // (the page-locked upload ring does not depend on the shape: it stays until the prover goes)
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
     alloc_bytes_ = 0;
@@ -235,6 +235,48 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     SP_TIMEPOINT("  setup: tables");
     ready_ = true;
     stage_ = 1;
+    return SP_OK;
+}
+
+// sp_prewarm, first half: everything a first proof would otherwise create on its critical path that is not device memory of the
+// shape - the page-locked read-back slots (hipHostMalloc costs ~1 ms a piece), the side stream and its events, the copy stream
+// and the upload timers, and for callers of the row-major entry points the page-locked ring and the parked gather threads.
+int StarkProver::warm_plumbing(bool host_rows) {
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    if (!h_pin_ && hipHostMalloc(&h_pin_, 4096, hipHostMallocDefault) != hipSuccess) { h_pin_ = nullptr; return SP_E_ALLOC; }
+    if (!h_wide_ && hipHostMalloc(reinterpret_cast<void**>(&h_wide_), 64, hipHostMallocDefault) != hipSuccess) { h_wide_ = nullptr; return SP_E_ALLOC; }
+    SP_TRY(ensure_side());
+    SP_TRY(ensure_upload((uint32_t)UPLOAD_MAX_GROUPS));
+    if (host_rows) SP_TRY(ensure_ring_and_pool());
+    return SP_OK;
+}
+
+// sp_prewarm, second half: round 1's kernel sequence at the REAL shape on whatever the arena holds (the transforms have no
+// data-dependent control flow and accept any 256-bit operand; the hash kernels convert and absorb whatever they read) - the
+// size-specific kernel variants take their first launch here, and the device reaches its clocks before the trace exists.
+int StarkProver::warm_round1() {
+    if (!ready_ || stage_ != 1) return SP_E_STATE;
+    SP_HIP_CHECK(hipSetDevice(c_->device));
+    SP_HIP_CHECK(hipMemsetAsync(d_trace_, 0, sizeof(fe) * n_ * C_, c_->stream));
+    for (int seg = 0; seg < 2; ++seg) {
+        const uint32_t col0 = seg ? Cm_ : 0, cols = seg ? Ca_ : Cm_;
+        if (!cols) continue;
+        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(d_coeffs_ + (uint64_t)col0 * n_, (int)logn_, cols, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
+        SP_TRY(c_->ntt->lde_coset_major(d_coeffs_ + (uint64_t)col0 * n_, d_lde_ + (uint64_t)col0 * Nl_, (int)logn_, (int)logb_, cols, n_, Nl_, (int)logG_, (int)rank_));
+        TreeBuf& t = seg ? tree_aux_ : tree_main_;
+        const MerkleHash mh = merkle_hash(false);
+        if (t.top == t.sub) {
+            SP_TRY(merkle_hash_leaves(c_->stream, d_lde_ + (uint64_t)col0 * Nl_, Nl_, cols, Nl_, t.sub, lde_order(), mh));
+            SP_TRY(merkle_reduce(c_->stream, t.sub, Nl_, nullptr, mh));
+        } else {
+            SP_TRY(merkle_hash_leaves_flat(c_->stream, d_lde_ + (uint64_t)col0 * Nl_, Nl_, cols, Nl_, reinterpret_cast<digest32*>(d_local_), lde_order(), mh));
+            SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, nullptr, mh));
+        }
+    }
+    // the composition columns' shape too: two columns, the 2n-point inverse transform
+    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(d_h12s_, (int)logn_ + 1, 1, 2 * n_, d_post_comp_));
+    SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
+    SP_TRY(wait_stream());
     return SP_OK;
 }
 

@@ -78,6 +78,9 @@ class StarkProver : public sp_deletable {
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
     int open(const std::vector<uint64_t>& iotas, Openings& out);
 
+    // sp_prewarm (capi_prove.cpp): host-side plumbing of a first proof, and round 1's kernels at the real shape on arena contents
+    int warm_plumbing(bool host_rows);
+    int warm_round1();
     // AIRs other than Cairo: frame rows of the transition constraints (reset to {0, 1} by setup)
     void set_frame_offsets(const std::vector<uint32_t>& ofs) { offsets_ = ofs; }
     uint32_t frame_rows() const { return (uint32_t)offsets_.size(); }
@@ -128,6 +131,7 @@ class StarkProver : public sp_deletable {
     UploadTimers up_ev_[UPLOAD_MAX_GROUPS];
     hipEvent_t up_start_ = nullptr;
     int ensure_upload(uint32_t groups);
+    int ensure_ring_and_pool();   // page-locked ring slots + parked gather threads of the row-major upload
     int finish_upload_stats(uint32_t groups, uint64_t bytes, double gather_ms, double host_ms, int kind);
     hipStream_t copy_stream_ = nullptr;                       // host-buffer uploads (commit_trace_pipelined)
     static constexpr int UPLOAD_SLOTS = 4;                    // ring of chunk slots: the gather may run three chunks ahead of the DMA

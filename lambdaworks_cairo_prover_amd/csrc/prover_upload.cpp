@@ -323,6 +323,27 @@ static void host_gather_block(const uint8_t* src, uint64_t n, size_t row_bytes, 
         for (uint32_t u = 0; u < cw; ++u) __builtin_memcpy(dst + ((size_t)u * n + i) * 32, s + 32 * (size_t)u, 32);
 }
 
+static size_t upload_chunk_bytes() {
+    static const size_t chunk_mb = [] { const char* e = std::getenv("SP_UPLOAD_CHUNK_MB"); return e ? (size_t)std::min(64, std::max(1, std::atoi(e))) : (size_t)32; }();
+    return chunk_mb << 20;
+}
+
+int StarkProver::ensure_ring_and_pool() {
+    // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
+    // 100 ms period and the upload is a burst of a quarter of a proof, so twice the quota's CPUs for that long stays inside it
+    // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
+    // proofs of a 64-thread gather in a 16-CPU container.
+    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
+    const size_t chunk = upload_chunk_bytes();
+    if (stage_bytes_ < chunk) {
+        for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
+        stage_bytes_ = 0;
+        for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
+        stage_bytes_ = chunk;
+    }
+    return SP_OK;
+}
+
 // interpolate_and_commit (reference prover.rs:126-159) from a row-major HOST buffer (the reference's TraceTable, trace.rs:9-13),
 // in column groups: while group g is interpolated and extended on the compute stream, the chunks of the groups behind it are
 // transposed out of the table into a small ring of page-locked slots by a few host threads (256 KB blocks off a shared counter: a
@@ -347,15 +368,10 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         done += w;
     }
     const uint32_t groups = (uint32_t)gsize.size();
-    static const size_t chunk_mb = [] { const char* e = std::getenv("SP_UPLOAD_CHUNK_MB"); return e ? (size_t)std::min(64, std::max(1, std::atoi(e))) : (size_t)32; }();
-    const size_t chunk = chunk_mb << 20;   // bytes per ring slot
+    const size_t chunk = upload_chunk_bytes();   // bytes per ring slot
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
-    // gather threads: the option, but at most twice the CPUs this process can really have.  A cgroup quota counts CPU time per
-    // 100 ms period and the upload is a burst of a quarter of a proof, so twice the quota's CPUs for that long stays inside it
-    // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
-    // proofs of a 64-thread gather in a 16-CPU container.
-    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
+    SP_TRY(ensure_ring_and_pool());
     if (!pool_bound_) {
         // Where the workers run.  The ring is page-locked memory and lives on the GPU's NUMA node; the caller's table lives where
         // the caller's threads ran.  On the two-socket hosts of the pool half of the boxes have the two on different nodes, and a
@@ -381,12 +397,6 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         if (!cpus.empty()) pool_->bind(cpus);
     }
     SP_TRY(ensure_upload(groups));
-    if (stage_bytes_ < chunk) {
-        for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
-        stage_bytes_ = 0;
-        for (auto& p : h_stage_) if (hipHostMalloc(&p, chunk, hipHostMallocDefault) != hipSuccess) { sp_set_error("commit_trace: pinned staging allocation failed"); return SP_E_ALLOC; }
-        stage_bytes_ = chunk;
-    }
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;

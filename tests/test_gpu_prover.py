@@ -210,3 +210,27 @@ def test_column_entry_point_argument_checks(hip_ctx):
         lib.sp_host_free(buf)
     assert hip_ctx.cairo_prove_columns(cols_be, n, c, run.public_inputs_c, opt) == want      # pageable columns
     assert "PAGEABLE" in hip_ctx.last_upload_stats()["kind"]
+
+
+def test_prewarm_then_prove_gives_the_same_bytes(hip_lib, oracle):
+    """sp_prewarm (arena, tables, plumbing, three small proofs, round 1's kernels at the real shape on arena contents) changes
+    nothing a proof computes: the proofs that follow - every entry point, the warmed shape and another one - are the oracle's."""
+    opts = (4, 5, 3, 4)
+    opt = api.ProofOptions(*opts)
+    run = api.CairoRun.fibonacci(9000)           # 2^16 rows: the row-major call takes the upload pipeline
+    trace = run.main_trace()
+    want = oracle.cairo_prove(trace, run.public_inputs_c, opts)
+    with api.Context(device=0) as ctx:
+        ctx.prewarm(run.n_rows, 34, 18, False, opt)
+        assert ctx.cairo_prove_run(run, opt) == want
+        assert ctx.cairo_prove(trace, run.public_inputs_c, opt) == want
+        assert ctx.last_upload_stats()["kind"].startswith("row-major")
+        ctx.prewarm(run.n_rows, 34, 18, False, opt, api.SP_PREWARM_CLOCKS)      # again, between proofs of the same shape
+        assert ctx.cairo_prove_run(run, opt) == want
+        small = api.CairoRun.fibonacci(100)
+        assert ctx.cairo_prove(small.main_trace(), small.public_inputs_c, api.ProofOptions(8, 3, 3, 1)) == \
+            oracle.cairo_prove(small.main_trace(), small.public_inputs_c, (8, 3, 3, 1))
+    with api.Context(device=0) as ctx:           # a shape smaller than the pre-warm's own small proofs, 43-column layout announced
+        ctx.prewarm(1 << 7, 34, 18, False, api.ProofOptions(2, 3, 3, 1))
+        tiny = api.CairoRun.fibonacci(10)
+        assert ctx.cairo_prove_run(tiny, api.ProofOptions(2, 3, 3, 1)) == oracle.cairo_prove(tiny.main_trace(), tiny.public_inputs_c, (2, 3, 3, 1))
