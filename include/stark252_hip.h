@@ -131,11 +131,15 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  leaf of a row of columns = hash_many(row), leaf of a single-element tree (FRI layers) =
  *                                  hash_single(x).  Transcript and grinding stay Keccak; the proof layout does not change.
  *                                  Such proofs are checked with sp_cairo_verify_backend / sp_air_verify_backend.
+ *   SP_OPT_DEVICE_TRACE (1)        sp_cairo_prove_run builds the main trace ON THE DEVICE from the run's register states and memory
+ *                                  (build_main_trace, src/cairo/execution_trace.rs:57-87: 24 B per step + 32 B per memory cell cross
+ *                                  PCIe instead of the n x cols table); 0: the run's host table goes up column group by column group.
  *   SP_OPT_MERKLE_ONE_COLUMN_ROWS (0)  which Poseidon tree sp_merkle_build / sp_merkle_build_dev build for fe_per_leaf == 1: 0 the
  *                                  single-element tree of a FRI layer (leaf = hash_single(x), fri_commitment.rs:39), 1 the tree over
  *                                  rows of ONE column (leaf = hash_many over one element) - what the prover commits a one-column trace
  *                                  segment with (prover.rs:96-104 batch_commit).  Keccak256 trees have one leaf form; no effect there. */
-enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 5 };
+enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 5,
+       SP_OPT_DEVICE_TRACE = 6 };
 enum { SP_MERKLE_KECCAK256 = 0, SP_MERKLE_POSEIDON = 1 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 
@@ -303,7 +307,8 @@ int sp_host_alloc(uint64_t bytes, void** out);
 void sp_host_free(void* p);
 void sp_free(void* p);
 /* How the main trace of the last proof reached the device: out = {kind (0: one copy / resident, 1: row-major host buffer gathered
- * into column groups by host threads, 2: DMA of page-locked host columns, 3: host columns in pageable memory), column groups, bytes, host ms until the last chunk had been gathered and sent (kind 1), bytes over that time in GB/s, DMA ms
+ * into column groups by host threads, 2: DMA of page-locked host columns, 3: host columns in pageable memory, 4: register states +
+ * memory of a run from page-locked memory, trace built on the device, 5: the same from pageable memory), column groups, bytes, host ms until the last chunk had been gathered and sent (kind 1), bytes over that time in GB/s, DMA ms
  * (sum over the groups), DMA GB/s, exposed ms (how long the compute stream waited for column groups in total), longest wait
  * for one group ms, host wall ms of the upload loop}. */
 int sp_last_upload_stats(sp_ctx* ctx, double out[10]);
@@ -389,9 +394,15 @@ int sp_cairo_run_public_inputs(const sp_cairo_run* run, sp_cairo_public_inputs* 
  * HIP runtime was usable when the run was built).  The pointer lives as long as the run. */
 int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_t* n_rows, uint32_t* n_cols, int* pinned_out);
 /* generate_prover_args + generate_cairo_proof (reference src/cairo/runner/run.rs:242-263, src/cairo/air.rs:1165-1171) for a run
- * of this front-end: the run's own column-major page-locked trace goes up by DMA, column group by column group, behind the
- * transforms of the groups before it (sp_cairo_prove_columns on sp_cairo_run_columns + sp_cairo_run_public_inputs). */
+ * of this front-end.  By default the register states and the memory of the run go up and the device writes the main trace itself
+ * (SP_OPT_DEVICE_TRACE; the host never builds the table); with the option off - or for a run whose memory is not one flat array -
+ * the run's own column-major page-locked table goes up by DMA, column group by column group, behind the transforms of the groups
+ * before it (sp_cairo_prove_columns on sp_cairo_run_columns + sp_cairo_run_public_inputs). */
 int sp_cairo_prove_run(sp_ctx* ctx, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len);
+/* build_main_trace (reference src/cairo/execution_trace.rs:57-87) on the device: the table sp_cairo_prove_run proves (SP_OPT_DEVICE_TRACE),
+ * downloaded as sp_cairo_run_main_trace would return it (row-major n x cols, `fe_encoding`) - for callers that want the table, and
+ * for the parity tests of the device builder. */
+int sp_cairo_run_main_trace_dev(sp_ctx* ctx, const sp_cairo_run* run, int fe_encoding, uint8_t* out);
 
 /* verify_cairo_proof (reference src/cairo/air.rs:1176-1182, src/starks/verifier.rs:559-657) on the host CPU: returns 1 when the
  * proof is accepted, 0 when it is rejected or malformed. Ships with the library so that proofs of shapes without a golden

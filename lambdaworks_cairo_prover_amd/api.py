@@ -179,7 +179,8 @@ class Context:
         v = (ctypes.c_double * 10)()
         check(self._lib.sp_last_upload_stats(self._h, v))
         kinds = {0: "single copy / resident", 1: "row-major host buffer, gathered by host threads", 2: "host columns, DMA from page-locked memory",
-                 3: "host columns in PAGEABLE memory (staged by the runtime)"}
+                 3: "host columns in PAGEABLE memory (staged by the runtime)", 4: "run image (register states + memory, page-locked), trace built on the device",
+                 5: "run image in PAGEABLE memory, trace built on the device"}
         return {"kind": kinds.get(int(v[0]), "?"), "groups": int(v[1]), "bytes": int(v[2]), "gather_ms": round(v[3], 3), "gather_gbs": round(v[4], 1),
                 "dma_ms": round(v[5], 3), "dma_gbs": round(v[6], 1), "exposed_ms": round(v[7], 3), "max_stall_ms": round(v[8], 3), "host_ms": round(v[9], 3)}
 
@@ -317,6 +318,12 @@ class CairoRun:
     def main_trace(self, fe_encoding=SP_FE_CANON_BE):
         out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
         check(self._lib.sp_cairo_run_main_trace(self._h, fe_encoding, _u8p(out)))
+        return out
+
+    def main_trace_dev(self, ctx, fe_encoding=SP_FE_CANON_BE):
+        """sp_cairo_run_main_trace_dev: the same table, built by the device from the run's register states and memory."""
+        out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
+        check(self._lib.sp_cairo_run_main_trace_dev(ctx._h, self._h, fe_encoding, _u8p(out)))
         return out
 
     def columns(self):
@@ -556,7 +563,7 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 1, 2, 3, 4, 5
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS, SP_OPT_DEVICE_TRACE = 1, 2, 3, 4, 5, 6
 SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
 SP_PREWARM_KERNELS, SP_PREWARM_CLOCKS, SP_PREWARM_HOST_ROWS, SP_PREWARM_ALL = 1, 2, 4, 7
 
@@ -586,6 +593,6 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
             "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

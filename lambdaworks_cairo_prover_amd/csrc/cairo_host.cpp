@@ -199,13 +199,17 @@ static void host_batch_inverse_nonzero(std::vector<fe>& v) {
     for (size_t i = v.size(); i-- > 0;) { const fe x = v[i]; v[i] = fe_mul(inv, pre[i]); inv = fe_mul(inv, x); }
 }
 
-void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TraceColumns& T) {
+// Pass A of build_main_trace: everything that decides the SHAPE of the trace (and everything that can fail), without touching the
+// table - the four memory addresses and three offsets of every step, the unused range-check values and memory addresses that
+// become extra rows, the row count.  Validates what the fill (host or device) relies on: every instruction decodes, every
+// operand cell exists, jnz rows have the flags the reference demands.
+void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TracePlan& P) {
     const size_t steps = regs.size();
     if (steps == 0) throw std::runtime_error("empty register trace");
     const MemorySegment* rc_seg = pub.segment(0);
-    const size_t cols = rc_seg ? 43 : 34;
-    const fe zero = fe_zero(), one = fe_one();
-    // ---- pass A: the four memory addresses and three offsets of every step (what decides the number of rows)
+    P = TracePlan();
+    P.steps = steps;
+    P.cols = rc_seg ? 43 : 34;
     std::vector<uint64_t> addr(4 * steps);    // [step][pc, dst, op0, op1]
     std::vector<uint16_t> off(3 * steps);     // [step][dst, op0, op1] (biased)
     host_parallel_for(steps, 4096, [&](size_t b, size_t e) {
@@ -214,13 +218,18 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
             const Decoded d = decode(mem_at(mem, r.pc));
             const uint64_t dst_addr = add_signed(d.dst_reg ? r.fp : r.ap, d.off_dst);
             const uint64_t op0_addr = add_signed(d.op0_reg ? r.fp : r.ap, d.off_op0);
-            const uint64_t op1_base = d.op1_src == 0 ? fe_low_u64(mem_at(mem, op0_addr)) : d.op1_src == 1 ? r.pc : d.op1_src == 2 ? r.fp : r.ap;
-            addr[4 * i] = r.pc; addr[4 * i + 1] = dst_addr; addr[4 * i + 2] = op0_addr; addr[4 * i + 3] = add_signed(op1_base, d.off_op1);
+            const fe& op0 = mem_at(mem, op0_addr);
+            const uint64_t op1_base = d.op1_src == 0 ? fe_low_u64(op0) : d.op1_src == 1 ? r.pc : d.op1_src == 2 ? r.fp : r.ap;
+            const uint64_t op1_addr = add_signed(op1_base, d.off_op1);
+            (void)mem_at(mem, dst_addr);
+            (void)mem_at(mem, op1_addr);
+            if (d.pc_update == 4 && !(d.res_logic == 0 && d.opcode == 0 && d.ap_update != 1)) throw std::runtime_error("Undefined Behavior");   // execution_trace.rs:382-440
+            addr[4 * i] = r.pc; addr[4 * i + 1] = dst_addr; addr[4 * i + 2] = op0_addr; addr[4 * i + 3] = op1_addr;
             off[3 * i] = (uint16_t)d.off_dst; off[3 * i + 1] = (uint16_t)d.off_op0; off[3 * i + 2] = (uint16_t)d.off_op1;
         }
     });
     // get_rc_holes (execution_trace.rs:136-185): every value strictly between the smallest and the largest offset that no step uses
-    std::vector<uint16_t> missing;
+    std::vector<uint16_t>& missing = P.missing;
     {
         std::vector<uint8_t> seen(65536, 0);
         for (uint16_t v : off) seen[v] = 1;
@@ -235,11 +244,13 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
     }
     // get_memory_holes (execution_trace.rs:195-255): the addresses above the public memory that lie between two accessed
     // addresses and are not accessed themselves, in increasing order
-    std::vector<uint64_t> holes;
+    std::vector<uint64_t>& holes = P.holes;
+    uint64_t hi_addr = 0;
     {
         const uint64_t codelen = pub.public_memory.size();
         uint64_t lo = ~0ULL, hi = 0;
         for (uint64_t a : addr) { lo = std::min(lo, a); hi = std::max(hi, a); }
+        hi_addr = hi;
         // A run's memory is (nearly) continuous, so [lo, hi] is a small multiple of the 4 * steps accesses: presence bitmap.  A sparse
         // range (an odd or hostile dump) takes the sorted formulation, whose cost is O(accesses) before any hole is enumerated; and a
         // dump whose holes could never fit a trace is refused before gigabytes of them are collected.
@@ -268,12 +279,28 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
             }
         }
     }
-    const size_t r_rc = steps, r_holes = r_rc + missing.size() / 3, r_dummy = r_holes + (holes.size() + 3) / 4,
-                 r_pad = r_dummy + (pub.public_memory.size() >> 2) + 1;
+    if (rc_seg) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624): the first rows carry the range-checked values
+        P.rc_start = rc_seg->start;
+        P.rc_count = std::min<uint64_t>(rc_seg->end > rc_seg->start ? rc_seg->end - rc_seg->start : 0, steps);
+        for (uint64_t k = 0; k < P.rc_count; ++k) (void)mem_at(mem, P.rc_start + k);
+        if (P.rc_count) hi_addr = std::max(hi_addr, P.rc_start + P.rc_count - 1);
+    }
+    P.r_rc = steps; P.r_holes = P.r_rc + missing.size() / 3; P.r_dummy = P.r_holes + (holes.size() + 3) / 4;
+    const size_t r_pad = P.r_dummy + (pub.public_memory.size() >> 2) + 1;
     size_t n = 1;
     while (n < r_pad) n <<= 1;
+    P.n = n;
+    P.mem_cells = hi_addr + 1;
+    P.dense = mem.sparse.empty() && P.mem_cells <= mem.dense.size();   // every cell a row reads lives in the flat array
+}
+
+// Pass B: build_cairo_execution_trace (execution_trace.rs:261-356) and the rows behind the steps, into a host table.
+void fill_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, const TracePlan& P, TraceColumns& T) {
+    const size_t steps = P.steps, cols = P.cols, n = P.n, r_rc = P.r_rc, r_holes = P.r_holes, r_dummy = P.r_dummy;
+    const std::vector<uint16_t>& missing = P.missing;
+    const std::vector<uint64_t>& holes = P.holes;
+    const fe zero = fe_zero(), one = fe_one();
     T.allocate(n, cols);
-    // ---- pass B: build_cairo_execution_trace (execution_trace.rs:261-356), one row per step
     host_parallel_for(steps, 4096, [&](size_t b, size_t e) {
         std::vector<size_t> jnz_rows;
         std::vector<fe> jnz_dst;
@@ -283,9 +310,12 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
             const Decoded d = decode(inst);
             for (int k = 0; k < 15; ++k) T.at(i, k) = ((d.flags >> k) & 1) ? one : zero;
             T.at(i, 15) = zero;
-            const uint64_t dst_addr = addr[4 * i + 1], op0_addr = addr[4 * i + 2], op1_addr = addr[4 * i + 3];
+            const uint64_t dst_addr = add_signed(d.dst_reg ? r.fp : r.ap, d.off_dst);
+            const uint64_t op0_addr = add_signed(d.op0_reg ? r.fp : r.ap, d.off_op0);
             fe dst = mem_at(mem, dst_addr);
             fe op0 = mem_at(mem, op0_addr);
+            const uint64_t op1_base = d.op1_src == 0 ? fe_low_u64(op0) : d.op1_src == 1 ? r.pc : d.op1_src == 2 ? r.fp : r.ap;
+            const uint64_t op1_addr = add_signed(op1_base, d.off_op1);
             const fe op1 = mem_at(mem, op1_addr);
             fe res;
             bool deferred = false;
@@ -315,11 +345,10 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
             T.at(i, 31) = fe_mul(T.at(i, 30), jnz_dst[k]);
         }
     });
-    if (rc_seg) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624)
-        const size_t cnt = (size_t)std::min<uint64_t>(rc_seg->end > rc_seg->start ? rc_seg->end - rc_seg->start : 0, steps);
-        host_parallel_for(cnt, 4096, [&](size_t b, size_t e) {
+    if (P.rc_count) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624)
+        host_parallel_for(P.rc_count, 4096, [&](size_t b, size_t e) {
             for (size_t k = b; k < e; ++k) {
-                const fe& v = mem_at(mem, rc_seg->start + k);
+                const fe& v = mem_at(mem, P.rc_start + k);
                 const fe raw = fe_from_mont(v);
                 for (int c = 0; c < 8; ++c) T.at(k, 34 + c) = fe_from_u64((raw.v[c / 2] >> (16 * (c & 1))) & 0xffff);
                 T.at(k, 42) = v;
@@ -352,6 +381,50 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
             for (size_t c = b; c < e; ++c) std::fill(&T.at(r_dummy, c), &T.at(0, c) + n, last[c]);
         });
     }
+}
+
+void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TraceColumns& T) {
+    TracePlan P;
+    plan_main_trace(regs, mem, pub, P);
+    fill_main_trace(regs, mem, P, T);
+}
+
+// The inputs of the device's trace builder in one buffer (page-locked when the process already drives a device, so that it crosses
+// PCIe as one plain DMA): register states, the memory cells the rows read, the two hole lists.
+void TraceImage::release() {
+    if (base) { if (pinned) (void)hipHostFree(base); else std::free(base); }
+    base = nullptr; bytes = 0; pinned = false;
+}
+void TraceImage::build(const std::vector<RegisterState>& regs, const CairoMemory& mem, const TracePlan& P) {
+    release();
+    if (!P.dense) return;
+    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
+    off_regs = 0;
+    off_mem = up(off_regs + 24 * (uint64_t)P.steps);
+    off_missing = up(off_mem + 32 * P.mem_cells);
+    off_holes = up(off_missing + 2 * (uint64_t)P.missing.size());
+    bytes = up(off_holes + 8 * (uint64_t)P.holes.size());
+    void* p = hip_runtime_in_use() ? alloc_pinned(bytes) : nullptr;
+    if (p) pinned = true;
+    else if (posix_memalign(&p, 4096, bytes) != 0 || !p) throw std::bad_alloc();
+    base = static_cast<uint8_t*>(p);
+    static_assert(sizeof(RegisterState) == 24, "register states are uploaded as they are");
+    const uint8_t* rsrc = reinterpret_cast<const uint8_t*>(regs.data());
+    host_parallel_for(24 * (size_t)P.steps, 1 << 22, [&](size_t b, size_t e) { std::memcpy(base + off_regs + b, rsrc + b, e - b); });
+    const uint8_t* msrc = reinterpret_cast<const uint8_t*>(mem.dense.data());
+    host_parallel_for(32 * (size_t)P.mem_cells, 1 << 22, [&](size_t b, size_t e) { std::memcpy(base + off_mem + b, msrc + b, e - b); });
+    if (!P.missing.empty()) std::memcpy(base + off_missing, P.missing.data(), 2 * P.missing.size());
+    if (!P.holes.empty()) std::memcpy(base + off_holes, P.holes.data(), 8 * P.holes.size());
+}
+bool TraceImage::try_pin() {
+    std::lock_guard<std::mutex> lk(pin_mutex);
+    if (pinned || !base) return pinned;
+    uint8_t* p = static_cast<uint8_t*>(alloc_pinned(bytes));
+    if (!p) return false;
+    host_parallel_for(bytes, 1 << 22, [&](size_t b, size_t e) { std::memcpy(p + b, base + b, e - b); });
+    std::free(base);          // (the image's address is never handed out)
+    base = p; pinned = true;
+    return true;
 }
 
 // cairo-run's non-proof-mode layout (reference src/cairo/runner/run.rs:64-240 drives cairo-vm 0.6.0 that way): program at

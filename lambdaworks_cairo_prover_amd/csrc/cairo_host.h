@@ -106,6 +106,35 @@ bool parse_memory_le(const uint8_t* bytes, size_t len, CairoMemory& out);
 PublicInputs public_inputs_from_regs_and_mem(const std::vector<RegisterState>& regs, const CairoMemory& mem,
                                              size_t program_size, const std::vector<MemorySegment>& segments);
 
+// What build_main_trace decides before it writes a single row (pass A): shape, extra rows, and that every cell it will read exists.
+struct TracePlan {
+    size_t steps = 0, cols = 0, n = 0;          // cols = 34, or 43 with the range-check builtin; n = rows, a power of two
+    size_t r_rc = 0, r_holes = 0, r_dummy = 0;  // first row of: range-check holes, memory holes, public-memory dummies + padding
+    std::vector<uint16_t> missing;              // unused offsets, three per row, padded with the largest one (execution_trace.rs:136-185)
+    std::vector<uint64_t> holes;                // unused addresses, four per row (execution_trace.rs:195-255)
+    uint64_t rc_start = 0, rc_count = 0;        // rows 0 .. rc_count-1 carry the range-checked values at rc_start + row (rc builtin)
+    uint64_t mem_cells = 0;                     // 1 + the highest address any row reads
+    bool dense = false;                         // all of them live in CairoMemory::dense: the device builder can index the memory
+};
+void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TracePlan& plan);
+void fill_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, const TracePlan& plan, TraceColumns& out);
+
+// Inputs of the device-side builder (csrc/trace_kernels.hip): [register states 24 B x steps][memory 32 B x mem_cells][missing
+// offsets u16][memory holes u64], each part 256-byte aligned, in one host buffer.
+struct TraceImage {
+    uint8_t* base = nullptr;
+    uint64_t bytes = 0, off_regs = 0, off_mem = 0, off_missing = 0, off_holes = 0;
+    bool pinned = false;
+    std::mutex pin_mutex;
+    TraceImage() = default;
+    TraceImage(const TraceImage&) = delete;
+    TraceImage& operator=(const TraceImage&) = delete;
+    ~TraceImage() { release(); }
+    void build(const std::vector<RegisterState>& regs, const CairoMemory& mem, const TracePlan& plan);   // nothing when !plan.dense
+    bool try_pin();
+    void release();
+};
+
 // execution_trace.rs:57-87. Builds the n x cols main trace (cols = 34, or 43 with the rc builtin), n a power of two, column-major
 // in `out`; sets pub.range_check_min/max. Throws std::runtime_error on undecodable instructions.
 void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& mem, PublicInputs& pub, TraceColumns& out);

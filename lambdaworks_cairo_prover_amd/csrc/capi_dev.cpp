@@ -110,6 +110,9 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             if (value != SP_MERKLE_KECCAK256 && value != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
             c->opt_merkle_backend = (int)value;
             break;
+        case SP_OPT_DEVICE_TRACE:
+            c->opt_device_trace = value != 0;
+            return SP_OK;                     // (shapes no prover buffer)
         case SP_OPT_MERKLE_ONE_COLUMN_ROWS:
             c->opt_merkle_one_column_rows = value != 0;
             return SP_OK;                     // (shapes no prover buffer)

@@ -9,12 +9,28 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <mutex>
+#include <exception>
 
 struct sp_cairo_run {
     std::vector<sp::RegisterState> regs;
     sp::CairoMemory mem;
     sp::PublicInputs pub;
-    sp::TraceColumns main_trace;   // column-major, device layout (pinned when the HIP runtime provides it)
+    sp::TracePlan plan;            // shape and extra rows of the main trace (pass A of build_main_trace: validated at run creation)
+    sp::TraceImage image;          // register states + memory + hole lists in one buffer: what the device-side builder uploads
+    // The n x cols table itself, column-major in the device layout (pinned when the HIP runtime provides it).  Built on first use:
+    // sp_cairo_prove_run builds the trace ON THE DEVICE from `image` (70 MB instead of 1.1 GB at 2^20 rows), so a caller that only
+    // proves never pays for the host table; sp_cairo_run_main_trace / sp_cairo_run_columns and the host-column proof path do.
+    sp::TraceColumns main_trace;
+    std::once_flag main_trace_once;
+    std::exception_ptr main_trace_error;
+    const sp::TraceColumns& host_trace() {
+        std::call_once(main_trace_once, [this] {
+            try { sp::fill_main_trace(regs, mem, plan, main_trace); } catch (...) { main_trace_error = std::current_exception(); }
+        });
+        if (main_trace_error) std::rethrow_exception(main_trace_error);
+        return main_trace;
+    }
     size_t n_rows = 0, n_cols = 0;
     // flattened views handed out by sp_cairo_run_public_inputs
     std::vector<uint8_t> seg_types;
@@ -24,7 +40,13 @@ struct sp_cairo_run {
 
 namespace sp {   // for capi_prove.cpp (sp_cairo_prove_run)
 const PublicInputs& cairo_run_public_inputs(const sp_cairo_run* run) { return run->pub; }
-const TraceColumns& cairo_run_columns(const sp_cairo_run* run) { return run->main_trace; }
+const TraceColumns& cairo_run_columns(const sp_cairo_run* run) { return const_cast<sp_cairo_run*>(run)->host_trace(); }
+// (nullptr when the memory of the run is not one flat array: the caller falls back to the host table)
+bool cairo_run_device_inputs(const sp_cairo_run* run, const TracePlan** plan, TraceImage** image) {
+    if (!run->image.base) return false;
+    *plan = &run->plan; *image = &const_cast<sp_cairo_run*>(run)->image;
+    return true;
+}
 }
 static thread_local std::string g_last_error;
 void sp_set_error(const std::string& s) { g_last_error = s; }
@@ -96,8 +118,11 @@ int sp_fe_from_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
 
 static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out, const std::vector<sp::MemorySegment>& segments = {}) {
     r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, segments);
-    sp::build_main_trace(r->regs, r->mem, r->pub, r->main_trace);
-    r->n_rows = r->main_trace.n_rows; r->n_cols = r->main_trace.n_cols;
+    sp::plan_main_trace(r->regs, r->mem, r->pub, r->plan);      // shape, range_check_min / max, every check the fill relies on
+    r->image.build(r->regs, r->mem, r->plan);
+    r->n_rows = r->plan.n; r->n_cols = r->plan.cols;
+    static const bool eager = std::getenv("SP_RUN_EAGER_TRACE") != nullptr;
+    if (eager || !r->image.base) (void)r->host_trace();         // (no flat memory: the host table is the only form there is)
     *out = r;
     return SP_OK;
 }
@@ -164,7 +189,9 @@ int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_co
 int sp_cairo_run_main_trace(const sp_cairo_run* run, int enc, uint8_t* out) {
     if (!run || !out || (enc != SP_FE_CANON_BE && enc != SP_FE_MONT_LIMBS)) return SP_E_INVALID_ARG;
     // row-major n x cols in the ABI encoding (what the reference's TraceTable holds, trace.rs:9-13) from the column-major store
-    const sp::TraceColumns& T = run->main_trace;
+    const sp::TraceColumns* Tp = nullptr;
+    try { Tp = &const_cast<sp_cairo_run*>(run)->host_trace(); } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_PROGRAM; }
+    const sp::TraceColumns& T = *Tp;
     sp::host_parallel_for(T.n_rows, 1024, [&](size_t b, size_t e) {
         for (size_t i = b; i < e; ++i)
             for (size_t c = 0; c < T.n_cols; ++c) {
@@ -181,9 +208,11 @@ int sp_cairo_run_main_trace(const sp_cairo_run* run, int enc, uint8_t* out) {
 int sp_cairo_run_columns(const sp_cairo_run* run, const void** cols_out, uint64_t* n_rows, uint32_t* n_cols, int* pinned) {
     if (!run || !cols_out) return SP_E_INVALID_ARG;
     bool is_pinned = false;
-    *cols_out = run->main_trace.current(&is_pinned);
-    if (n_rows) *n_rows = run->main_trace.n_rows;
-    if (n_cols) *n_cols = (uint32_t)run->main_trace.n_cols;
+    const sp::TraceColumns* Tp = nullptr;
+    try { Tp = &const_cast<sp_cairo_run*>(run)->host_trace(); } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_PROGRAM; }
+    *cols_out = Tp->current(&is_pinned);
+    if (n_rows) *n_rows = Tp->n_rows;
+    if (n_cols) *n_cols = (uint32_t)Tp->n_cols;
     if (pinned) *pinned = is_pinned ? 1 : 0;
     return SP_OK;
 }

@@ -7,6 +7,7 @@
 namespace sp {   // capi_host.cpp
 const PublicInputs& cairo_run_public_inputs(const sp_cairo_run* run);
 const TraceColumns& cairo_run_columns(const sp_cairo_run* run);
+bool cairo_run_device_inputs(const sp_cairo_run* run, const TracePlan** plan, TraceImage** image);
 }
 using namespace sp;
 
@@ -27,7 +28,7 @@ int sp_prove_setup(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols,
     return h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o);
 }
 
-// A small VALID Cairo proof (fib(1100): 2^13 rows) through the three input forms on this context: every kernel family of the proof
+// A small VALID Cairo proof (fib(1100): 2^13 rows) through the four input forms on this context: every kernel family of the proof
 // path - transforms, hashing, sorts and scans of the auxiliary trace, constraint check and composition, out-of-domain folds, DEEP,
 // the FRI chain, grinding, openings, the decode / transpose kernels of the uploads - takes its first launch (code-object load,
 // kernel-object set-up) here instead of inside the caller's first proof.
@@ -39,7 +40,9 @@ static int warm_small_proofs(sp_ctx* c, const ProofOptionsHost& o) {
         run_program_plain(prog, regs, mem, 1u << 20);
         PublicInputs pub = public_inputs_from_regs_and_mem(regs, mem, prog.size(), {});
         TraceColumns T;
-        build_main_trace(regs, mem, pub, T);
+        TracePlan plan;
+        plan_main_trace(regs, mem, pub, plan);
+        fill_main_trace(regs, mem, plan, T);
         const uint64_t n = T.n_rows;
         const uint32_t cols = (uint32_t)T.n_cols;
         std::vector<uint8_t> bytes;
@@ -55,6 +58,13 @@ static int warm_small_proofs(sp_ctx* c, const ProofOptionsHost& o) {
         for (uint64_t i = 0; i < n; ++i)
             for (uint32_t j = 0; j < cols; ++j) std::memcpy(&rows[(i * cols + j) * 32], &enc_cols[((size_t)j * n + i) * 32], 32);
         SP_TRY(cairo_prove(c, rows.data(), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_ROWS));
+        // (4) the run itself: register states + memory up, the table written by the device (sp_cairo_prove_run's default)
+        TraceImage image;
+        image.build(regs, mem, plan);
+        if (image.base) {
+            StarkProver::TraceBuildInput in{&plan, &image};
+            SP_TRY(cairo_prove(c, reinterpret_cast<const uint8_t*>(&in), n, cols, pub, o, bytes, ms, StarkProver::TRACE_DEVICE_BUILD));
+        }
         return SP_OK;
     } catch (const std::exception& e) { sp_set_error(std::string("sp_prewarm: ") + e.what()); return SP_E_INVALID_ARG; }
 }
@@ -216,12 +226,62 @@ int sp_cairo_prove_columns(sp_ctx* c, const uint8_t* main_trace_cols, uint64_t n
 }
 int sp_cairo_prove_run(sp_ctx* c, const sp_cairo_run* run, const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len) {
     if (!run || !c) return SP_E_INVALID_ARG;
-    // a run built before this process had a context keeps its trace in pageable memory: copied into page-locked memory once (the
-    // pageable copy stays valid until sp_cairo_run_free - its address may have been handed out by sp_cairo_run_columns)
-    const_cast<TraceColumns&>(cairo_run_columns(run)).try_pin();
-    const TraceColumns& T = cairo_run_columns(run);
-    return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.current()), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
-                            proof_len, StarkProver::TRACE_HOST_COLUMNS, -1, T.n_rows);
+    try {
+        // The trace built on the device from the run's register states and memory (SP_OPT_DEVICE_TRACE, the default): 24 B per step and
+        // 32 B per memory cell cross PCIe instead of the n x cols table, and the host never builds that table at all.
+        const TracePlan* plan = nullptr;
+        TraceImage* image = nullptr;
+        if (c->opt_device_trace && cairo_run_device_inputs(run, &plan, &image)) {
+            StarkProver::TraceBuildInput in{plan, image};
+            return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(&in), plan->n, (uint32_t)plan->cols, cairo_run_public_inputs(run), opt, proof_out,
+                                    proof_len, StarkProver::TRACE_DEVICE_BUILD);
+        }
+        // the host table (built on first use), column-major in the device layout.  A run built before this process had a context keeps
+        // it in pageable memory: copied into page-locked memory once (the pageable copy stays valid until sp_cairo_run_free - its
+        // address may have been handed out by sp_cairo_run_columns)
+        const_cast<TraceColumns&>(cairo_run_columns(run)).try_pin();
+        const TraceColumns& T = cairo_run_columns(run);
+        return cairo_prove_impl(c, reinterpret_cast<const uint8_t*>(T.current()), T.n_rows, (uint32_t)T.n_cols, cairo_run_public_inputs(run), opt, proof_out,
+                                proof_len, StarkProver::TRACE_HOST_COLUMNS, -1, T.n_rows);
+    } catch (const std::exception& e) { sp_set_error(e.what()); return SP_E_PROGRAM; }
+}
+
+// build_main_trace on the device, for callers (and tests) that want the table itself: out = row-major n x cols in `fe_encoding`,
+// what sp_cairo_run_main_trace produces on the host.
+int sp_cairo_run_main_trace_dev(sp_ctx* c, const sp_cairo_run* run, int enc, uint8_t* out) {
+    if (!c || !run || !out || (enc != SP_FE_CANON_BE && enc != SP_FE_MONT_LIMBS)) return SP_E_INVALID_ARG;
+    const TracePlan* plan = nullptr;
+    TraceImage* image = nullptr;
+    if (!cairo_run_device_inputs(run, &plan, &image)) { sp_set_error("sp_cairo_run_main_trace_dev: the memory of this run is not one flat array"); return SP_E_UNSUPPORTED; }
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    const TracePlan& P = *plan;
+    struct Buf { void* p = nullptr; ~Buf() { if (p) (void)hipFree(p); } } img, table, enc_dev, flag;
+    const size_t table_bytes = (size_t)P.n * P.cols * 32;
+    if (hipMalloc(&img.p, image->bytes + main_trace_scratch_bytes(P.steps)) != hipSuccess || hipMalloc(&table.p, table_bytes) != hipSuccess ||
+        hipMalloc(&enc_dev.p, table_bytes) != hipSuccess || hipMalloc(&flag.p, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return SP_E_ALLOC; }
+    uint8_t* stage = static_cast<uint8_t*>(img.p);
+    SP_HIP_CHECK(hipMemcpyAsync(stage, image->base, image->bytes, hipMemcpyHostToDevice, c->stream));
+    SP_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
+    MainTraceArgs a{};
+    a.regs = reinterpret_cast<const uint64_t*>(stage + image->off_regs);
+    a.mem = reinterpret_cast<const fe*>(stage + image->off_mem);
+    a.missing = reinterpret_cast<const uint16_t*>(stage + image->off_missing);
+    a.holes = reinterpret_cast<const uint64_t*>(stage + image->off_holes);
+    a.steps = P.steps; a.cells = P.mem_cells; a.n = P.n; a.r_rc = P.r_rc; a.r_holes = P.r_holes; a.r_dummy = P.r_dummy; a.n_holes = P.holes.size();
+    a.rc_start = P.rc_start; a.rc_count = P.rc_count; a.cols = (uint32_t)P.cols; a.trace = static_cast<fe*>(table.p);
+    SP_TRY(cairo_main_trace_device(c->stream, a, stage + image->bytes, static_cast<int*>(flag.p)));
+    SP_TRY(encode_elements(c->stream, enc, static_cast<const fe*>(table.p), (uint64_t)P.n * P.cols, static_cast<uint8_t*>(enc_dev.p)));
+    std::vector<uint8_t> cols_host(table_bytes);
+    int f = 0;
+    SP_HIP_CHECK(hipMemcpyAsync(cols_host.data(), enc_dev.p, table_bytes, hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipMemcpyAsync(&f, flag.p, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    if (f) { sp_set_error("sp_cairo_run_main_trace_dev: a row reads beyond the memory image"); return SP_E_INVALID_ARG; }
+    host_parallel_for(P.n, 1024, [&](size_t b, size_t e) {
+        for (size_t i = b; i < e; ++i)
+            for (size_t j = 0; j < P.cols; ++j) std::memcpy(out + (i * P.cols + j) * 32, &cols_host[(j * P.n + i) * 32], 32);
+    });
+    return SP_OK;
 }
 
 int sp_last_upload_stats(sp_ctx* c, double out[10]) {

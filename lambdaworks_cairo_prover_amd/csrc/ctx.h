@@ -37,6 +37,7 @@ struct sp_ctx {
     bool opt_shard_interpolation = true;
     uint32_t opt_upload_threads = 24;
     int opt_merkle_backend = SP_MERKLE_KECCAK256;
+    bool opt_device_trace = true;             // sp_cairo_prove_run builds the main trace on the device from the run's registers and memory
     bool opt_merkle_one_column_rows = false;   // sp_merkle_build* with fe_per_leaf == 1 under Poseidon: row tree instead of the FRI-layer tree
     sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

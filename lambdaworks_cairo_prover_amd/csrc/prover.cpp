@@ -484,6 +484,10 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         }
         return rc;
     };
+    if (src == TRACE_DEVICE_BUILD) {
+        if (segment != 0) return SP_E_INVALID_ARG;
+        return drained(commit_trace_built(*reinterpret_cast<const TraceBuildInput*>(rows_host), root_out));
+    }
     if (src == TRACE_HOST_COLUMNS) {
         if (col_enc >= 0 && col_enc != SP_FE_MONT_LIMBS && col_enc != SP_FE_CANON_BE) return SP_E_INVALID_ARG;
         if (col_stride && col_stride < n_) return SP_E_INVALID_ARG;
@@ -504,6 +508,51 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     if (segment == 0) SP_TRY(launch_aux_presort());
     return commit_segment_resident(segment, cols, root_out);
+}
+
+// interpolate_and_commit (reference prover.rs:126-159) of the Cairo main segment from the RUN instead of the table: the register
+// states and the memory cross PCIe (24 B per step + 32 B per cell: 70 MB where the table has 1.1 GB at 2^20 rows) and the device
+// writes the table itself - build_main_trace, reference src/cairo/execution_trace.rs:57-87 (trace_kernels.hip).  With several
+// ranks every rank builds the whole trace from the same 70 MB: no rank waits for a gigabyte of host table.
+int StarkProver::commit_trace_built(const TraceBuildInput& in, uint8_t root_out[32]) {
+    if (!in.plan || !in.image) return SP_E_INVALID_ARG;
+    const TracePlan& P = *in.plan;
+    TraceImage& I = *in.image;
+    if (!I.base || !P.dense || P.n != n_ || P.cols != Cm_ || P.steps == 0 || P.steps > n_) { sp_set_error("commit_trace: the run does not fit the prover's shape"); return SP_E_INVALID_ARG; }
+    (void)I.try_pin();          // a run built before this process had a context: page-locked from here on
+    SP_TRY(ensure_upload(1));
+    if (!h_wide_ && hipHostMalloc(reinterpret_cast<void**>(&h_wide_), 64, hipHostMallocDefault) != hipSuccess) { h_wide_ = nullptr; sp_set_error("pinned flag slot: allocation failed"); return SP_E_ALLOC; }
+    // staging: the image and the builder's scratch sit in this segment's (not yet written) LDE area when they fit
+    const size_t need = (size_t)I.bytes + main_trace_scratch_bytes(P.steps);
+    uint8_t* stage = reinterpret_cast<uint8_t*>(d_lde_);
+    struct Tmp { void* p = nullptr; hipStream_t st; ~Tmp() { if (p) { (void)hipStreamSynchronize(st); (void)hipFree(p); } } } tmp;
+    tmp.st = c_->stream;
+    if (need > sizeof(fe) * std::max<uint64_t>(Nl_, n_) * Cm_) {
+        if (hipMalloc(&tmp.p, need) != hipSuccess) { (void)hipGetLastError(); sp_set_error("commit_trace: staging allocation failed"); return SP_E_ALLOC; }
+        stage = static_cast<uint8_t*>(tmp.p);
+    }
+    const double t0 = wall_ms();
+    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma0, c_->stream));
+    SP_HIP_CHECK(hipMemcpyAsync(stage, I.base, I.bytes, hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma1, c_->stream));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].ready, c_->stream));
+    SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    MainTraceArgs a{};
+    a.regs = reinterpret_cast<const uint64_t*>(stage + I.off_regs);
+    a.mem = reinterpret_cast<const fe*>(stage + I.off_mem);
+    a.missing = reinterpret_cast<const uint16_t*>(stage + I.off_missing);
+    a.holes = reinterpret_cast<const uint64_t*>(stage + I.off_holes);
+    a.steps = P.steps; a.cells = P.mem_cells; a.n = n_; a.r_rc = P.r_rc; a.r_holes = P.r_holes; a.r_dummy = P.r_dummy; a.n_holes = P.holes.size();
+    a.rc_start = P.rc_start; a.rc_count = P.rc_count; a.cols = Cm_; a.trace = d_trace_;
+    SP_TRY(cairo_main_trace_device(c_->stream, a, stage + I.bytes, c_->d_flag));
+    SP_HIP_CHECK(hipMemcpyAsync(h_wide_ + 4, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].done, c_->stream));
+    const double host_ms = wall_ms() - t0;
+    SP_TRY(launch_aux_presort());
+    SP_TRY(commit_segment_resident(0, Cm_, root_out));        // (its read-back of the root waits for everything above)
+    if (h_wide_[4]) { sp_set_error("commit_trace: a trace row reads beyond the run's memory image"); return SP_E_INVALID_ARG; }
+    return finish_upload_stats(1, I.bytes, 0.0, host_ms, I.pinned ? 4 : 5);
 }
 
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.

@@ -5,6 +5,8 @@
 #include "stark_kernels.h"
 #include "cairo_air_host.h"
 #include "aux_kernels.h"
+#include "trace_kernels.h"
+#include "cairo_host.h"
 #include <vector>
 #include <memory>
 #include <array>
@@ -47,7 +49,10 @@ class StarkProver : public sp_deletable {
     // rows_on_device: `rows` is device memory (same row-major ABI encoding) — no PCIe copy inside the round
     // src = TRACE_HOST_COLUMNS: column-major [cols][n] host memory (column j at src + j * col_stride * 32; col_stride 0 = n), in the
     // DEVICE layout (col_enc < 0) or an ABI encoding (col_enc = sp_fe_encoding): every column group is one DMA, no host gather
-    enum TraceSource { TRACE_HOST_ROWS = 0, TRACE_DEVICE_ROWS = 1, TRACE_HOST_COLUMNS = 2 };
+    // src = TRACE_DEVICE_BUILD: `rows` points at a TraceBuildInput - the register states and the memory of a run go up (24 B per step,
+    // 32 B per cell) and the table is written by the device (trace_kernels.h)
+    enum TraceSource { TRACE_HOST_ROWS = 0, TRACE_DEVICE_ROWS = 1, TRACE_HOST_COLUMNS = 2, TRACE_DEVICE_BUILD = 3 };
+    struct TraceBuildInput { const TracePlan* plan; TraceImage* image; };
     int commit_trace(int segment, const uint8_t* rows, uint32_t cols, uint8_t root_out[32], TraceSource src = TRACE_HOST_ROWS,
                      int col_enc = -1, uint64_t col_stride = 0);
     // round 1, Cairo auxiliary segment built on the device from the resident main trace (reference cairo/air.rs:660-729)
@@ -124,6 +129,7 @@ class StarkProver : public sp_deletable {
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
     int commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]);
+    int commit_trace_built(const TraceBuildInput& in, uint8_t root_out[32]);
     // upload pipeline bookkeeping (sp_last_upload_stats): per column group the DMA interval on the copy stream, the moment the
     // group is usable and the moment the compute stream is done with it
     static constexpr int UPLOAD_MAX_GROUPS = 48;

@@ -80,3 +80,16 @@ def output_rc_program():
     main += assert_ap_eq_deref_fp(-3, -3, 1)                     # assert [range_check_ptr + 1] = 7
     main += push_fp_plus(-4, 2) + push_fp_plus(-3, 2) + ret()
     return main, 1
+
+
+def holes_program():
+    """A builtin-free program whose run leaves memory holes (ap jumps over 60 cells it never writes) and range-check holes (offsets
+    -61 .. 1 with most values in between unused), with a taken and a not-taken jnz.  Returns (words, entry_pc)."""
+    main = push_imm(5) + push_imm(0)
+    main += [word(OP0_FP | OP1_IMM | AP_ADD, -1, -1, 1), 60]                     # ap += 60          (dst, op0: cells that exist)
+    main += [word(OP0_FP | OP1_AP | AP_ADD1 | ASSERT, 0, -1, -62)]               # [ap] = [ap - 62]  (= 5); ap++
+    main += [word(OP0_FP | OP1_IMM | PC_JNZ, -1, -1, 1), 3]                      # jmp rel 3 if [ap - 1] != 0   (taken: skips the next push)
+    main += push_imm(11)[:1]                                                     # (one word: jumped over together with ...)
+    main += [word(OP0_FP | OP1_IMM | PC_JNZ, -62, -1, 1), 2]                     # jmp rel 2 if [ap - 62] != 0  ([ap-62] = 0: not taken)
+    main += ret()
+    return main, 1
