@@ -265,6 +265,7 @@ def cold_child(args):
         th.start()
         run = api.CairoRun.fibonacci(fib)
         t_run = (time.perf_counter() - t0) * 1e3
+        trace = run.main_trace() if rows else None        # (the caller's row-major table exists before the proof call, like the run)
         th.join()
         t_both = (time.perf_counter() - t0) * 1e3
         t_setup = box.get("ms")
@@ -273,8 +274,7 @@ def cold_child(args):
         t0 = time.perf_counter()
         run = api.CairoRun.fibonacci(fib)
         t_run = (time.perf_counter() - t0) * 1e3
-    rows = args.cold_path.startswith("rows")
-    trace = run.main_trace() if rows else None
+        trace = run.main_trace() if rows else None
     ms = []
     for _ in range(4):
         t0 = time.perf_counter()
@@ -284,7 +284,7 @@ def cold_child(args):
     with open(args.cold_child, "w") as f:
         json.dump({"first_call_ms": ms[0], "second_call_ms": ms[1], "third_call_ms": ms[2], "context_create_ms": t_ctx, "prewarm_ms": t_setup,
                    "front_end_and_prewarm_ms": t_both,
-                   "trace_rows": run.n_rows, "front_end_run_ms": t_run, "import_torch_and_library_ms": t_imp,
+                   "trace_rows": run.n_rows, "front_end_run_ms": t_run, "front_end_split": run.timings(), "import_torch_and_library_ms": t_imp,
                    "proof_sha256": hashlib.sha256(proof).hexdigest()}, f)
     ctx.close()
 
@@ -316,13 +316,17 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
     dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))  # input resident in HBM
     torch.cuda.synchronize()
     n, cols = trace.shape[0], trace.shape[1]
+    calls = [1]
     proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)  # allocations, tables
     t_w = time.perf_counter()
     while (time.perf_counter() - t_w) * 1e3 < WARM_MS and world == 1:                     # clock ramp (ranks must stay in step: N = 1 only)
         ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+        calls[0] += 1
     if world > 1:
         for _ in range(3):
             ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+        calls[0] += 3
+    calls[0] += 5
     times = []
     for _ in range(5):
         if dist is not None:
@@ -336,9 +340,22 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
             dt = float(t.item())
         times.append(dt)
     rounds_dev = ctx.last_round_ms()
-    host_ms, run_ms, up_rows, up_run = [], [], None, None
+    host_ms, run_ms, runcols_ms, up_rows, up_run = [], [], [], None, None
     ctx.cairo_prove(trace, run.public_inputs_c, opt)        # (first call: pinned staging ring, gather threads)
     ctx.cairo_prove_run(run, opt)
+    calls[0] += 2
+    ctx.set_option(api.SP_OPT_DEVICE_TRACE, 0)              # the run's host table, column group by column group (round 3's path)
+    try:
+        ctx.cairo_prove_run(run, opt)
+        for _ in range(3):
+            if dist is not None:
+                dist.barrier()
+            t0 = time.perf_counter()
+            ctx.cairo_prove_run(run, opt)
+            runcols_ms.append((time.perf_counter() - t0) * 1e3)
+        calls[0] += 4
+    finally:
+        ctx.set_option(api.SP_OPT_DEVICE_TRACE, 1)
     for _ in range(4):
         if dist is not None:
             dist.barrier()
@@ -360,10 +377,12 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
             "proof_gen_ms_from_host_buffer": min(host_ms), "proof_gen_ms_from_host_buffer_all": host_ms, "upload": up_rows,
             "proof_gen_ms_from_run": min(run_ms), "proof_gen_ms_from_run_all": run_ms, "upload_run": up_run,
+            "proof_gen_ms_from_run_host_table_all": runcols_ms, "proofs_run": calls[0] + 8,
             "note": "proof_gen_ms: wall time of sp_cairo_prove_dev (main trace resident in HBM).  *_from_host_buffer: sp_cairo_prove, the "
                     "drop-in call on the reference's row-major TraceTable in pageable memory (host threads gather column groups into a "
-                    "pinned ring, DMA, transforms of the groups overlapped).  *_from_run: sp_cairo_prove_run, the front-end's own "
-                    "page-locked column-major trace (plain DMA per column group).  upload / upload_run: sp_last_upload_stats of the "
+                    "pinned ring, DMA, transforms of the groups overlapped).  *_from_run: sp_cairo_prove_run - the run's register states "
+                    "and memory go up and the device builds the trace (SP_OPT_DEVICE_TRACE); *_from_run_host_table: the same call with the "
+                    "option off (the run's page-locked column-major table, plain DMA per column group).  upload / upload_run: sp_last_upload_stats of the "
                     "fastest of those calls - exposed_ms is how long the compute stream waited for column groups"}
 
 
@@ -460,7 +479,7 @@ def compact_line(full):
             continue
         s = {"rows": p.get("trace_rows"), "blowup": p.get("blowup"), "n_gpus": p.get("n_gpus"),
              "resident_ms": _med_min(p.get("proof_gen_ms_all")), "from_rows_ms": _med_min(p.get("proof_gen_ms_from_host_buffer_all")),
-             "from_run_ms": _med_min(p.get("proof_gen_ms_from_run_all")), "from_run_devtrace_ms": _med_min(p.get("proof_gen_ms_from_run_devtrace_all")),
+             "from_run_ms": _med_min(p.get("proof_gen_ms_from_run_all")), "from_run_host_table_ms": _med_min(p.get("proof_gen_ms_from_run_host_table_all")),
              "first_call_ms": _r(p.get("first_call_ms")), "prewarmed_first_call_ms": _r(p.get("prewarmed_first_call_ms")),
              "warm_same_child_ms": _r(p.get("prewarmed_child_warm_ms")), "sha": (p.get("proof_sha256") or "")[:8]}
         summ[name] = {k: v for k, v in s.items() if v is not None}
@@ -496,11 +515,14 @@ XGMI_LINK_EFFICIENCY = 0.6           # what RCCL's point-to-point and ring kerne
 COLLECTIVE_LATENCY_MS = 0.03
 
 
-def project_ranks(api, fib, blowup, ranks, single_gpu_ms):
+def project_ranks(api, fib, blowup, ranks, single_gpu_ms, single_rows_ms=None, single_run_ms=None):
     """PROJECTION, not a measurement: rank 0's share of a `ranks`-way sharded proof on this one GPU over the library's timing-only
     transport (sp_comm_init_null: nothing is exchanged, received blocks are zero-filled), which gives the per-rank compute time with
     every kernel at its real size, plus a model of the xGMI time of the collectives it issued (their byte counts are exact):
-    received bytes / ((ranks - 1) links x 76.8 GB/s x 0.6) + 30 us per call.  The proof bytes of such a run are meaningless."""
+    received bytes / ((ranks - 1) links x 76.8 GB/s x 0.6) + 30 us per call.  Both interpolation modes are timed (by column with a
+    coefficient all-gather / on every rank), and - in the mode the library picks by itself - the two host-input legs: the
+    reference's row-major table (every rank uploads 1/ranks of it, the trace columns are all-gathered) and the run (registers +
+    memory up, the trace built on every rank).  The proof bytes of such runs are meaningless."""
     import torch
     run = api.CairoRun.fibonacci(fib)
     trace = run.main_trace()
@@ -508,33 +530,70 @@ def project_ranks(api, fib, blowup, ranks, single_gpu_ms):
     dev_trace = torch.from_numpy(trace).to(torch.device(f"cuda:{torch.cuda.current_device()}"))
     torch.cuda.synchronize()
     n, cols = trace.shape[0], trace.shape[1]
+
+    def model(per, groups):
+        ingest_gbs = max(1, groups - 1) * XGMI_LINK_GBS_PER_DIRECTION * XGMI_LINK_EFFICIENCY
+        return per["received_bytes"] / (ingest_gbs * 1e9) * 1e3 + (per["allgather_calls"] + per["alltoall_calls"]) * COLLECTIVE_LATENCY_MS, ingest_gbs
+
+    def leg(ctx, call, reps=3, warm=2):
+        for _ in range(warm):
+            call()
+        before = ctx.comm_stats()
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            call()
+            times.append((time.perf_counter() - t0) * 1e3)
+        after = ctx.comm_stats()
+        per = {k: (after[k] - before[k]) / reps for k in ("allgather_calls", "allgather_bytes", "alltoall_calls", "alltoall_bytes", "received_bytes")}
+        return min(times), per
+
+    out = {"projection": True, "ranks": ranks, "single_gpu_ms": single_gpu_ms, "modes": {}}
+    for mode, name in ((0, "replicated_interpolation"), (1, "sharded_interpolation")):
+        ctx = api.Context(device=torch.cuda.current_device())
+        try:
+            ctx.init_null(ranks, 0)
+            ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, mode)
+            compute_ms, per = leg(ctx, lambda: ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt), warm=3)
+            info, dev_bytes, rounds = ctx.last_proof_info(), ctx.prover_device_bytes(), ctx.last_round_ms()
+        finally:
+            ctx.close()
+        groups = max(1, info["groups"])
+        comm_ms, ingest = model(per, groups)
+        out["modes"][name] = {"compute_ms": compute_ms, "comm_ms_model": comm_ms, "device_round_ms": rounds, "collectives_per_proof": per,
+                              "device_bytes_per_rank": dev_bytes, "speedup_ceiling": single_gpu_ms / (compute_ms + comm_ms) if single_gpu_ms else None,
+                              "speedup_if_comm_hidden": single_gpu_ms / compute_ms if single_gpu_ms else None}
+        out["groups"], out["assumed_ingest_gbs"] = groups, ingest
+    # the mode the library chooses by itself (SP_OPT_SHARD_INTERPOLATION = 2: the link model), and the host-input legs in it
     ctx = api.Context(device=torch.cuda.current_device())
     try:
         ctx.init_null(ranks, 0)
-        for _ in range(3):
-            ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
-        before = ctx.comm_stats()
-        times = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
-            times.append((time.perf_counter() - t0) * 1e3)
-        after = ctx.comm_stats()
-        info, dev_bytes, rounds = ctx.last_proof_info(), ctx.prover_device_bytes(), ctx.last_round_ms()
+        ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
+        chosen = "sharded_interpolation" if ctx.last_proof_info()["interpolation_sharded"] else "replicated_interpolation"
+        rows_ms, rows_per = leg(ctx, lambda: ctx.cairo_prove(trace, run.public_inputs_c, opt))
+        rows_up = ctx.last_upload_stats()
+        run_ms, run_per = leg(ctx, lambda: ctx.cairo_prove_run(run, opt))
+        run_up = ctx.last_upload_stats()
     finally:
         ctx.close()
-    per = {k: (after[k] - before[k]) / 3 for k in ("allgather_calls", "allgather_bytes", "alltoall_calls", "alltoall_bytes", "received_bytes")}
-    groups = max(1, info["groups"])
-    ingest_gbs = max(1, groups - 1) * XGMI_LINK_GBS_PER_DIRECTION * XGMI_LINK_EFFICIENCY
-    comm_ms = per["received_bytes"] / (ingest_gbs * 1e9) * 1e3 + (per["allgather_calls"] + per["alltoall_calls"]) * COLLECTIVE_LATENCY_MS
-    compute_ms = min(times)
-    return {"projection": True, "ranks": ranks, "groups": groups, "compute_ms": compute_ms, "comm_ms_model": comm_ms,
-            "device_round_ms": rounds, "collectives_per_proof": per, "assumed_ingest_gbs": ingest_gbs, "device_bytes_per_rank": dev_bytes,
-            "single_gpu_ms": single_gpu_ms, "speedup_ceiling": single_gpu_ms / (compute_ms + comm_ms) if single_gpu_ms else None,
-            "speedup_if_comm_hidden": single_gpu_ms / compute_ms if single_gpu_ms else None,
-            "note": "NOT a measurement of a multi-GPU run: rank 0's compute share timed on one GPU with a null transport (bytes not "
-                    "exchanged, proof bytes meaningless) + a bandwidth model of the exact collective byte counts; the collectives are "
-                    "blocking in this run, so compute_ms + comm_ms_model assumes no overlap"}
+    out["default_mode"] = chosen
+    best = out["modes"][chosen]
+    out["compute_ms"], out["comm_ms_model"] = best["compute_ms"], best["comm_ms_model"]
+    out["speedup_ceiling"], out["speedup_if_comm_hidden"] = best["speedup_ceiling"], best["speedup_if_comm_hidden"]
+    rows_comm, _ = model(rows_per, out["groups"])
+    run_comm, _ = model(run_per, out["groups"])
+    out["from_host_rows"] = {"compute_and_upload_ms": rows_ms, "comm_ms_model": rows_comm, "uploaded_bytes_per_rank": rows_up["bytes"], "upload": rows_up,
+                             "single_gpu_ms": single_rows_ms, "speedup_ceiling": single_rows_ms / (rows_ms + rows_comm) if single_rows_ms else None}
+    out["from_run"] = {"compute_and_upload_ms": run_ms, "comm_ms_model": run_comm, "uploaded_bytes_per_rank": run_up["bytes"],
+                       "single_gpu_ms": single_run_ms, "speedup_ceiling": single_run_ms / (run_ms + run_comm) if single_run_ms else None}
+    out["best"] = {"mode": chosen, "compute_ms": _r(best["compute_ms"]), "comm_ms_model": _r(best["comm_ms_model"]), "x_no_overlap": _r(out["speedup_ceiling"]),
+                   "x_comm_hidden": _r(out["speedup_if_comm_hidden"]),
+                   "other_mode_x_no_overlap": _r(out["modes"]["sharded_interpolation" if chosen.startswith("repl") else "replicated_interpolation"]["speedup_ceiling"]),
+                   "from_rows_x": _r(out["from_host_rows"]["speedup_ceiling"]), "from_run_x": _r(out["from_run"]["speedup_ceiling"])}
+    out["note"] = ("NOT a measurement of a multi-GPU run: rank 0's compute share timed on one GPU with a null transport (bytes not exchanged, proof "
+                   "bytes meaningless) + a bandwidth model of the exact collective byte counts; compute_ms + comm_ms_model assumes NO overlap "
+                   "(the blocking collectives of this run), speedup_if_comm_hidden all of it")
+    return out
 
 
 def _free_port():
@@ -583,7 +642,8 @@ def proof_child(args):
                 before = ctx.comm_stats()
                 result[key] = proof_benchmark(api, ctx, fib, blowup, world, dist)
                 after = ctx.comm_stats()
-                result[key]["collective_bytes_per_proof"] = {k: (after[k] - before[k]) // 12 for k in ("allgather_bytes", "alltoall_bytes", "received_bytes")}
+                result[key]["collective_bytes_per_proof"] = {k: (after[k] - before[k]) // max(1, result[key].get("proofs_run", 1))
+                                                             for k in ("allgather_bytes", "alltoall_bytes", "received_bytes")}
             except Exception as e:
                 result[key] = {"error": repr(e)}
         stats = ctx.comm_stats()
@@ -811,7 +871,8 @@ def main():
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
                         try:
                             # (more ranks than LDE cosets only replicate roles: project blowup-many ranks at most)
-                            out["projected"][key] = project_ranks(api, fib, blowup, min(args.project_ranks, blowup), out[key].get("proof_gen_ms"))
+                            out["projected"][key] = project_ranks(api, fib, blowup, min(args.project_ranks, blowup), out[key].get("proof_gen_ms"),
+                                                                  out[key].get("proof_gen_ms_from_host_buffer"), out[key].get("proof_gen_ms_from_run"))
                         except Exception as e:
                             out["projected"][key] = {"error": repr(e)}
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)

@@ -119,8 +119,11 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
 /* Tuning knobs of the sharded prover (defaults in parentheses):
  *   SP_OPT_FRI_SHARD_MIN_LOG (16)  FRI layers with at least 2^value leaves keep their evaluations and trees sharded; smaller
  *                                  layers are all-gathered once and continue replicated (fri/mod.rs:20-72 is sequential in the layers);
- *   SP_OPT_SHARD_INTERPOLATION (1) 1: the size-n inverse transforms of a trace segment are split by column over the ranks and the
- *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns.
+ *   SP_OPT_SHARD_INTERPOLATION (2) 1: the size-n inverse transforms of a trace segment are split by column over the ranks and the
+ *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns;
+ *                                  2: whichever is faster for the shape on the link model - a rank saves (1 - 1/G) of the inverse transforms
+ *                                  and receives (1 - 1/G) of the coefficients, which pays when (G - 1) x link rate x log2 n > 64 x 1.35e11.
+ *   SP_OPT_LINK_GBS (46)           GB/s one xGMI link delivers per direction, for that decision (76.8 GB/s x an assumed 0.6).
  *   SP_OPT_UPLOAD_THREADS (24)     host threads that gather the column groups of a row-major host trace into pinned memory
  *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB).
  *   SP_OPT_MERKLE_BACKEND (SP_MERKLE_KECCAK256)  the hash of every commitment of the context (trace, composition and FRI trees,
@@ -139,7 +142,7 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  rows of ONE column (leaf = hash_many over one element) - what the prover commits a one-column trace
  *                                  segment with (prover.rs:96-104 batch_commit).  Keccak256 trees have one leaf form; no effect there. */
 enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 5,
-       SP_OPT_DEVICE_TRACE = 6 };
+       SP_OPT_DEVICE_TRACE = 6, SP_OPT_LINK_GBS = 7 };
 enum { SP_MERKLE_KECCAK256 = 0, SP_MERKLE_POSEIDON = 1 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 
@@ -384,6 +387,10 @@ int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out);
 int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint8_t* memory, uint64_t memory_len,
                             uint64_t program_size, sp_cairo_run** out);
 void sp_cairo_run_free(sp_cairo_run* run);
+/* Where the front-end's time went, in ms: out = {the VM (0 for runs read from dumps), the shape pass of build_main_trace (addresses,
+ * offsets, range-check and memory holes, every validity check), the upload image for the device-side trace builder, the n x cols
+ * host table (0 until something asks for it: sp_cairo_run_main_trace / _columns, or a proof with SP_OPT_DEVICE_TRACE off)}. */
+int sp_cairo_run_timings(const sp_cairo_run* run, double out[4]);
 /* Shape of the main trace: n rows (power of two) x cols (34, or 43 with the range-check builtin). */
 int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_cols, uint64_t* num_steps);
 /* Copies the row-major main trace in `fe_encoding` (n*cols*32 bytes). */

@@ -320,6 +320,12 @@ class CairoRun:
         check(self._lib.sp_cairo_run_main_trace(self._h, fe_encoding, _u8p(out)))
         return out
 
+    def timings(self):
+        """sp_cairo_run_timings: ms spent in the VM, the shape pass, the upload image and (once built) the host table."""
+        v = (ctypes.c_double * 4)()
+        check(self._lib.sp_cairo_run_timings(self._h, v))
+        return {"vm_ms": round(v[0], 2), "trace_shape_ms": round(v[1], 2), "device_image_ms": round(v[2], 2), "host_table_ms": round(v[3], 2)}
+
     def main_trace_dev(self, ctx, fe_encoding=SP_FE_CANON_BE):
         """sp_cairo_run_main_trace_dev: the same table, built by the device from the run's register states and memory."""
         out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
@@ -563,7 +569,7 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS, SP_OPT_DEVICE_TRACE = 1, 2, 3, 4, 5, 6
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS, SP_OPT_DEVICE_TRACE, SP_OPT_LINK_GBS = 1, 2, 3, 4, 5, 6, 7
 SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
 SP_PREWARM_KERNELS, SP_PREWARM_CLOCKS, SP_PREWARM_HOST_ROWS, SP_PREWARM_ALL = 1, 2, 4, 7
 
@@ -593,6 +599,6 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
             "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

@@ -101,7 +101,14 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             if (value < 1 || value > 40) return SP_E_INVALID_ARG;
             c->opt_fri_shard_min_log = (uint32_t)value;
             break;
-        case SP_OPT_SHARD_INTERPOLATION: c->opt_shard_interpolation = value != 0; break;
+        case SP_OPT_SHARD_INTERPOLATION:
+            if (value < 0 || value > 2) return SP_E_INVALID_ARG;
+            c->opt_shard_interpolation = (int)value;
+            break;
+        case SP_OPT_LINK_GBS:
+            if (value < 1 || value > 10000) return SP_E_INVALID_ARG;
+            c->opt_link_gbs = (double)value;
+            break;
         case SP_OPT_UPLOAD_THREADS:
             if (value < 1 || value > 128) return SP_E_INVALID_ARG;
             c->opt_upload_threads = (uint32_t)value;

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <chrono>
 #include <mutex>
 #include <exception>
 
@@ -26,12 +27,15 @@ struct sp_cairo_run {
     std::exception_ptr main_trace_error;
     const sp::TraceColumns& host_trace() {
         std::call_once(main_trace_once, [this] {
+            const auto t0 = std::chrono::steady_clock::now();
             try { sp::fill_main_trace(regs, mem, plan, main_trace); } catch (...) { main_trace_error = std::current_exception(); }
+            t_table_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
         if (main_trace_error) std::rethrow_exception(main_trace_error);
         return main_trace;
     }
     size_t n_rows = 0, n_cols = 0;
+    double t_vm_ms = 0, t_plan_ms = 0, t_image_ms = 0, t_table_ms = 0;   // sp_cairo_run_timings
     // flattened views handed out by sp_cairo_run_public_inputs
     std::vector<uint8_t> seg_types;
     std::vector<uint64_t> seg_ranges;
@@ -117,9 +121,13 @@ int sp_fe_from_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
 }
 
 static int finish_run(sp_cairo_run* r, size_t program_size, sp_cairo_run** out, const std::vector<sp::MemorySegment>& segments = {}) {
+    const auto t0 = std::chrono::steady_clock::now();
     r->pub = sp::public_inputs_from_regs_and_mem(r->regs, r->mem, program_size, segments);
     sp::plan_main_trace(r->regs, r->mem, r->pub, r->plan);      // shape, range_check_min / max, every check the fill relies on
+    const auto t1 = std::chrono::steady_clock::now();
     r->image.build(r->regs, r->mem, r->plan);
+    r->t_plan_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    r->t_image_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
     r->n_rows = r->plan.n; r->n_cols = r->plan.cols;
     static const bool eager = std::getenv("SP_RUN_EAGER_TRACE") != nullptr;
     if (eager || !r->image.base) (void)r->host_trace();         // (no flat memory: the host table is the only form there is)
@@ -133,7 +141,7 @@ int sp_cairo_run_program_at(const uint8_t* words, uint64_t n_words, uint64_t ent
     try {
         std::vector<fe> prog(n_words);
         for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
-        sp::run_program_plain(prog, r->regs, r->mem, max_steps, entry_pc);
+        { const auto tv = std::chrono::steady_clock::now(); sp::run_program_plain(prog, r->regs, r->mem, max_steps, entry_pc); r->t_vm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count(); }
         return finish_run(r, n_words, out);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
 }
@@ -146,7 +154,7 @@ int sp_cairo_run_program_builtins(const uint8_t* words, uint64_t n_words, uint64
         std::vector<fe> prog(n_words);
         for (uint64_t i = 0; i < n_words; ++i) prog[i] = fe_from_bytes_be(words + 32 * i);
         std::vector<sp::MemorySegment> segs;
-        sp::run_program_builtins(prog, builtins_mask, r->regs, r->mem, max_steps, entry_pc, segs);
+        { const auto tv = std::chrono::steady_clock::now(); sp::run_program_builtins(prog, builtins_mask, r->regs, r->mem, max_steps, entry_pc, segs); r->t_vm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count(); }
         return finish_run(r, n_words, out, segs);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
 }
@@ -160,7 +168,7 @@ int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out) {
     sp_cairo_run* r = new sp_cairo_run();
     try {
         std::vector<fe> prog = sp::fibonacci_program(fib_index);
-        sp::run_program_plain(prog, r->regs, r->mem, 7 * fib_index + 64);
+        { const auto tv = std::chrono::steady_clock::now(); sp::run_program_plain(prog, r->regs, r->mem, 7 * fib_index + 64); r->t_vm_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tv).count(); }
         return finish_run(r, prog.size(), out);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
 }
@@ -177,6 +185,12 @@ int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint
 }
 
 void sp_cairo_run_free(sp_cairo_run* run) { delete run; }
+
+int sp_cairo_run_timings(const sp_cairo_run* run, double out[4]) {
+    if (!run || !out) return SP_E_INVALID_ARG;
+    out[0] = run->t_vm_ms; out[1] = run->t_plan_ms; out[2] = run->t_image_ms; out[3] = run->t_table_ms;
+    return SP_OK;
+}
 
 int sp_cairo_run_shape(const sp_cairo_run* run, uint64_t* n_rows, uint32_t* n_cols, uint64_t* num_steps) {
     if (!run) return SP_E_INVALID_ARG;

@@ -34,7 +34,8 @@ struct sp_ctx {
     void* allgather_user = nullptr;
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
-    bool opt_shard_interpolation = true;
+    int opt_shard_interpolation = 2;          // 0 replicated, 1 by column + coefficient all-gather, 2 whichever the link model makes faster
+    double opt_link_gbs = 46.0;               // what one xGMI link delivers per direction (76.8 GB/s x 0.6): the model behind mode 2
     uint32_t opt_upload_threads = 24;
     int opt_merkle_backend = SP_MERKLE_KECCAK256;
     bool opt_device_trace = true;             // sp_cairo_prove_run builds the main trace on the device from the run's registers and memory

@@ -114,7 +114,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     }
     if (c_->world > 1 && !c_->allgather) { sp_set_error("setup: world > 1 needs sp_set_collective / sp_comm_init_rccl"); return SP_E_STATE; }
     if (ready_ && (arena_ || !allocs_.empty()) && n == n_ && main_cols == Cm_ && aux_cols == Ca_ && has_rc == has_rc_ && opt.blowup_factor == opt_.blowup_factor &&
-        opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_) {
+        opt.coset_offset == opt_.coset_offset && (uint32_t)c_->world == world_ && (uint32_t)c_->rank == wrank_ && c_->opt_shard_interpolation == shard_mode_) {
         // same shape as the previous proof on this context: keep every device buffer and table
         opt_ = opt; stage_ = 1; fri_layer_ = 0;
         bpre_valid_ = false; deep_pref_ = false; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
@@ -128,11 +128,22 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     d_gather_ = nullptr; gather_cap_ = 0; d_fullN_ = nullptr; d_small_ = nullptr; d_deepx_ = nullptr; deepx_cap_ = 0; d_cstage_ = nullptr; d_local_ = nullptr; d_recv_ = nullptr; d_roots_ = nullptr;
     opt_ = opt; n_ = n; logn_ = (uint32_t)k; logb_ = (uint32_t)lb; logN_ = logn_ + logb_; N_ = n << lb;
     Cm_ = main_cols; Ca_ = aux_cols; C_ = main_cols + aux_cols; has_rc_ = has_rc;
-    world_ = (uint32_t)c_->world; wrank_ = (uint32_t)c_->rank;
+    world_ = (uint32_t)c_->world; wrank_ = (uint32_t)c_->rank; shard_mode_ = c_->opt_shard_interpolation;
     // one or more LDE cosets per group; with more ranks than cosets the surplus ranks replicate a role (moving half a coset's
     // LDE over one xGMI link costs more than computing it)
     G_ = std::min<uint32_t>(world_, 1u << lb); logG_ = (uint32_t)sp_log2_exact(G_); rank_ = wrank_ & (G_ - 1);
     Nl_ = N_ >> logG_;
+    // Interpolation by column with an all-gather of the coefficients, or on every rank?  A rank saves
+    // (1 - 1/G) of the size-n inverse transforms (n log n / 2 butterflies per column at ~1.35e11 / s) and receives (1 - 1/G) of the
+    // coefficients (32 n bytes per column over G - 1 links): sharding pays when  64 x 1.35e11 < (G - 1) x link bytes/s x log2 n.
+    // On 46 GB/s per link that needs (G - 1) log2 n > 188 - no shape this prover sees - so mode 2 interpolates everywhere unless the
+    // caller states a faster fabric (SP_OPT_LINK_GBS); an exchange that overlaps the transforms completely (stream-ordered
+    // transport) is worth at most the inverse transforms it replaces, 3 - 5 ms at 2^20 rows.
+    shard_interp_ = false;
+    if (G_ > 1) {
+        if (c_->opt_shard_interpolation == 1) shard_interp_ = true;
+        else if (c_->opt_shard_interpolation == 2) shard_interp_ = 64.0 * 1.35e11 < (double)(G_ - 1) * c_->opt_link_gbs * 1e9 * (double)k;
+    }
     if (G_ > 1 && N_ < 2ull * G_ * G_) { sp_set_error("setup: the LDE domain is too small for this many ranks"); return SP_E_INVALID_ARG; }
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
@@ -155,7 +166,7 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
             SP_TRY(alloc((void**)&d_local_, sizeof(fe) * Nl_));
             SP_TRY(alloc((void**)&d_recv_, sizeof(fe) * Nl_));
             SP_TRY(alloc((void**)&d_roots_, sizeof(digest32) * world_));
-            if (c_->opt_shard_interpolation) {
+            if (shard_interp_) {
                 cpr_max_ = (std::max(Cm_, Ca_) + G_ - 1) / G_;
                 SP_TRY(alloc((void**)&d_cstage_, sizeof(fe) * (uint64_t)world_ * cpr_max_ * n_));
             }
@@ -494,8 +505,11 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
         return drained(commit_trace_columns(segment, rows_host, cols, col_enc, col_stride ? col_stride : n_, root_out));
     }
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
-    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= (64ull << 20))
+    static const uint64_t pipeline_min_bytes = [] { const char* e = std::getenv("SP_UPLOAD_MIN_MB"); return (uint64_t)(e ? std::max(0, std::atoi(e)) : 64) << 20; }();
+    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes)
         return drained(commit_trace_pipelined(segment, rows_host, cols, root_out));
+    if (!rows_on_device && G_ > 1 && cols >= 2 * G_ && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes)
+        return drained(commit_trace_rows_sharded(segment, rows_host, cols, root_out));
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
@@ -508,6 +522,35 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     if (segment == 0) SP_TRY(launch_aux_presort());
     return commit_segment_resident(segment, cols, root_out);
+}
+
+// interpolate_and_commit (reference prover.rs:126-159) from the reference's row-major host table with SEVERAL ranks.  Every rank
+// holds the same table (the shim's `&TraceTable`), so no rank needs to push all of it through its own PCIe link - and on one host
+// the G gathers of the whole table would go through the same memory controllers: the rank with role r gathers and uploads the
+// ceil(cols / G) columns from min(r cpr, cols - cpr) on only (the upload ring of the one-GPU path, restricted to that window), and
+// the natural-order columns are all-gathered over the fabric: cols n 32 bytes in total (1.1 GB at 2^20 x 34: ~3 ms on the link
+// model) instead of G times that through the host (20 ms of PCIe per rank, and the host's memory bandwidth shared by all).
+// Every rank needs the whole trace anyway - the auxiliary trace and the exact constraint check read it - so the all-gather carries
+// trace VALUES and the interpolation follows as configured (SP_OPT_SHARD_INTERPOLATION).
+int StarkProver::commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+    const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    const uint32_t cpr = (cols + G_ - 1) / G_;
+    auto first_col = [&](uint32_t role) { return std::min(role * cpr, cols - cpr); };
+    fe* trace = d_trace_ + (uint64_t)col0 * n_;
+    SP_TRY(commit_trace_pipelined(segment, rows_host, cols, root_out, first_col(rank_), cpr, true));
+    // (the LDE area of this segment is free until the transforms below: landing zone of the all-gather)
+    const uint64_t block = (uint64_t)cpr * n_;
+    fe* stage = nullptr;
+    if ((uint64_t)world_ * block <= std::max<uint64_t>(Nl_, n_) * cols) stage = d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_);
+    else { SP_TRY(ensure_gather((uint64_t)world_ * block)); stage = d_gather_; }
+    SP_TRY(all_gather(trace + (uint64_t)first_col(rank_) * n_, stage, block * sizeof(fe)));
+    for (uint32_t role = 0; role < G_; ++role) {      // (the first G slots are the G roles; the own block is in place already)
+        if (role == rank_) continue;
+        SP_HIP_CHECK(hipMemcpyAsync(trace + (uint64_t)first_col(role) * n_, stage + (uint64_t)role * block, block * sizeof(fe), hipMemcpyDeviceToDevice, c_->stream));
+    }
+    if (segment == 0) SP_TRY(launch_aux_presort());
+    SP_TRY(commit_segment_resident(segment, cols, root_out));
+    return finish_upload_stats(pending_up_groups_, pending_up_bytes_, pending_up_gather_ms_, pending_up_host_ms_, 1);
 }
 
 // interpolate_and_commit (reference prover.rs:126-159) of the Cairo main segment from the RUN instead of the table: the register
@@ -561,7 +604,7 @@ int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t roo
     fe* coeffs = d_coeffs_ + (uint64_t)col0 * n_;
     // interpolate_fft (reference trace.rs:104-110): natural -> bit-reversed h-scaled coefficients (the trace stays intact)
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
-    if (G_ > 1 && d_cstage_ && cols >= G_) {
+    if (G_ > 1 && shard_interp_ && d_cstage_ && cols >= G_) {
         // columns are independent (prover.rs:174-183): role s interpolates the cpr columns from min(s cpr, cols - cpr) on
         // (the last blocks overlap instead of being ragged), all-gathers bring every coefficient everywhere (§8(e) item 1).
         // With a stream-ordered transport the cpr columns go in up to four blocks: the exchange of block k runs on the
@@ -1098,7 +1141,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     }
     bpre_valid_ = false;
     c_->proof_info[0] = (sub_coset || pair_path) ? 1u : (h_full_ ? 3u : 2u);
-    c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && d_cstage_) ? 1u : 0u;
+    c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && shard_interp_) ? 1u : 0u;
     SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
     stage_ = 4;
     return SP_OK;

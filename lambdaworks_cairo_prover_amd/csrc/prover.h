@@ -127,7 +127,13 @@ class StarkProver : public sp_deletable {
         return commit_local(cols_dev, stride, ncols, Nl_, lde_order(), tree, root_out);
     }
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
-    int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t table_cols, uint8_t root_out[32], uint32_t c_begin = 0, uint32_t c_count = 0,
+                               bool window_only = false);
+    // several ranks, row-major host table: every rank uploads the columns of its role only, the trace columns are all-gathered
+    int commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    uint32_t pending_up_groups_ = 0; uint64_t pending_up_bytes_ = 0; double pending_up_gather_ms_ = 0, pending_up_host_ms_ = 0;
+    int shard_mode_ = 2;
+    bool shard_interp_ = false;    // this shape interpolates by column and all-gathers coefficients (SP_OPT_SHARD_INTERPOLATION, setup())
     int commit_trace_columns(int segment, const uint8_t* cols_host, uint32_t cols, int col_enc, uint64_t col_stride, uint8_t root_out[32]);
     int commit_trace_built(const TraceBuildInput& in, uint8_t root_out[32]);
     // upload pipeline bookkeeping (sp_last_upload_stats): per column group the DMA interval on the copy stream, the moment the

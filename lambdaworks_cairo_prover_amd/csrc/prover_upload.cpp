@@ -84,7 +84,7 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
         // transforms take 0.7 ms per column, so with small groups the compute stream waits for the first column only; doubling
         // groups (1, 1, 2, 4, 8, 8, ...) made it wait 4 ms per proof - every group twice the size of the one being transformed
         uint32_t w = done < 2 ? 1u : 2u;
-        if (G_ > 1 && d_cstage_) w = cols;            // column-sharded interpolation works on the whole segment
+        if (G_ > 1 && shard_interp_) w = cols;        // column-sharded interpolation works on the whole segment
         w = std::min(w, cols - done);
         gsize.push_back(w);
         done += w;
@@ -104,7 +104,7 @@ int StarkProver::commit_trace_columns(int segment, const uint8_t* cols_host, uin
     fe* lde = d_lde_ + (uint64_t)col0 * Nl_;
     SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the trace area's previous readers are behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
-    const bool sharded_interp = G_ > 1 && d_cstage_ && cols >= G_;
+    const bool sharded_interp = G_ > 1 && shard_interp_ && cols >= G_;
     uint32_t c0 = 0;
     for (uint32_t g = 0; g < groups; c0 += gsize[g], ++g) {
         const uint32_t w = gsize[g];
@@ -351,8 +351,13 @@ int StarkProver::ensure_ring_and_pool() {
 // straight into the trace area.  A chunk is a block of rows of one group, 32 MB at most: the DMA of one chunk runs beside the gather
 // of the next whatever the size of the group, and the ring (4 x 32 MB) takes a sixth of the time to pin that three group-sized slots
 // did (56 ms of a first proof at 2^20 rows).
-int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+// window_only: several ranks - only the columns [c_begin, c_begin + c_count) of the table (the block this rank's role contributes to
+// the all-gather of the trace, commit_trace_rows_sharded) are gathered, uploaded and decoded; no transforms, no commitment.
+int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t table_cols, uint8_t root_out[32], uint32_t c_begin, uint32_t c_count,
+                                        bool window_only) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
+    const uint32_t cols = window_only ? c_count : table_cols;
+    if (!window_only) { c_begin = 0; c_count = table_cols; }
     // Column groups.  Group g can be transformed once it has crossed PCIe (~0.6 ms per column of 2^20 rows) and everything behind
     // it still has to be transformed (~0.7 ms per column at blowup 8, 0.2 ms at blowup 4, where the upload is the bound): two single
     // columns start the pipeline, then pairs, always from an even column on (two columns share a 64-byte line of a row).  A group is
@@ -382,7 +387,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         pool_bound_ = true;
         const char* bind_env = std::getenv("SP_UPLOAD_BIND");
         const char mode = bind_env ? bind_env[0] : 'g';
-        const int node_table = numa_node_of_memory(rows_host, (size_t)n_ * cols * 32), node_gpu = numa_node_of_device(c_->device);
+        const int node_table = numa_node_of_memory(rows_host, (size_t)n_ * table_cols * 32), node_gpu = numa_node_of_device(c_->device);
         const int node = mode == 't' ? node_table : (mode == 'g' ? node_gpu : -1);
         std::vector<int> cpus;
         if (node >= 0) {
@@ -407,7 +412,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     std::vector<Chunk> chunks;
     uint64_t n_blocks = 0;
     {
-        uint32_t c = 0;
+        uint32_t c = c_begin;
         for (uint32_t g = 0; g < groups; c += gsize[g], ++g) {
             const uint32_t cw = gsize[g];
             // (the two single columns that start the pipeline in quarter-size chunks: the first DMA leaves after 0.16 ms of gathering
@@ -476,10 +481,12 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                     // kernel of the proof: the rows -> columns kernels this replaces ran on a highest-priority stream beside the
                     // transforms and made those 1.3 - 2.2 x slower for as long as the upload lasted - tools/upload_interference.py)
                     SP_TRY(decode_elements(c_->stream, c_->enc, reinterpret_cast<const uint8_t*>(trace + (uint64_t)gc0 * n_), (uint64_t)w * n_, trace + (uint64_t)gc0 * n_));
-                    // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
-                    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)gc0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)gc0 * n_));
-                    SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)gc0 * n_, lde + (uint64_t)gc0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
-                    if (segment == 0) SP_TRY(maybe_leaf_head(cols, gc0 + w, lde));
+                    if (!window_only) {
+                        // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
+                        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)gc0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)gc0 * n_));
+                        SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)gc0 * n_, lde + (uint64_t)gc0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
+                        if (segment == 0) SP_TRY(maybe_leaf_head(cols, gc0 + w, lde));
+                    }
                     SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
                 }
                 if (++k == n_chunks) gather_end = wall_ms();
@@ -513,7 +520,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
             }
             const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)ck.cw * 32)) & ~(uint64_t)1;
             const uint64_t br0 = (b - ck.first_block) * block_rows;
-            host_gather_block(rows_host + ck.r0 * (size_t)cols * 32, ck.rows, (size_t)cols * 32, (size_t)ck.c * 32, ck.cw, static_cast<uint8_t*>(h_stage_[ck.slot]),
+            host_gather_block(rows_host + ck.r0 * (size_t)table_cols * 32, ck.rows, (size_t)table_cols * 32, (size_t)ck.c * 32, ck.cw, static_cast<uint8_t*>(h_stage_[ck.slot]),
                               br0, std::min<uint64_t>(ck.rows, br0 + block_rows));
             blocks_done[k].fetch_add(1, std::memory_order_acq_rel);
         }
@@ -522,6 +529,10 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     const double gather_ms = gather_end - t0;
     const double host_ms = wall_ms() - t0;
     SP_TIMEPOINT("  upload + transforms of the groups");
+    if (window_only) {   // (the caller finishes the statistics once the compute stream has been waited for)
+        pending_up_groups_ = groups; pending_up_bytes_ = (uint64_t)cols * n_ * 32; pending_up_gather_ms_ = gather_ms; pending_up_host_ms_ = host_ms;
+        return SP_OK;
+    }
     if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
     SP_TIMEPOINT("  aux presort queued (+ its workspace)");
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));

@@ -57,6 +57,8 @@ def _worker(rank, world, port, case, options, knobs, q):
     sys.path.insert(0, here)
     from lambdaworks_cairo_prover_amd import api
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if knobs.get("rows_window"):
+        os.environ["SP_UPLOAD_MIN_MB"] = "0"      # (read once per process by the library)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         trace, pub, keep = _inputs(case)
@@ -75,6 +77,8 @@ def _worker(rank, world, port, case, options, knobs, q):
         proof2 = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))  # buffer reuse path
         stats = ctx.comm_stats()
         stats["composition_path"] = ctx.last_proof_info()["composition_path"]
+        stats["interpolation_sharded"] = ctx.last_proof_info()["interpolation_sharded"]
+        stats["upload_kind"] = ctx.last_upload_stats()["kind"]
         q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE", stats))
         ctx.close()
     except Exception:
@@ -102,11 +106,11 @@ RND = lambda n, seed, rc=False: {"kind": "random", "n": n, "seed": seed, "rc": r
 
 CASES = [
     # (world, case, options, knobs)
-    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5}),
-    (4, FIB(100), (4, 5, 3, 2), {"fri_min_log": 6}),
-    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "alltoall": False}),          # digest exchange through the all-gather fallback
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "shard_interp": 1}),         # interpolation by column + coefficient all-gather
+    (4, FIB(100), (4, 5, 3, 2), {"fri_min_log": 6}),                             # default: the link model decides (replicated on 46 GB/s links)
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "alltoall": False, "shard_interp": 1}),   # digest exchange through the all-gather fallback
     (2, FIB(60), (2, 3, 3, 1), {"fri_min_log": 4, "shard_interp": 0}),           # replicated interpolation
-    (8, FIB(100), (8, 4, 3, 1), {"fri_min_log": 8}),                             # one coset per rank
+    (8, FIB(100), (8, 4, 3, 1), {"fri_min_log": 8, "shard_interp": 1}),          # one coset per rank
     (8, FIB(60), (16, 3, 3, 1), {"fri_min_log": 8}),                             # two cosets per rank (configs[4]'s shape in small)
     (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7}),                             # more ranks than cosets: ranks 4..7 replicate roles 0..3
     (4, FIB(140), (4, 6, 3, 1), {}),                                             # default knobs: the whole FRI replicated at this size
@@ -115,10 +119,10 @@ CASES = [
     (4, RND(128, 13, rc=True), (4, 3, 3, 1), {"fri_min_log": 5, "alltoall": False}),
     (8, RND(256, 14), (8, 3, 3, 1), {}),
     # stream-ordered all-gather hook: 17 (9) columns per role in four blocks, 9 (5) in three, replicas beyond the blowup factor
-    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "async": True}),
-    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "async": True}),
-    (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7, "async": True}),
-    (4, RND(256, 15, rc=True), (8, 4, 3, 2), {"fri_min_log": 6, "async": True}),
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "async": True, "shard_interp": 1}),
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "async": True, "shard_interp": 1}),
+    (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7, "async": True, "shard_interp": 1}),
+    (4, RND(256, 15, rc=True), (8, 4, 3, 2), {"fri_min_log": 6, "async": True, "shard_interp": 1}),
     # the exact trace check of round 2 is split by rows over the ranks (n >= 256 world): a violation in the last rank's slice only
     (2, {"kind": "fib_flip", "fib": 100, "row": 700, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
     (4, {"kind": "fib_flip", "fib": 100, "row": 3, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
@@ -126,7 +130,13 @@ CASES = [
     # Poseidon commitments (the optional backend of configs[4]): subtrees, digest all-to-all and top tree over field-element digests
     (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "poseidon": True}),
     (8, FIB(60), (16, 3, 3, 1), {"fri_min_log": 8, "poseidon": True}),
-    (4, RND(256, 17), (8, 4, 3, 2), {"fri_min_log": 6, "poseidon": True, "async": True}),
+    (4, RND(256, 17), (8, 4, 3, 2), {"fri_min_log": 6, "poseidon": True, "async": True, "shard_interp": 1}),
+    # the row-major host table with several ranks: every rank uploads the columns of its role only, the trace columns are all-gathered
+    # (SP_UPLOAD_MIN_MB=0 sends these small tables down the path the big ones take)
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "rows_window": True}),
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "rows_window": True, "shard_interp": 1}),
+    (8, FIB(100), (4, 3, 3, 1), {"fri_min_log": 7, "rows_window": True}),
+    (4, RND(256, 18, rc=True), (8, 4, 3, 2), {"fri_min_log": 6, "rows_window": True, "async": True, "shard_interp": 1}),
 ]
 
 
@@ -154,8 +164,11 @@ def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_
         assert stats["composition_path"] == (1 if case["kind"] == "fib" else 3)     # (one flipped cell: deg H >= 2n, like a random trace)
         if knobs.get("alltoall", True) and world <= options[0]:
             assert stats["alltoall_calls"] >= 3          # main, aux and composition commitments at least
+        assert stats["interpolation_sharded"] == (1 if knobs.get("shard_interp") == 1 else 0)
         if knobs.get("async"):
             assert stats["allgather_calls"] >= 2 * (3 + 3)   # two proofs, each segment's coefficients in three or four blocks
+        if knobs.get("rows_window"):
+            assert stats["upload_kind"].startswith("row-major")   # (the one-copy path reports "single copy")
 
 
 def _rccl_worker(rank, world, port, fib_index, options, q):
