@@ -1405,7 +1405,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
 }
 
 int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value) {
-    if (!fri_chain_available() || fri_layer_ != 1) { sp_set_error("fri_commit_chain: layer 0 not committed, or a sharded prover"); return SP_E_STATE; }
+    if (!fri_chain_available()) { sp_set_error("fri_commit_chain: no layer committed yet, or the next layer to fold is sharded"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const fe* roots = nullptr;
     SP_TRY(c_->ntt->roots((int)logN_, &roots));
@@ -1422,26 +1422,31 @@ int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], st
     std::vector<uint8_t>& up = h_up_fri_;     // (a member: the asynchronous copy below may still read it when an error path returns)
     up.assign(32 + (size_t)L * 32, 0);
     std::memcpy(up.data(), state32, 32);
+    const uint32_t k0 = fri_layer_ - 1;           // the layer to fold first (0 on one GPU; the first replicated layer otherwise)
     fe oi = fri_offset_inv_;
-    for (uint32_t k = 0; k < L; ++k) { const fe c = fe_mul(half_, oi); std::memcpy(up.data() + 32 + (size_t)k * 32, &c, 32); oi = fe_sqr(oi); }
+    for (uint32_t k = k0; k < L; ++k) { const fe c = fe_mul(half_, oi); std::memcpy(up.data() + 32 + (size_t)k * 32, &c, 32); oi = fe_sqr(oi); }
     SP_HIP_CHECK(hipMemcpyAsync(d_fri_chain_, up.data(), up.size(), hipMemcpyHostToDevice, c_->stream));
     const fe cst0 = fe_mul(fe_mul(zeta0, half_), fri_offset_inv_);
-    for (uint32_t k = 0; k < L; ++k) {            // fold layer k into layer k + 1 and commit it
+    for (uint32_t k = k0; k < L; ++k) {           // fold layer k into layer k + 1 and commit it
         const uint64_t M = N_ >> k;
-        SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, k == 0 ? nullptr : d_cst + k));
+        static const bool fused = std::getenv("SP_FRI_NO_FUSED_LEAVES") == nullptr;      // (A/B switch)
+        const bool fuse = fused && k + 1 < L && merkle_hash(true) == MerkleHash::KECCAK256;
+        if (fuse) SP_TRY(fri_fold_hash(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, k == k0 ? nullptr : d_cst + k,
+                                       fri_trees_[k + 1].sub + (fri_trees_[k + 1].sub_leaves - 1)));
+        else SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, k == k0 ? nullptr : d_cst + k));
         if (k + 1 < L) {
             TreeBuf& t = fri_trees_[k + 1];
-            SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}, merkle_hash(true)));
+            if (!fuse) SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}, merkle_hash(true)));
             const FriChallenge ch{d_state, d_cmul + (k + 1), d_cst + (k + 1), d_roots + 4 * (size_t)(k + 1)};
             SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch, merkle_hash(true)));
         }
     }
-    for (uint32_t k = 0; k < L; ++k) { fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_); }
-    // roots of layers 1 .. L-1 and the b evaluations of the last fold (fri/mod.rs:58-67, see fri_fold_commit)
-    roots_out.assign(L - 1, std::array<uint8_t, 32>{});
-    if (L > 1) {
-        if ((size_t)(L - 1) * 32 > 4096) return SP_E_UNSUPPORTED;
-        SP_TRY(readback(roots_out.data(), d_roots + 4, (size_t)(L - 1) * 32));
+    for (uint32_t k = k0; k < L; ++k) { fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_); }
+    // roots of layers k0 + 1 .. L-1 and the b evaluations of the last fold (fri/mod.rs:58-67, see fri_fold_commit)
+    roots_out.assign(L - 1 - k0, std::array<uint8_t, 32>{});
+    if (L - 1 > k0) {
+        if ((size_t)(L - 1 - k0) * 32 > 4096) return SP_E_UNSUPPORTED;
+        SP_TRY(readback(roots_out.data(), d_roots + 4 * (size_t)(k0 + 1), (size_t)(L - 1 - k0) * 32));
     }
     const uint32_t bb = 1u << logb_;
     std::vector<fe> ev(bb);

@@ -76,9 +76,12 @@ class StarkProver : public sp_deletable {
     int fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_value, int* is_last);
     // The whole commit phase after layer 0 without a host round trip per layer (one GPU): the launch that produces a layer's
     // root also takes the transcript step (append root, sample zeta - merkle.h FriChallenge) and leaves zeta's fold constant
-    // in device memory for the next layer.  state32 = the transcript buffer after zeta_0 was sampled (32 bytes); roots_out =
-    // the roots of layers 1 .. L-1, which the caller feeds to its own transcript afterwards.
-    bool fri_chain_available() const { return G_ == 1 && stage_ == 6 && logn_ >= 2; }
+    // in device memory for the next layer.  state32 = the transcript buffer after that zeta was sampled (32 bytes); roots_out =
+    // the roots of the layers committed here (those after the last one committed before the call), which the caller feeds to its
+    // own transcript afterwards.
+    // Several ranks: available from the first layer every rank holds whole (the sharded layers in front of it go through
+    // fri_fold_commit, one exchange each); the caller passes the zeta of the layer to fold next.
+    bool fri_chain_available() const { return stage_ == 6 && logn_ >= 2 && fri_layer_ >= 1 && !fri_sharded(fri_layer_ - 1); }
     int fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value);
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
     int open(const std::vector<uint64_t>& iotas, Openings& out);

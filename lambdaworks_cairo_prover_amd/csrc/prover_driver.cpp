@@ -193,18 +193,20 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         fri_roots.emplace_back(root, root + 32);
         tr.append(root, 32);
         fe last_value;
-        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
-            const fe zeta0 = tr.to_field();
-            std::vector<std::array<uint8_t, 32>> rest;
-            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
-            for (auto& r : rest) {
-                fri_roots.emplace_back(r.begin(), r.end());
-                tr.append(r.data(), 32);
-                (void)tr.to_field();      // zeta_k: the device sampled the same value
-            }
-        } else
         for (;;) {
             fe zeta = tr.to_field();
+            // From the first layer this rank holds whole (layer 0 on one GPU; behind the sharded layers otherwise) the layers follow
+            // each other on the device without a host round trip; the transcript catches up afterwards.
+            if (P->fri_chain_available()) {
+                std::vector<std::array<uint8_t, 32>> rest;
+                SP_TRY(P->fri_commit_chain(zeta, tr.buf.data(), rest, &last_value));
+                for (auto& r : rest) {
+                    fri_roots.emplace_back(r.begin(), r.end());
+                    tr.append(r.data(), 32);
+                    (void)tr.to_field();      // zeta_k: the device sampled the same value
+                }
+                break;
+            }
             int is_last = 0;
             SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
             if (is_last) break;
@@ -327,18 +329,20 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         fri_roots.emplace_back(root, root + 32);
         tr.append(root, 32);
         fe last_value;
-        if (P->fri_chain_available()) {   // one GPU: the layers follow each other on the device, the transcript catches up afterwards
-            const fe zeta0 = tr.to_field();
-            std::vector<std::array<uint8_t, 32>> rest;
-            SP_TRY(P->fri_commit_chain(zeta0, tr.buf.data(), rest, &last_value));
-            for (auto& r : rest) {
-                fri_roots.emplace_back(r.begin(), r.end());
-                tr.append(r.data(), 32);
-                (void)tr.to_field();      // zeta_k: the device sampled the same value
-            }
-        } else
         for (;;) {
             fe zeta = tr.to_field();
+            // From the first layer this rank holds whole (layer 0 on one GPU; behind the sharded layers otherwise) the layers follow
+            // each other on the device without a host round trip; the transcript catches up afterwards.
+            if (P->fri_chain_available()) {
+                std::vector<std::array<uint8_t, 32>> rest;
+                SP_TRY(P->fri_commit_chain(zeta, tr.buf.data(), rest, &last_value));
+                for (auto& r : rest) {
+                    fri_roots.emplace_back(r.begin(), r.end());
+                    tr.append(r.data(), 32);
+                    (void)tr.to_field();      // zeta_k: the device sampled the same value
+                }
+                break;
+            }
             int is_last = 0;
             SP_TRY(P->fri_fold_commit(zeta, root, &last_value, &is_last));
             if (is_last) break;

@@ -112,6 +112,9 @@ int deep_composition(hipStream_t st, const fe* lde, const fe* h1, const fe* h2, 
 // form: next[i] = (cur[i] + cur[i+M/2]) / 2 + zeta * (cur[i] - cur[i+M/2]) / (2 x_i),  x_i = offset * w_M^i, i < M/2.
 // roots_N: half table of w_N; M = N >> layer. c = zeta / (2 * offset).
 // Sharded layer: M = the elements this rank holds, local index l = global index (l << shard_log) | shard_rank.
+// the same with the leaf digests of the produced layer (Keccak256 trees, one GPU): leaves_out[i] = Keccak256(next[i] as 32-byte BE)
+int fri_fold_hash(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
+                  const fe* c_dev, digest32* leaves_out);
 int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
              uint32_t shard_log = 0, uint32_t shard_rank = 0, const fe* c_dev = nullptr);   // c_dev (device, nullable) replaces c
 

@@ -441,6 +441,42 @@ __global__ void __launch_bounds__(256) fri_fold_kernel(const fe* cur, fe* next, 
     fe w = root_pow(roots, e, logN);
     sk_st(next + i, a.half * (x + y) + a.c * (w * (x - y)));
 }
+// The fold and the leaf hash of the layer it produces in one launch (FriLayer::new, fri_commitment.rs:30-47: the leaf of a FRI tree
+// is Keccak256 of the element's canonical 32-byte big-endian encoding): the folded element never travels to HBM and back before it is
+// hashed, and every layer of the commit phase is one launch and one dependent latency shorter.
+__global__ void __launch_bounds__(256) fri_fold_hash_kernel(const fe* cur, fe* next, uint64_t Mh, uint32_t logN, uint32_t layer, const fe* roots, FriArgs a,
+                                                            const fe* c_dev, digest32* leaves_out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Mh) return;
+    if (c_dev) a.c = sk_ld(c_dev);
+    fe x = sk_ld(cur + i), y = sk_ld(cur + Mh + i);
+    uint32_t Nm = (1u << logN) - 1;
+    uint32_t e = (0u - ((uint32_t)i << layer)) & Nm;
+    fe w = root_pow(roots, e, logN);
+    const fe v = a.half * (x + y) + a.c * (w * (x - y));
+    sk_st(next + i, v);
+    const fe raw = fe_from_mont(v);
+    uint64_t s[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) s[k] = 0;
+#pragma unroll
+    for (uint32_t l = 0; l < 4; ++l) s[l] = sp_bswap64((uint64_t)raw.v[2 * (3 - l)] | ((uint64_t)raw.v[2 * (3 - l) + 1] << 32));
+    s[4] = 0x01ULL;
+    s[16] = 0x8000000000000000ULL;
+    sp_keccak_f1600_dev(s);
+    digest32 d;
+    d.w[0] = s[0]; d.w[1] = s[1]; d.w[2] = s[2]; d.w[3] = s[3];
+    leaves_out[i] = d;
+}
+int fri_fold_hash(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
+                  const fe* c_dev, digest32* leaves_out) {
+    uint64_t Mh = M >> 1;
+    FriArgs a; a.half = half; a.c = c;
+    hipLaunchKernelGGL(fri_fold_hash_kernel, dim3((unsigned)((Mh + 255) / 256)), dim3(256), 0, st, cur, next, Mh, logN, layer, roots_N, a, c_dev, leaves_out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 int fri_fold(hipStream_t st, const fe* cur, fe* next, uint64_t M, uint32_t logN, uint32_t layer, const fe* roots_N, const fe& half, const fe& c,
              uint32_t shard_log, uint32_t shard_rank, const fe* c_dev) {
     uint64_t Mh = M >> 1;   // M = elements this rank holds

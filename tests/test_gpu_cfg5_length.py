@@ -53,8 +53,8 @@ def test_ntt_and_lde_at_cfg5_lengths_match_oracle(hip_ctx, oracle, k):
 
 def test_whole_proof_of_a_2_24_row_trace_on_one_gpu(hip_lib):
     """n = 2^24 rows x 52 columns (BASELINE configs[4]'s trace length; blowup 4: N = 2^26 LDE points, 112 GB of LDE columns):
-    the product verifier accepts the proof and rejects it after a byte flip; the run's page-locked columns
-    (sp_cairo_prove_run), the reference's row-major host table (sp_cairo_prove) and the device-resident table
+    the product verifier accepts the proof and rejects it after a byte flip; the run itself (sp_cairo_prove_run: trace built on
+    the device, and the run's page-locked columns with that option off), the reference's row-major host table (sp_cairo_prove) and the device-resident table
     (sp_cairo_prove_dev) give the same bytes.  Blowup 2 when less than 250 GB of device memory is free."""
     free = _free_device_bytes()
     if free < 150e9:
@@ -64,10 +64,15 @@ def test_whole_proof_of_a_2_24_row_trace_on_one_gpu(hip_lib):
     with api.Context(device=0) as ctx:
         run = api.CairoRun.fibonacci(2390000)            # 16 730 009 steps -> 2^24 rows
         assert run.n_rows == 1 << 24 and run.n_cols == 34
-        proof = ctx.cairo_prove_run(run, opt)
+        proof = ctx.cairo_prove_run(run, opt)            # the trace built on the device: 0.4 GB of registers + 0.7 GB of memory go up
         info, up, dev_bytes, rounds = ctx.last_proof_info(), ctx.last_upload_stats(), ctx.prover_device_bytes(), ctx.last_round_ms()
         assert info["composition_path"] == 1             # the 2n-point composition (2^25 points) after a clean trace check
-        assert up["kind"].startswith("host columns") and up["bytes"] == (1 << 24) * 34 * 32
+        assert up["kind"].startswith("run image") and up["bytes"] < 0.1 * (1 << 24) * 34 * 32
+        ctx.set_option(api.SP_OPT_DEVICE_TRACE, 0)       # and the run's own page-locked table (18 GB), column group by column group
+        assert ctx.cairo_prove_run(run, opt) == proof
+        up_cols = ctx.last_upload_stats()
+        assert up_cols["kind"].startswith("host columns") and up_cols["bytes"] == (1 << 24) * 34 * 32
+        ctx.set_option(api.SP_OPT_DEVICE_TRACE, 1)
         assert api.cairo_verify(proof, run.public_inputs_c, opt)
         bad = bytearray(proof)
         bad[len(bad) // 3] ^= 0x10

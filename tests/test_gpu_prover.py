@@ -144,8 +144,14 @@ def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
     st_rows = hip_ctx.last_upload_stats()
     assert rows == want
     assert st_rows["kind"].startswith("row-major") and st_rows["groups"] > 3 and st_rows["bytes"] == trace.nbytes
-    by_run = hip_ctx.cairo_prove_run(run, opt)
-    st_run = hip_ctx.last_upload_stats()
+    assert hip_ctx.cairo_prove_run(run, opt) == want               # (default: the trace built on the device from the run)
+    assert hip_ctx.last_upload_stats()["kind"].startswith("run image")
+    hip_ctx.set_option(api.SP_OPT_DEVICE_TRACE, 0)
+    try:
+        by_run = hip_ctx.cairo_prove_run(run, opt)
+        st_run = hip_ctx.last_upload_stats()
+    finally:
+        hip_ctx.set_option(api.SP_OPT_DEVICE_TRACE, 1)
     assert by_run == want
     assert st_run["kind"].startswith("host columns") and st_run["bytes"] == trace.nbytes and st_run["gather_ms"] == 0
     addr, n, c, pinned = run.columns()
