@@ -83,7 +83,8 @@ def test_cfg5_shape_eight_ranks_two_cosets_each(hip_lib, backend):
     per_rank = []
     for rank, digest, dev_bytes, info, stats in sorted(got):
         assert digest == want, (rank, digest[:400])
-        assert info["groups"] == WORLD and info["interpolation_sharded"] == 1 and info["composition_path"] == 1
+        # (interpolation: the link model's choice - on every rank at 46 GB/s per link; by column is pinned in test_gpu_multirank*.py)
+        assert info["groups"] == WORLD and info["interpolation_sharded"] == 0 and info["composition_path"] == 1
         assert info["fri_sharded_layers"] >= 5          # layers of >= 2^16 leaves keep their evaluations and trees sharded
         assert stats["alltoall_calls"] >= 3 + info["fri_sharded_layers"]
         per_rank.append(dev_bytes)
