@@ -110,6 +110,13 @@ int sp_comm_init_null(sp_ctx* ctx, int world, int rank);
  * (grouped ncclSend/ncclRecv on the context stream).  Call after sp_set_collective. */
 typedef int (*sp_alltoall_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_pair);
 int sp_set_alltoall(sp_ctx* ctx, sp_alltoall_fn fn);
+/* Stream-ordered form of the all-to-all (same layout as sp_alltoall_fn), optional: with it AND sp_set_collective_async the digest
+ * exchange and the root all-gather of a commitment are enqueued on the prover's compute stream between the kernels that produce and
+ * consume them instead of each costing a host round trip, and the FRI commit phase runs through its sharded layers without any - the
+ * launch that finishes a layer's top tree takes the transcript step on the device (fri/mod.rs:37-67 is one dependent chain).
+ * sp_comm_init_rccl installs it (grouped ncclSend / ncclRecv on the stream it is given).  Call after sp_set_collective. */
+typedef int (*sp_alltoall_async_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_pair, void* hip_stream);
+int sp_set_alltoall_async(sp_ctx* ctx, sp_alltoall_async_fn fn);
 /* Collective traffic of this context since creation: out = {world, all-gather calls, bytes contributed to all-gathers,
  * all-to-all calls, bytes sent in all-to-alls, bytes received in all collectives}. */
 int sp_comm_stats(sp_ctx* ctx, uint64_t out[6]);

@@ -488,36 +488,51 @@ _HOST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
 class StagedAsyncAllGather:
-    """Test aid for the stream-ordered all-gather hook (sp_set_collective_async) when the ranks share one GPU: the exchange is a
-    device-to-host copy, a host function (hipLaunchHostFunc) that runs a gloo all_gather on a process group OF ITS OWN - it runs
-    beside the blocking hooks' collectives of the main thread - and a host-to-device copy, all enqueued on the stream the prover
-    hands over.  Production runs use the library's RCCL communicator (ncclAllGather on that stream)."""
+    """Test aid for the stream-ordered hooks (sp_set_collective_async, sp_set_alltoall_async) when the ranks share one GPU: an exchange
+    is a device-to-host copy, a host function (hipLaunchHostFunc) that runs the gloo collective on a process group OF ITS OWN - one
+    per stream the prover enqueues on (its communication stream, its compute stream), beside the blocking hooks' collectives of the
+    main thread - and a host-to-device copy, all enqueued on the stream the prover hands over.  Production runs use the library's
+    RCCL communicator (ncclAllGather / grouped ncclSend + ncclRecv on that stream)."""
 
-    def __init__(self):
+    def __init__(self, alltoall=True):
         import torch.distributed as dist
         self.dist = dist
-        self.group = dist.new_group(backend="gloo")
+        self.groups = [dist.new_group(backend="gloo"), dist.new_group(backend="gloo")]
+        self.stream_slot = {}                  # stream handle -> group index, in the order the streams are first seen (the same on every rank)
         self.world = dist.get_world_size()
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
         self.hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
         self.hip.hipLaunchHostFunc.argtypes = [ctypes.c_void_p, _HOST_FN, ctypes.c_void_p]
+        self.hip.hipHostFree.argtypes = [ctypes.c_void_p]
         self.pending, self.calls = {}, 0
+        self.live, self.ran = [], {}           # staging buffers in flight; per stream slot, the last call whose host function has run
         self.cfn = ALLGATHER_ASYNC_FN(self._call)
+        self.a2a_cfn = ALLGATHER_ASYNC_FN(self._call_a2a) if alltoall else None     # sp_alltoall_async_fn has the same C signature
         self.hostfn = _HOST_FN(self._host)
 
-    def _call(self, user, send, recv, nbytes, stream):
+    def _enqueue(self, kind, send, recv, send_bytes, recv_bytes, stream):
         try:
+            key = int(stream or 0)
+            if key not in self.stream_slot:
+                self.stream_slot[key] = len(self.stream_slot)
+            slot = self.stream_slot[key]
+            # (a stream runs in order: once the host function of a LATER call on it has run, the copies of an earlier one are done)
+            done = [b for b in self.live if b[0] == slot and b[1] < self.ran.get(slot, 0)]
+            for b in done:
+                self.hip.hipHostFree(b[2]); self.hip.hipHostFree(b[3])
+                self.live.remove(b)
             hs, hr = ctypes.c_void_p(), ctypes.c_void_p()
-            if self.hip.hipHostMalloc(ctypes.byref(hs), nbytes, 0) != 0 or self.hip.hipHostMalloc(ctypes.byref(hr), nbytes * self.world, 0) != 0:
+            if self.hip.hipHostMalloc(ctypes.byref(hs), send_bytes, 0) != 0 or self.hip.hipHostMalloc(ctypes.byref(hr), recv_bytes, 0) != 0:
                 return -1
             self.calls += 1
-            self.pending[self.calls] = (hs.value, hr.value, nbytes)
-            if self.hip.hipMemcpyAsync(hs, send, nbytes, 2, stream) != 0:
+            self.live.append((slot, self.calls, hs.value, hr.value))
+            self.pending[self.calls] = (kind, hs.value, hr.value, send_bytes, recv_bytes, slot)
+            if self.hip.hipMemcpyAsync(hs, send, send_bytes, 2, stream) != 0:
                 return -2
             if self.hip.hipLaunchHostFunc(stream, self.hostfn, ctypes.c_void_p(self.calls)) != 0:
                 return -3
-            if self.hip.hipMemcpyAsync(recv, hr, nbytes * self.world, 1, stream) != 0:
+            if self.hip.hipMemcpyAsync(recv, hr, recv_bytes, 1, stream) != 0:
                 return -4
             return 0
         except Exception:  # never let an exception cross the C boundary
@@ -525,15 +540,28 @@ class StagedAsyncAllGather:
             traceback.print_exc()
             return -5
 
+    def _call(self, user, send, recv, nbytes, stream):
+        return self._enqueue("allgather", send, recv, nbytes, nbytes * self.world, stream)
+
+    def _call_a2a(self, user, send, recv, nbytes, stream):
+        return self._enqueue("alltoall", send, recv, nbytes * self.world, nbytes * self.world, stream)
+
     def _host(self, key):
         try:
             import torch
-            hs, hr, nbytes = self.pending[int(key)]
-            mine = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(hs)).copy())
-            outs = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(self.world)]
-            self.dist.all_gather(outs, mine, group=self.group)
-            for i, o in enumerate(outs):
-                ctypes.memmove(hr + i * nbytes, o.data_ptr(), nbytes)
+            kind, hs, hr, send_bytes, recv_bytes, slot = self.pending.pop(int(key))
+            group = self.groups[slot]
+            mine = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * send_bytes).from_address(hs)).copy())
+            if kind == "allgather":
+                outs = [torch.empty(send_bytes, dtype=torch.uint8) for _ in range(self.world)]
+                self.dist.all_gather(outs, mine, group=group)
+                for i, o in enumerate(outs):
+                    ctypes.memmove(hr + i * send_bytes, o.data_ptr(), send_bytes)
+            else:
+                out = torch.empty(recv_bytes, dtype=torch.uint8)
+                self.dist.all_to_all_single(out, mine, group=group)
+                ctypes.memmove(hr, out.data_ptr(), recv_bytes)
+            self.ran[slot] = max(self.ran.get(slot, 0), int(key))
         except Exception:
             import traceback
             traceback.print_exc()
@@ -543,6 +571,8 @@ def _ctx_set_collective_async(self, hook):
     """Install a stream-ordered all-gather hook (sp_set_collective_async); call after set_collective."""
     self._async_hook = hook  # keep the callbacks alive
     check(self._lib.sp_set_collective_async(self._h, hook.cfn if hook is not None else None))
+    if hook is not None and getattr(hook, "a2a_cfn", None) is not None:
+        check(self._lib.sp_set_alltoall_async(self._h, hook.a2a_cfn))
 
 
 def _ctx_set_collective(self, world, rank, hook, alltoall=True):

@@ -71,13 +71,19 @@ int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* 
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) || (world > 1 && !fn)) return SP_E_INVALID_ARG;
     delete c->prover_state_deleter_holder;   // a prover shaped for another world size must not survive
     c->prover_state_deleter_holder = nullptr;
-    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr; c->allgather_async = nullptr;
+    c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr; c->allgather_async = nullptr; c->alltoall_async = nullptr;
     return SP_OK;
 }
 
 int sp_set_collective_async(sp_ctx* c, sp_allgather_async_fn fn) {
     if (!c) return SP_E_INVALID_ARG;
     c->allgather_async = fn;
+    return SP_OK;
+}
+
+int sp_set_alltoall_async(sp_ctx* c, sp_alltoall_async_fn fn) {
+    if (!c) return SP_E_INVALID_ARG;
+    c->alltoall_async = fn;
     return SP_OK;
 }
 
@@ -148,17 +154,23 @@ int rccl_allgather_async(void* user, const void* send, void* recv, uint64_t byte
     return ncclAllGather(send, recv, bytes, ncclUint8, rc->comm, static_cast<hipStream_t>(stream)) == ncclSuccess ? 0 : -1;
 }
 // all-to-all of equal blocks as grouped point-to-point transfers (xGMI is point-to-point: every pair uses its own link)
-int rccl_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
+int rccl_alltoall_async(void* user, const void* send, void* recv, uint64_t bytes, void* stream) {
     RcclComm* rc = static_cast<RcclComm*>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
     const uint8_t* s = static_cast<const uint8_t*>(send);
     uint8_t* r = static_cast<uint8_t*>(recv);
     if (ncclGroupStart() != ncclSuccess) return -1;
     int rcode = 0;   // the group is closed whatever happens inside it: a communicator left in group mode queues every later call
     for (int peer = 0; peer < rc->world && rcode == 0; ++peer) {
-        if (ncclSend(s + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) rcode = -3;
-        else if (ncclRecv(r + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, rc->stream) != ncclSuccess) rcode = -4;
+        if (ncclSend(s + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, st) != ncclSuccess) rcode = -3;
+        else if (ncclRecv(r + (size_t)peer * bytes, bytes, ncclUint8, peer, rc->comm, st) != ncclSuccess) rcode = -4;
     }
     if (ncclGroupEnd() != ncclSuccess && rcode == 0) rcode = -5;
+    return rcode;
+}
+int rccl_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
+    RcclComm* rc = static_cast<RcclComm*>(user);
+    const int rcode = rccl_alltoall_async(user, send, recv, bytes, rc->stream);
     if (rcode != 0) return rcode;
     if (hipStreamSynchronize(rc->stream) != hipSuccess) return -2;
     return 0;
@@ -189,11 +201,17 @@ int null_allgather_async(void* user, const void* send, void* recv, uint64_t byte
     if (nc->rank + 1 < nc->world && hipMemsetAsync(mine + bytes, 0, (size_t)(nc->world - 1 - nc->rank) * bytes, st) != hipSuccess) return -1;
     return 0;
 }
+int null_alltoall_async(void* user, const void* send, void* recv, uint64_t bytes, void* stream) {
+    NullComm* nc = static_cast<NullComm*>(user);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    uint8_t* r = static_cast<uint8_t*>(recv);
+    if (hipMemsetAsync(r, 0, (size_t)nc->world * bytes, st) != hipSuccess) return -1;
+    if (hipMemcpyAsync(r + (size_t)nc->rank * bytes, static_cast<const uint8_t*>(send) + (size_t)nc->rank * bytes, bytes, hipMemcpyDeviceToDevice, st) != hipSuccess) return -1;
+    return 0;
+}
 int null_alltoall(void* user, const void* send, void* recv, uint64_t bytes) {
     NullComm* nc = static_cast<NullComm*>(user);
-    uint8_t* r = static_cast<uint8_t*>(recv);
-    if (hipMemsetAsync(r, 0, (size_t)nc->world * bytes, nc->stream) != hipSuccess) return -1;
-    if (hipMemcpyAsync(r + (size_t)nc->rank * bytes, static_cast<const uint8_t*>(send) + (size_t)nc->rank * bytes, bytes, hipMemcpyDeviceToDevice, nc->stream) != hipSuccess) return -1;
+    if (null_alltoall_async(user, send, recv, bytes, nc->stream) != 0) return -1;
     return hipStreamSynchronize(nc->stream) == hipSuccess ? 0 : -2;
 }
 }  // namespace
@@ -206,6 +224,7 @@ int sp_comm_init_null(sp_ctx* c, int world, int rank) {
     c->comm_holder = nc;
     SP_TRY(sp_set_collective(c, world, rank, null_allgather, nc));
     SP_TRY(sp_set_collective_async(c, null_allgather_async));
+    SP_TRY(sp_set_alltoall_async(c, null_alltoall_async));
     return sp_set_alltoall(c, null_alltoall);
 }
 
@@ -230,6 +249,7 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     c->comm_holder = rc;
     SP_TRY(sp_set_collective(c, world, rank, rccl_allgather, rc));
     SP_TRY(sp_set_collective_async(c, rccl_allgather_async));
+    SP_TRY(sp_set_alltoall_async(c, rccl_alltoall_async));
     return sp_set_alltoall(c, rccl_alltoall);
 }
 

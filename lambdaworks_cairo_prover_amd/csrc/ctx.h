@@ -31,6 +31,7 @@ struct sp_ctx {
     // stream-ordered form of the all-gather (sp_comm_init_rccl, sp_set_collective_async): enqueued on the given stream, returns at
     // once - lets the prover run an exchange beside its transforms instead of in front of them
     sp_allgather_async_fn allgather_async = nullptr;
+    sp_alltoall_async_fn alltoall_async = nullptr;
     void* allgather_user = nullptr;
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option

@@ -396,7 +396,13 @@ int StarkProver::full_domain_buffer(fe** out) {
 
 // Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank]
 // (the first G slots are the G distinct roles).
-int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank) {
+int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, bool stream_ordered) {
+    if (stream_ordered && comm_async()) {
+        const int rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, c_->stream);
+        if (rc != 0) { sp_set_error("stream-ordered all-gather failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+        c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
+        return SP_OK;
+    }
     SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
     int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
     if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
@@ -428,8 +434,14 @@ int StarkProver::all_gather_end(int slot) {
 
 // Block d of `send` goes to the rank with role d; recv[s] = what role s addressed to this rank.  One all-to-all when the
 // hook exists (every rank is its own role then); otherwise an all-gather of the whole send array and a local selection.
-int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes) {
-    if (c_->alltoall && world_ == G_) {
+int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes, bool stream_ordered) {
+    if (stream_ordered && comm_async() && c_->alltoall_async && world_ == G_) {
+        const int rc = c_->alltoall_async(c_->allgather_user, send_dev, recv_dev, bytes, c_->stream);
+        if (rc != 0) { sp_set_error("stream-ordered all-to-all failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
+        c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
+        return SP_OK;
+    }
+    if (c_->alltoall && world_ == G_ && !(stream_ordered && comm_async())) {
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         int rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes);
         if (rc != 0) { sp_set_error("all-to-all hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
@@ -438,7 +450,7 @@ int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t 
     }
     const uint64_t per_rank = bytes * G_;
     SP_TRY(ensure_gather((per_rank * world_ + sizeof(fe) - 1) / sizeof(fe)));
-    SP_TRY(all_gather(send_dev, d_gather_, per_rank));
+    SP_TRY(all_gather(send_dev, d_gather_, per_rank, stream_ordered));
     const uint8_t* g = reinterpret_cast<const uint8_t*>(d_gather_);
     for (uint32_t src = 0; src < G_; ++src)   // the first G slots are the G roles
         SP_HIP_CHECK(hipMemcpyAsync(static_cast<uint8_t*>(recv_dev) + (uint64_t)src * bytes, g + (uint64_t)src * per_rank + (uint64_t)rank_ * bytes, bytes,
@@ -451,7 +463,7 @@ int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t 
 // [d N/G, (d+1) N/G) - block d of the local digest array is exactly this rank's share of that range - then every rank reduces
 // its subtree, the G subtree roots are all-gathered and the top log2 G levels finished everywhere.
 int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32],
-                              bool single_element_tree) {
+                              bool single_element_tree, const FriChallenge* ch) {
     const MerkleHash mh = merkle_hash(single_element_tree);
     const bool head_done = leaf_head_done_;
     leaf_head_done_ = false;
@@ -460,18 +472,21 @@ int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncol
             SP_TRY(merkle_hash_leaves_tail(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<const uint64_t*>(d_scratch_), tree.sub, order));
         else
         SP_TRY(merkle_hash_leaves(c_->stream, cols_dev, stride, ncols, L, tree.sub, order, mh));
-        SP_TRY(merkle_reduce(c_->stream, tree.sub, L, nullptr, mh));
+        SP_TRY(merkle_reduce(c_->stream, tree.sub, L, ch, mh));
     } else {
         if (L != tree.sub_leaves || L > Nl_) return SP_E_STATE;
+        // (both exchanges are consumed on the compute stream, and the read-back of the root below waits for it: stream-ordered
+        // where the transport can - two host round trips less per commitment)
         SP_TRY(merkle_hash_leaves_flat(c_->stream, cols_dev, stride, ncols, L, reinterpret_cast<digest32*>(d_local_), order, mh));
-        SP_TRY(exchange_blocks(d_local_, d_recv_, (L >> logG_) * sizeof(digest32)));
+        SP_TRY(exchange_blocks(d_local_, d_recv_, (L >> logG_) * sizeof(digest32), true));
         // recv[s][j] = leaf (first + j) G + s of the global order = leaf j G + s of this rank's range
         SP_TRY(interleave_shards(c_->stream, d_recv_, tree.sub + (L - 1), L >> logG_, ShardMap{logG_, logG_, 0}));
         SP_TRY(merkle_reduce(c_->stream, tree.sub, L, nullptr, mh));
-        SP_TRY(all_gather(tree.sub, d_roots_, sizeof(digest32)));
+        SP_TRY(all_gather(tree.sub, d_roots_, sizeof(digest32), true));
         SP_HIP_CHECK(hipMemcpyAsync(tree.top + (G_ - 1), d_roots_, G_ * sizeof(digest32), hipMemcpyDeviceToDevice, c_->stream));
-        SP_TRY(merkle_reduce(c_->stream, tree.top, G_, nullptr, mh));
+        SP_TRY(merkle_reduce(c_->stream, tree.top, G_, ch, mh));
     }
+    if (ch) return SP_OK;
     return readback(root_out, tree.top, 32);
 }
 
@@ -543,7 +558,7 @@ int StarkProver::commit_trace_rows_sharded(int segment, const uint8_t* rows_host
     fe* stage = nullptr;
     if ((uint64_t)world_ * block <= std::max<uint64_t>(Nl_, n_) * cols) stage = d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_);
     else { SP_TRY(ensure_gather((uint64_t)world_ * block)); stage = d_gather_; }
-    SP_TRY(all_gather(trace + (uint64_t)first_col(rank_) * n_, stage, block * sizeof(fe)));
+    SP_TRY(all_gather(trace + (uint64_t)first_col(rank_) * n_, stage, block * sizeof(fe), true));
     for (uint32_t role = 0; role < G_; ++role) {      // (the first G slots are the G roles; the own block is in place already)
         if (role == rank_) continue;
         SP_HIP_CHECK(hipMemcpyAsync(trace + (uint64_t)first_col(role) * n_, stage + (uint64_t)role * block, block * sizeof(fe), hipMemcpyDeviceToDevice, c_->stream));
@@ -1020,6 +1035,8 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     // points of the cosets 0 and b/2 only; otherwise (the reference still proves such traces, with longer H1/H2) fall
     // back to the whole domain and the general split, so the bytes are identical for every input.
     int flag = 0;
+    int flag_pref = 0;
+    bool pair_flag_pending = false;
     bool sub_coset = allow_sub_coset && logb_ >= logG_ + 1;  // this rank holds both cosets c0 = rank and c0 + b/2 (always on one GPU)
     // one coset per rank (G = b): the 2n points of the cosets 0 and b/2 live on two ranks - every rank evaluates its own coset, the
     // evaluations are all-gathered and the pair (0, b/2) is interpolated everywhere
@@ -1030,7 +1047,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         if (!prog_dev && world_ > 1 && n_ >= 256ull * world_) {
             // every rank checked its own n / world rows of the (replicated) trace: one flag per rank, combined everywhere
             if (!d_flags_all_) SP_TRY(alloc((void**)&d_flags_all_, sizeof(int) * world_));
-            SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int)));
+            SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int), true));
             std::vector<int> flags(world_, 0);
             SP_HIP_CHECK(hipMemcpyAsync(flags.data(), d_flags_all_, sizeof(int) * world_, hipMemcpyDeviceToHost, c_->stream));
             SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // (also: K is a stack object)
@@ -1065,7 +1082,6 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
             SP_TRY(coset_minus_points(c_->stream, binv, M, logn_ + 1, roots_m, hp, points.data(), nd, ShardMap{0, 0, 0}));
             SP_TRY(batch_inverse(c_->stream, binv, inv_scratch, (uint64_t)nd * M, c_->d_flag));
         }
-        int flag_pref = 0;
         if (nd && pref) SP_HIP_CHECK(hipMemcpyAsync(&flag_pref, d_flag_side_ + 1, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         fe* comp2 = d_h12s_;                      // [2n] evaluations H(h w_2n^i), then [H1s | H2s]
         SP_TRY(evaluate(M, logb_ - logG_ - 1, binv, comp2));
@@ -1074,8 +1090,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         // 2n c_j hp^j for j = 2k, position n + q for j = 2k + 1 (k = rev_n(q)); the post factors leave a_k h^k = c_2k h^k
         // and b_k h^k = c_(2k+1) h^k:  (2n)^-1 (h^-1 u^2)^k  and  (2n)^-1 (h^-1 u) (h^-1 u^2)^k,  u = w_N^-c0.
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(comp2, (int)logn_ + 1, 1, M, d_post_comp_));   // (tables: setup())
-        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
-        if (flag | flag_pref) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        pair_flag_pending = true;                 // the two flags are looked at behind the commitment's read-back: no wait of its own here
         h_full_ = false;
         SP_TRY(c_->ntt->lde_coset_major(d_h12s_, d_h12_, (int)logn_, (int)logb_, 2, n_, Nl_, (int)logG_, (int)rank_));
     } else if (pair_path) {
@@ -1088,8 +1103,8 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         SP_TRY(evaluate(Nl_, 0, binv, d_local_));                   // H on this rank's coset
         SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
         SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
-        SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(fe)));    // (synchronises: flag is valid)
-        if (flag) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
+        SP_TRY(all_gather(d_local_, d_gather_, Nl_ * sizeof(fe), true));
+        pair_flag_pending = true;                                    // (checked behind the commitment's read-back, which waits for the stream)
         const uint32_t other = G_ >> 1;                              // the rank that holds coset b/2
         if (other != 1) SP_HIP_CHECK(hipMemcpyAsync(d_gather_ + n_, d_gather_ + (uint64_t)other * n_, n_ * sizeof(fe), hipMemcpyDeviceToDevice, c_->stream));
         fe* comp2 = d_h12s_;                                         // H(h w_2n^i): even i from coset 0, odd i from coset b/2
@@ -1109,7 +1124,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
         SP_TRY(evaluate(Nl_, 0, binv, comp_local));
         if (G_ > 1) {  // composition-polynomial reduction: all-gather the per-coset evaluations
             SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
-            SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe)));
+            SP_TRY(all_gather(comp_local, d_gather_, Nl_ * sizeof(fe), true));
             SP_TRY(interleave_shards(c_->stream, d_gather_, comp, n_, shard_map()));
         }
         // --- interpolate_offset_fft + even/odd split (reference evaluation_table.rs:27-33, prover.rs:250-252)
@@ -1143,6 +1158,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     c_->proof_info[0] = (sub_coset || pair_path) ? 1u : (h_full_ ? 3u : 2u);
     c_->proof_info[1] = fri_rep_; c_->proof_info[2] = G_; c_->proof_info[3] = (G_ > 1 && shard_interp_) ? 1u : 0u;
     SP_TRY(commit_columns(d_h12_, Nl_, 2, tree_comp_, root_out));
+    if (pair_flag_pending && (flag | flag_pref)) { sp_set_error("composition: zero boundary denominator"); return SP_E_ZERO_INVERSE; }
     stage_ = 4;
     return SP_OK;
 }
@@ -1342,7 +1358,7 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, Nl_, Nl_, 0, d_deep_consts_, inv, p0_local, lde_order(), R));
         if (G_ > 1 && !fri_sharded(0)) {
             SP_TRY(ensure_gather((uint64_t)world_ * Nl_));
-            SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe)));
+            SP_TRY(all_gather(p0_local, d_gather_, Nl_ * sizeof(fe), true));
             SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[0], n_, shard_map()));
         }
     }
@@ -1377,7 +1393,7 @@ int StarkProver::fri_fold_commit(const fe& zeta, uint8_t root_out[32], fe* last_
         SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], next_local, Ml, logN_, k, roots, half, cst, logG_, rank_));
         if (!fri_sharded(k + 1)) {   // from here on the layers are small: gather this one once and continue on every rank
             SP_TRY(ensure_gather((uint64_t)world_ * (Ml >> 1)));
-            SP_TRY(all_gather(next_local, d_gather_, (Ml >> 1) * sizeof(fe)));
+            SP_TRY(all_gather(next_local, d_gather_, (Ml >> 1) * sizeof(fe), true));
             SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[k + 1], (Ml >> 1), ShardMap{logG_, logG_, 0}));
         }
     } else {
@@ -1429,16 +1445,35 @@ int StarkProver::fri_commit_chain(const fe& zeta0, const uint8_t state32[32], st
     const fe cst0 = fe_mul(fe_mul(zeta0, half_), fri_offset_inv_);
     for (uint32_t k = k0; k < L; ++k) {           // fold layer k into layer k + 1 and commit it
         const uint64_t M = N_ >> k;
+        const fe* c_dev = k == k0 ? nullptr : d_cst + k;   // zeta_k half / offset_k: left in device memory by the launch that produced root k
+        const bool sharded_k = fri_sharded(k), sharded_k1 = k + 1 < L && fri_sharded(k + 1);
         static const bool fused = std::getenv("SP_FRI_NO_FUSED_LEAVES") == nullptr;      // (A/B switch)
-        const bool fuse = fused && k + 1 < L && merkle_hash(true) == MerkleHash::KECCAK256;
-        if (fuse) SP_TRY(fri_fold_hash(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, k == k0 ? nullptr : d_cst + k,
-                                       fri_trees_[k + 1].sub + (fri_trees_[k + 1].sub_leaves - 1)));
-        else SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, k == k0 ? nullptr : d_cst + k));
+        const bool fuse = fused && !sharded_k && k + 1 < L && merkle_hash(true) == MerkleHash::KECCAK256;
+        if (sharded_k) {
+            // several ranks, stream-ordered transport: the fold is local to a rank (the partner i + M/2 has the same residue mod G)
+            const uint64_t Ml = M >> logG_;
+            fe* next_local = sharded_k1 ? d_fri_evals_[k + 1] : d_local_;
+            SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], next_local, Ml, logN_, k, roots, half_, cst0, logG_, rank_, c_dev));
+            if (!sharded_k1) {   // from here on the layers are small: gathered once, continued on every rank
+                SP_TRY(ensure_gather((uint64_t)world_ * (Ml >> 1)));
+                SP_TRY(all_gather(next_local, d_gather_, (Ml >> 1) * sizeof(fe), true));
+                SP_TRY(interleave_shards(c_->stream, d_gather_, d_fri_evals_[k + 1], (Ml >> 1), ShardMap{logG_, logG_, 0}));
+            }
+        } else if (fuse) {
+            SP_TRY(fri_fold_hash(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, c_dev,
+                                 fri_trees_[k + 1].sub + (fri_trees_[k + 1].sub_leaves - 1)));
+        } else {
+            SP_TRY(fri_fold(c_->stream, d_fri_evals_[k], d_fri_evals_[k + 1], M, logN_, k, roots, half_, cst0, 0, 0, c_dev));
+        }
         if (k + 1 < L) {
             TreeBuf& t = fri_trees_[k + 1];
-            if (!fuse) SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}, merkle_hash(true)));
             const FriChallenge ch{d_state, d_cmul + (k + 1), d_cst + (k + 1), d_roots + 4 * (size_t)(k + 1)};
-            SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch, merkle_hash(true)));
+            if (sharded_k1) {
+                SP_TRY(commit_local(d_fri_evals_[k + 1], 0, 1, t.sub_leaves, LdeOrder{0, 0, 0}, t, nullptr, true, &ch));
+            } else {
+                if (!fuse) SP_TRY(merkle_hash_leaves(c_->stream, d_fri_evals_[k + 1], 0, 1, t.sub_leaves, t.sub, LdeOrder{0, 0, 0}, merkle_hash(true)));
+                SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, &ch, merkle_hash(true)));
+            }
         }
     }
     for (uint32_t k = k0; k < L; ++k) { fri_offset_ = fe_sqr(fri_offset_); fri_offset_inv_ = fe_sqr(fri_offset_inv_); }
@@ -1569,7 +1604,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     SP_TRY(gather_jobs(st, d_jobs, (uint32_t)jobs.size(), max_items, d_idx, blk));
     std::vector<fe> host(items * (G_ > 1 ? world_ : 1));
     if (G_ > 1) {
-        SP_TRY(all_gather(blk, all_dev, blk_bytes));
+        SP_TRY(all_gather(blk, all_dev, blk_bytes, true));
         SP_HIP_CHECK(hipMemcpyAsync(host.data(), all_dev, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
     } else {
         SP_HIP_CHECK(hipMemcpyAsync(host.data(), blk, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));

@@ -79,9 +79,10 @@ class StarkProver : public sp_deletable {
     // in device memory for the next layer.  state32 = the transcript buffer after that zeta was sampled (32 bytes); roots_out =
     // the roots of the layers committed here (those after the last one committed before the call), which the caller feeds to its
     // own transcript afterwards.
-    // Several ranks: available from the first layer every rank holds whole (the sharded layers in front of it go through
-    // fri_fold_commit, one exchange each); the caller passes the zeta of the layer to fold next.
-    bool fri_chain_available() const { return stage_ == 6 && logn_ >= 2 && fri_layer_ >= 1 && !fri_sharded(fri_layer_ - 1); }
+    // Several ranks: with a stream-ordered transport the sharded layers are part of the chain (their digest exchange and root
+    // all-gather sit on the compute stream); with blocking hooks it is available from the first layer every rank holds whole (the
+    // sharded layers in front of it go through fri_fold_commit, one exchange each).  The caller passes the zeta of the layer to fold next.
+    bool fri_chain_available() const { return stage_ == 6 && logn_ >= 2 && fri_layer_ >= 1 && (!fri_sharded(fri_layer_ - 1) || comm_async()); }
     int fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value);
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
     int open(const std::vector<uint64_t>& iotas, Openings& out);
@@ -119,8 +120,10 @@ class StarkProver : public sp_deletable {
     bool ready_ = false;   // setup() completed: every buffer below exists
     // Commitment over `L` leaves this rank holds in local natural order (leaf l = global leaf (l << logG) | rank): hash,
     // exchange the digests so that every rank owns a contiguous range, reduce the subtree, combine the G roots.
+    // ch (FRI commit chain): the launch that produces the root also takes the transcript step (merkle.h, FriChallenge); nothing is read
+    // back, root_out is not written
     int commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncols, uint64_t L, LdeOrder order, TreeBuf& tree, uint8_t root_out[32],
-                     bool single_element_tree = false);
+                     bool single_element_tree = false, const FriChallenge* ch = nullptr);
     // the hash of the commitments (sp_set_option SP_OPT_MERKLE_BACKEND): rows of columns, or the single elements of a FRI layer
     MerkleHash merkle_hash(bool single_element_tree) const {
         return c_->opt_merkle_backend == SP_MERKLE_POSEIDON ? (single_element_tree ? MerkleHash::POSEIDON_SINGLE : MerkleHash::POSEIDON_BATCH)
@@ -191,7 +194,9 @@ class StarkProver : public sp_deletable {
     int ensure_deep_scratch(uint64_t elems);
     fe* d_deepx_ = nullptr; uint64_t deepx_cap_ = 0;   // DEEP inverses when they outgrow the shared scratch
     int full_domain_buffer(fe** out);
-    int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
+    // stream_ordered: the caller consumes the result on the compute stream only (or waits for that stream itself): with a transport
+    // that can enqueue on a stream the exchange takes its place between the kernels instead of costing a host round trip
+    int all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, bool stream_ordered = false);
     // The same in two halves: begin() starts the exchange behind everything queued on the compute stream so far - on the
     // communication stream when the transport is stream-ordered, by blocking in the hook otherwise - and end() makes the compute
     // stream wait for it.  What is queued on the compute stream between the two runs beside the exchange.
@@ -202,7 +207,7 @@ class StarkProver : public sp_deletable {
     int all_gather_begin(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, int slot);
     int all_gather_end(int slot);
     // recv[s] = the block rank s addressed to this role: send = [G][bytes], recv = [G][bytes]
-    int exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes_per_block);
+    int exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes_per_block, bool stream_ordered = false);
     ShardMap shard_map() const { return ShardMap{logb_, logG_, rank_}; }
     bool has_rc_ = false;
     fe h_, hinv_, g_;                       // coset offset, its inverse, trace generator

@@ -100,3 +100,19 @@ def test_run_column_store_matches_the_row_major_trace():
     # the lambdaworks limb encoding of the same table
     lw = run.main_trace(api.SP_FE_MONT_LIMBS)
     assert np.array_equal(api.fe_to_device(lw.reshape(-1, 32), api.SP_FE_MONT_LIMBS).reshape(n, c, 32), raw.transpose(1, 0, 2))
+
+
+def test_run_builds_its_host_table_on_demand_only(hip_lib):
+    """A run validates its trace and fixes its shape at creation (the shape pass of build_main_trace) but writes the n x cols host
+    table only when something asks for it - sp_cairo_prove_run builds the trace on the device from the register states and the
+    memory (sp_cairo_run_timings reports the split)."""
+    run = api.CairoRun.fibonacci(500)
+    t = run.timings()
+    assert set(t) == {"vm_ms", "trace_shape_ms", "device_image_ms", "host_table_ms"}
+    assert t["host_table_ms"] == 0.0 and t["vm_ms"] > 0.0 and run.n_rows == 4096 and run.n_cols == 34
+    table = run.main_trace()
+    assert table.shape == (4096, 34, 32) and run.timings()["host_table_ms"] > 0.0
+    # a program that fails validation fails at run creation, as it did when the table was built eagerly
+    import pytest
+    with pytest.raises(api.SpError):
+        api.CairoRun.from_program([0x480680017FFF8000, 3, 0x400680017FFF7FFF, 4, 0x208B7FFF7FFF7FFE], max_steps=64)   # assert 3 == 4
