@@ -441,7 +441,7 @@ int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t 
         c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
         return SP_OK;
     }
-    if (c_->alltoall && world_ == G_ && !(stream_ordered && comm_async())) {
+    if (c_->alltoall && world_ == G_) {   // (also with a stream-ordered all-gather but no such all-to-all: one host round trip beats G times the bytes)
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
         int rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes);
         if (rc != 0) { sp_set_error("all-to-all hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
