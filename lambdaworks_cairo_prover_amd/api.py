@@ -506,6 +506,7 @@ class StagedAsyncAllGather:
         self.hip.hipLaunchHostFunc.argtypes = [ctypes.c_void_p, _HOST_FN, ctypes.c_void_p]
         self.hip.hipHostFree.argtypes = [ctypes.c_void_p]
         self.pending, self.calls = {}, 0
+        self.pool = {}                         # free page-locked staging buffers by size
         self.live, self.ran = [], {}           # staging buffers in flight; per stream slot, the last call whose host function has run
         self.cfn = ALLGATHER_ASYNC_FN(self._call)
         self.a2a_cfn = ALLGATHER_ASYNC_FN(self._call_a2a) if alltoall else None     # sp_alltoall_async_fn has the same C signature
@@ -519,14 +520,22 @@ class StagedAsyncAllGather:
             slot = self.stream_slot[key]
             # (a stream runs in order: once the host function of a LATER call on it has run, the copies of an earlier one are done)
             done = [b for b in self.live if b[0] == slot and b[1] < self.ran.get(slot, 0)]
-            for b in done:
-                self.hip.hipHostFree(b[2]); self.hip.hipHostFree(b[3])
+            for b in done:                     # back to the pool (page-locking memory costs ~0.1 ms per MB: never per call)
+                self.pool.setdefault(b[4], []).append(b[2]); self.pool.setdefault(b[5], []).append(b[3])
                 self.live.remove(b)
-            hs, hr = ctypes.c_void_p(), ctypes.c_void_p()
-            if self.hip.hipHostMalloc(ctypes.byref(hs), send_bytes, 0) != 0 or self.hip.hipHostMalloc(ctypes.byref(hr), recv_bytes, 0) != 0:
+
+            def take(nbytes):
+                free = self.pool.get(nbytes)
+                if free:
+                    return free.pop()
+                p = ctypes.c_void_p()
+                return p.value if self.hip.hipHostMalloc(ctypes.byref(p), nbytes, 0) == 0 else None
+            hs_v, hr_v = take(send_bytes), take(recv_bytes)
+            if hs_v is None or hr_v is None:
                 return -1
+            hs, hr = ctypes.c_void_p(hs_v), ctypes.c_void_p(hr_v)
             self.calls += 1
-            self.live.append((slot, self.calls, hs.value, hr.value))
+            self.live.append((slot, self.calls, hs.value, hr.value, send_bytes, recv_bytes))
             self.pending[self.calls] = (kind, hs.value, hr.value, send_bytes, recv_bytes, slot)
             if self.hip.hipMemcpyAsync(hs, send, send_bytes, 2, stream) != 0:
                 return -2

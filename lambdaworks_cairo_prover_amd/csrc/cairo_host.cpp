@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <exception>
 #include <new>
+#include <memory>
+#include <mutex>
 
 namespace sp {
 
@@ -211,8 +213,13 @@ void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& 
     P.steps = steps;
     P.cols = rc_seg ? 43 : 34;
     std::vector<uint64_t> addr(4 * steps);    // [step][pc, dst, op0, op1]
-    std::vector<uint16_t> off(3 * steps);     // [step][dst, op0, op1] (biased)
+    // every part of the pass runs on the host's threads: each chunk of steps keeps its own set of seen offsets and its own address range
+    std::mutex merge;
+    std::vector<uint64_t> seen_words(1024, 0);               // 65536 bits: the offsets some step uses
+    uint64_t lo_addr = ~0ULL, hi_addr = 0;
     host_parallel_for(steps, 4096, [&](size_t b, size_t e) {
+        std::vector<uint64_t> seen_local(1024, 0);
+        uint64_t lo = ~0ULL, hi = 0;
         for (size_t i = b; i < e; ++i) {
             const RegisterState& r = regs[i];
             const Decoded d = decode(mem_at(mem, r.pc));
@@ -225,18 +232,24 @@ void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& 
             (void)mem_at(mem, op1_addr);
             if (d.pc_update == 4 && !(d.res_logic == 0 && d.opcode == 0 && d.ap_update != 1)) throw std::runtime_error("Undefined Behavior");   // execution_trace.rs:382-440
             addr[4 * i] = r.pc; addr[4 * i + 1] = dst_addr; addr[4 * i + 2] = op0_addr; addr[4 * i + 3] = op1_addr;
-            off[3 * i] = (uint16_t)d.off_dst; off[3 * i + 1] = (uint16_t)d.off_op0; off[3 * i + 2] = (uint16_t)d.off_op1;
+            lo = std::min(std::min(lo, r.pc), std::min(dst_addr, std::min(op0_addr, op1_addr)));
+            hi = std::max(std::max(hi, r.pc), std::max(dst_addr, std::max(op0_addr, op1_addr)));
+            seen_local[d.off_dst >> 6] |= 1ULL << (d.off_dst & 63u);
+            seen_local[d.off_op0 >> 6] |= 1ULL << (d.off_op0 & 63u);
+            seen_local[d.off_op1 >> 6] |= 1ULL << (d.off_op1 & 63u);
         }
+        std::lock_guard<std::mutex> lk(merge);
+        for (size_t w = 0; w < 1024; ++w) seen_words[w] |= seen_local[w];
+        lo_addr = std::min(lo_addr, lo); hi_addr = std::max(hi_addr, hi);
     });
     // get_rc_holes (execution_trace.rs:136-185): every value strictly between the smallest and the largest offset that no step uses
     std::vector<uint16_t>& missing = P.missing;
     {
-        std::vector<uint8_t> seen(65536, 0);
-        for (uint16_t v : off) seen[v] = 1;
+        auto seen = [&](uint32_t v) { return (seen_words[v >> 6] >> (v & 63u)) & 1ULL; };
         uint32_t lo = 0, hi = 65535;
-        while (!seen[lo]) ++lo;
-        while (!seen[hi]) --hi;
-        for (uint32_t v = lo + 1; v < hi; ++v) if (!seen[v]) missing.push_back((uint16_t)v);
+        while (!seen(lo)) ++lo;
+        while (!seen(hi)) --hi;
+        for (uint32_t v = lo + 1; v < hi; ++v) if (!seen(v)) missing.push_back((uint16_t)v);
         const size_t pad = ((missing.size() + 2) / 3) * 3 - missing.size();
         for (size_t i = 0; i < pad; ++i) missing.push_back((uint16_t)hi);
         pub.range_check_min = (uint16_t)lo; pub.range_check_max = (uint16_t)hi;
@@ -245,21 +258,43 @@ void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& 
     // get_memory_holes (execution_trace.rs:195-255): the addresses above the public memory that lie between two accessed
     // addresses and are not accessed themselves, in increasing order
     std::vector<uint64_t>& holes = P.holes;
-    uint64_t hi_addr = 0;
+    uint64_t hi_addr_all = hi_addr;
     {
         const uint64_t codelen = pub.public_memory.size();
-        uint64_t lo = ~0ULL, hi = 0;
-        for (uint64_t a : addr) { lo = std::min(lo, a); hi = std::max(hi, a); }
-        hi_addr = hi;
+        const uint64_t lo = lo_addr, hi = hi_addr;
         // A run's memory is (nearly) continuous, so [lo, hi] is a small multiple of the 4 * steps accesses: presence bitmap.  A sparse
         // range (an odd or hostile dump) takes the sorted formulation, whose cost is O(accesses) before any hole is enumerated; and a
         // dump whose holes could never fit a trace is refused before gigabytes of them are collected.
         constexpr uint64_t MAX_HOLES = 1ULL << 30;
-        if (hi - lo <= 64ULL * 4 * steps + 4096) {           // presence bitmap over [lo, hi]
-            std::vector<uint64_t> bits(((hi - lo) >> 6) + 1, 0);
-            for (uint64_t a : addr) bits[(a - lo) >> 6] |= 1ULL << ((a - lo) & 63);
-            for (uint64_t h = std::max(lo + 1, codelen + 1); h < hi; ++h)
-                if (!((bits[(h - lo) >> 6] >> ((h - lo) & 63)) & 1)) holes.push_back(h);
+        if (hi - lo <= 64ULL * 4 * steps + 4096) {           // presence bitmap over [lo, hi], filled and scanned by all threads
+            const size_t words = (size_t)((hi - lo) >> 6) + 1;
+            std::unique_ptr<std::atomic<uint64_t>[]> bits(new std::atomic<uint64_t>[words]);
+            host_parallel_for(words, 1 << 16, [&](size_t b, size_t e) { for (size_t w = b; w < e; ++w) bits[w].store(0, std::memory_order_relaxed); });
+            host_parallel_for(addr.size(), 1 << 16, [&](size_t b, size_t e) {
+                for (size_t k = b; k < e; ++k) {     // (test first: every step's pc hits the same few words from every thread)
+                    const uint64_t a = addr[k] - lo, m = 1ULL << (a & 63);
+                    if (!(bits[a >> 6].load(std::memory_order_relaxed) & m)) bits[a >> 6].fetch_or(m, std::memory_order_relaxed);
+                }
+            });
+            const uint64_t first = std::max(lo + 1, codelen + 1);
+            if (first < hi) {
+                const size_t w0 = (size_t)((first - lo) >> 6), w1 = (size_t)((hi - 1 - lo) >> 6) + 1;    // words that hold [first, hi)
+                const size_t parts = std::max<size_t>(1, std::min<size_t>(64, (w1 - w0) / 4096));
+                std::vector<std::vector<uint64_t>> found(parts);
+                const size_t per = (w1 - w0 + parts - 1) / parts;
+                host_parallel_for(parts, 1, [&](size_t pb, size_t pe) {
+                    for (size_t part = pb; part < pe; ++part)
+                        for (size_t w = w0 + part * per; w < std::min(w1, w0 + (part + 1) * per); ++w) {
+                            uint64_t zero = ~bits[w].load(std::memory_order_relaxed);
+                            while (zero) {
+                                const uint64_t h = lo + ((uint64_t)w << 6) + (uint64_t)__builtin_ctzll(zero);
+                                zero &= zero - 1;
+                                if (h >= first && h < hi) found[part].push_back(h);
+                            }
+                        }
+                });
+                for (auto& f : found) holes.insert(holes.end(), f.begin(), f.end());
+            }
         } else {                                // scattered addresses: sort (the reference's own formulation)
             std::vector<uint64_t> sorted(addr);
             std::sort(sorted.begin(), sorted.end());
@@ -279,18 +314,19 @@ void plan_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& 
             }
         }
     }
+    uint64_t& hi_addr_ref = hi_addr_all;
     if (rc_seg) {  // add_rc_builtin_columns (execution_trace.rs:358-379, :604-624): the first rows carry the range-checked values
         P.rc_start = rc_seg->start;
         P.rc_count = std::min<uint64_t>(rc_seg->end > rc_seg->start ? rc_seg->end - rc_seg->start : 0, steps);
         for (uint64_t k = 0; k < P.rc_count; ++k) (void)mem_at(mem, P.rc_start + k);
-        if (P.rc_count) hi_addr = std::max(hi_addr, P.rc_start + P.rc_count - 1);
+        if (P.rc_count) hi_addr_ref = std::max(hi_addr_ref, P.rc_start + P.rc_count - 1);
     }
     P.r_rc = steps; P.r_holes = P.r_rc + missing.size() / 3; P.r_dummy = P.r_holes + (holes.size() + 3) / 4;
     const size_t r_pad = P.r_dummy + (pub.public_memory.size() >> 2) + 1;
     size_t n = 1;
     while (n < r_pad) n <<= 1;
     P.n = n;
-    P.mem_cells = hi_addr + 1;
+    P.mem_cells = hi_addr_all + 1;
     P.dense = mem.sparse.empty() && P.mem_cells <= mem.dense.size();   // every cell a row reads lives in the flat array
 }
 
