@@ -505,7 +505,7 @@ def compact_line(full):
     if isinstance(ap, dict) and "ms" in ap:
         summ["air_prove"] = {k: _r(ap.get(k)) for k in ("air", "rows", "blowup", "ms")}
     if isinstance(full.get("rccl"), dict):
-        summ["rccl"] = {k: full["rccl"].get(k) for k in ("world", "backend", "devices_shared")}
+        summ["rccl"] = dict({k: full["rccl"].get(k) for k in ("world", "backend", "devices_shared")}, selftest=full.get("transport_selftest"))
     line["summary"] = summ
     return line
 
@@ -669,6 +669,11 @@ def proof_child(args):
             ctx.init_rccl()                                   # the library's own RCCL communicator (xGMI)
         else:                                                 # development aid: ranks sharing one GPU, host-staged exchange
             ctx.set_collective(world, rank, api.StagedAllGather())
+        try:                                                  # rank-stamped blocks through every installed primitive, blocking and stream-ordered
+            ctx.comm_selftest(1 << 20)
+            result["transport_selftest"] = "ok"
+        except Exception as e:
+            result["transport_selftest"] = repr(e)
         for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
             try:
                 before = ctx.comm_stats()
@@ -927,7 +932,7 @@ def main():
             else:
                 res = proof_isolated(args, rank, local_rank, world, dist)
                 if rank == 0:
-                    for key in ("proof", "proof_cfg4", "rccl"):
+                    for key in ("proof", "proof_cfg4", "rccl", "transport_selftest"):
                         if isinstance(res, dict) and key in res:
                             out[key] = res[key]
                     if not isinstance(res, dict) or "proof" not in res:

@@ -290,6 +290,30 @@ int sp_comm_selftest(sp_ctx* c, uint64_t bytes_per_block) {
             for (uint64_t k = 0; k < words; ++k)
                 if (back[s2 * words + k] != stamp(s2, (uint64_t)c->rank, k)) { sp_set_error("sp_comm_selftest: all-to-all delivered a wrong block"); return SP_E_HIP; }
     }
+    // the stream-ordered forms, enqueued on the context stream between two copies like the prover enqueues them between kernels
+    if (c->allgather_async) {
+        for (uint64_t k = 0; k < words; ++k) h[k] = stamp((uint64_t)c->rank, 0xfffe, k);
+        SP_HIP_CHECK(hipMemcpyAsync(send.p, h.data(), bytes_per_block, hipMemcpyHostToDevice, c->stream));
+        SP_HIP_CHECK(hipMemsetAsync(recv.p, 0, W * bytes_per_block, c->stream));
+        if (c->allgather_async(c->allgather_user, send.p, recv.p, bytes_per_block, c->stream) != 0) { sp_set_error("sp_comm_selftest: stream-ordered all-gather failed"); return SP_E_HIP; }
+        SP_HIP_CHECK(hipMemcpyAsync(back.data(), recv.p, W * bytes_per_block, hipMemcpyDeviceToHost, c->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint64_t s2 = 0; s2 < W; ++s2)
+            for (uint64_t k = 0; k < words; ++k)
+                if (back[s2 * words + k] != stamp(s2, 0xfffe, k)) { sp_set_error("sp_comm_selftest: the stream-ordered all-gather delivered a wrong block"); return SP_E_HIP; }
+    }
+    if (c->alltoall_async) {
+        for (uint64_t d = 0; d < W; ++d)
+            for (uint64_t k = 0; k < words; ++k) h[d * words + k] = stamp((uint64_t)c->rank, d + 0x100, k);
+        SP_HIP_CHECK(hipMemcpyAsync(send.p, h.data(), W * bytes_per_block, hipMemcpyHostToDevice, c->stream));
+        SP_HIP_CHECK(hipMemsetAsync(recv.p, 0, W * bytes_per_block, c->stream));
+        if (c->alltoall_async(c->allgather_user, send.p, recv.p, bytes_per_block, c->stream) != 0) { sp_set_error("sp_comm_selftest: stream-ordered all-to-all failed"); return SP_E_HIP; }
+        SP_HIP_CHECK(hipMemcpyAsync(back.data(), recv.p, W * bytes_per_block, hipMemcpyDeviceToHost, c->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        for (uint64_t s2 = 0; s2 < W; ++s2)
+            for (uint64_t k = 0; k < words; ++k)
+                if (back[s2 * words + k] != stamp(s2, (uint64_t)c->rank + 0x100, k)) { sp_set_error("sp_comm_selftest: the stream-ordered all-to-all delivered a wrong block"); return SP_E_HIP; }
+    }
     return SP_OK;
 }
 

@@ -64,9 +64,9 @@ def _worker(rank, world, port, case, options, knobs, q):
         trace, pub, keep = _inputs(case)
         ctx = api.Context(device=0)
         ctx.set_collective(world, rank, api.StagedAllGather(), alltoall=knobs.get("alltoall", True))
-        ctx.comm_selftest(4096)
         if knobs.get("async"):   # stream-ordered all-gather: the coefficient exchange of a segment goes in column blocks beside the transforms
             ctx.set_collective_async(api.StagedAsyncAllGather(alltoall=knobs.get("async_a2a", True)))
+        ctx.comm_selftest(4096)  # rank-stamped blocks through every installed primitive (blocking and stream-ordered)
         if "fri_min_log" in knobs:
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
