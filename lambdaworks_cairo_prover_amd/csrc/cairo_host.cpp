@@ -429,7 +429,8 @@ void build_main_trace(const std::vector<RegisterState>& regs, const CairoMemory&
 // PCIe as one plain DMA): register states, the memory cells the rows read, the two hole lists.
 void TraceImage::release() {
     if (base) { if (pinned) (void)hipHostFree(base); else std::free(base); }
-    base = nullptr; bytes = 0; pinned = false;
+    if (retired) std::free(retired);
+    base = nullptr; retired = nullptr; bytes = 0; pinned = false;
 }
 void TraceImage::build(const std::vector<RegisterState>& regs, const CairoMemory& mem, const TracePlan& P) {
     release();
@@ -458,7 +459,7 @@ bool TraceImage::try_pin() {
     uint8_t* p = static_cast<uint8_t*>(alloc_pinned(bytes));
     if (!p) return false;
     host_parallel_for(bytes, 1 << 22, [&](size_t b, size_t e) { std::memcpy(p + b, base + b, e - b); });
-    std::free(base);          // (the image's address is never handed out)
+    retired = base;           // not freed before the run is: another prover of the process may be uploading from it right now
     base = p; pinned = true;
     return true;
 }

@@ -123,9 +123,15 @@ void fill_main_trace(const std::vector<RegisterState>& regs, const CairoMemory& 
 // offsets u16][memory holes u64], each part 256-byte aligned, in one host buffer.
 struct TraceImage {
     uint8_t* base = nullptr;
+    uint8_t* retired = nullptr;                // the pageable copy try_pin() replaced (kept until release(): it may be in use)
     uint64_t bytes = 0, off_regs = 0, off_mem = 0, off_missing = 0, off_holes = 0;
     bool pinned = false;
-    std::mutex pin_mutex;
+    mutable std::mutex pin_mutex;
+    const uint8_t* current(bool* pinned_out = nullptr) const {   // what to upload from (both copies hold the same bytes)
+        std::lock_guard<std::mutex> lk(pin_mutex);
+        if (pinned_out) *pinned_out = pinned;
+        return base;
+    }
     TraceImage() = default;
     TraceImage(const TraceImage&) = delete;
     TraceImage& operator=(const TraceImage&) = delete;

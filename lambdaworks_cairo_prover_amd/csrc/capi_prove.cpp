@@ -260,7 +260,7 @@ int sp_cairo_run_main_trace_dev(sp_ctx* c, const sp_cairo_run* run, int enc, uin
     if (hipMalloc(&img.p, image->bytes + main_trace_scratch_bytes(P.steps)) != hipSuccess || hipMalloc(&table.p, table_bytes) != hipSuccess ||
         hipMalloc(&enc_dev.p, table_bytes) != hipSuccess || hipMalloc(&flag.p, sizeof(int)) != hipSuccess) { (void)hipGetLastError(); return SP_E_ALLOC; }
     uint8_t* stage = static_cast<uint8_t*>(img.p);
-    SP_HIP_CHECK(hipMemcpyAsync(stage, image->base, image->bytes, hipMemcpyHostToDevice, c->stream));
+    SP_HIP_CHECK(hipMemcpyAsync(stage, image->current(), image->bytes, hipMemcpyHostToDevice, c->stream));
     SP_HIP_CHECK(hipMemsetAsync(flag.p, 0, sizeof(int), c->stream));
     MainTraceArgs a{};
     a.regs = reinterpret_cast<const uint64_t*>(stage + image->off_regs);
