@@ -29,9 +29,8 @@ StarkProver::~StarkProver() {
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     if (h_pin_) (void)hipHostFree(h_pin_);
     if (h_wide_) (void)hipHostFree(h_wide_);
-    for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_, ev_side2_aux_}) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
-    if (side2_stream_) (void)hipStreamDestroy(side2_stream_);
     if (ev_comm_fork_) (void)hipEventDestroy(ev_comm_fork_);
     for (auto& e : ev_comm_done_) if (e) (void)hipEventDestroy(e);
     if (comm_stream_) (void)hipStreamDestroy(comm_stream_);
@@ -39,8 +38,7 @@ StarkProver::~StarkProver() {
 
 int StarkProver::ensure_side() {
     if (!side_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&side_stream_, hipStreamNonBlocking));
-    if (!side2_stream_) SP_HIP_CHECK(hipStreamCreateWithFlags(&side2_stream_, hipStreamNonBlocking));
-    for (hipEvent_t* e : {&ev_side_fork_, &ev_side_deep_, &ev_side_bnd_, &ev_side_aux_, &ev_side_presort_, &ev_side2_aux_})
+    for (hipEvent_t* e : {&ev_side_fork_, &ev_side_deep_, &ev_side_bnd_, &ev_side_aux_, &ev_side_presort_})
         if (!*e) SP_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     return SP_OK;
 }
@@ -64,7 +62,6 @@ void StarkProver::free_all() {
     (void)hipStreamSynchronize(c_->stream);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
-    if (side2_stream_) (void)hipStreamSynchronize(side2_stream_);
     if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
     d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
@@ -307,7 +304,6 @@ void StarkProver::release(void* p, size_t bytes) {
     if (!p) return;
     (void)hipStreamSynchronize(c_->stream);
     if (side_stream_) (void)hipStreamSynchronize(side_stream_);
-    if (side2_stream_) (void)hipStreamSynchronize(side2_stream_);
     if (copy_stream_) (void)hipStreamSynchronize(copy_stream_);
     auto it = std::find(allocs_.begin(), allocs_.end(), p);
     if (it == allocs_.end()) return;     // carved out of the arena: the space comes back with the next setup()
@@ -619,15 +615,6 @@ int StarkProver::commit_trace_built(const TraceBuildInput& in, uint8_t root_out[
     return finish_upload_stats(1, I.bytes, 0.0, host_ms, image_pinned ? 4 : 5);
 }
 
-// interpolate_fft + evaluate_offset_fft (reference trace.rs:104-110, prover.rs:161-185) of the trace columns [col, col + count): natural
-// order in d_trace_ -> bit-reversed h-scaled coefficients -> this rank's cosets of the LDE
-int StarkProver::transform_columns(uint32_t col, uint32_t count) {
-    if (!count) return SP_OK;
-    fe* coeffs = d_coeffs_ + (uint64_t)col * n_;
-    SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs, (int)logn_, count, n_, d_t1_, d_trace_ + (uint64_t)col * n_));
-    return c_->ntt->lde_coset_major(coeffs, d_lde_ + (uint64_t)col * Nl_, (int)logn_, (int)logb_, count, n_, Nl_, (int)logG_, (int)rank_);
-}
-
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.
 int StarkProver::commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
@@ -770,37 +757,7 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     if (pre) SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_presort_, 0));
     SP_TRY(ensure_side());
     fe* aux_out = d_trace_ + (uint64_t)Cm_ * n_;
-    static const bool no_overlap = std::getenv("SP_AUX_NO_OVERLAP") != nullptr;      // (A/B switch)
-    const bool overlapped = pre && !no_overlap && !(G_ > 1 && shard_interp_);
     int flag = 0, flag_pre = 0;
-    if (overlapped) {
-        // The two permutation arguments are chains of dependent latencies (a batch inversion and a three-phase scan each: ~0.5 ms at
-        // 2^19 rows, ~1.1 ms at 2^20, with the chip nearly empty), and eleven of the eighteen auxiliary columns - the sorted offsets,
-        // addresses and values - need no challenge at all: their transforms (throughput work: 2 - 8 ms) go on the compute stream
-        // NOW, the chains beside them on the two side streams, and only the seven permutation columns wait for the chains.
-        constexpr uint32_t SORTED_COLS = 11;
-        SP_HIP_CHECK(hipEventRecord(ev_side_fork_, c_->stream));     // presort, cleared flag and the trace are behind this point
-        SP_HIP_CHECK(hipStreamWaitEvent(side_stream_, ev_side_fork_, 0));
-        SP_HIP_CHECK(hipStreamWaitEvent(side2_stream_, ev_side_fork_, 0));
-        SP_TRY(cairo_aux_memory_permutation(side2_stream_, auxws_, d_memcols_, n_, rap, c_->d_flag));
-        SP_TRY(cairo_aux_rc_permutation(side_stream_, auxws_, d_memcols_, n_, rap, c_->d_flag));
-        SP_HIP_CHECK(hipEventRecord(ev_side_aux_, side_stream_));
-        SP_HIP_CHECK(hipEventRecord(ev_side2_aux_, side2_stream_));
-        SP_TRY(cairo_aux_sorted_columns(c_->stream, auxws_, n_, aux_out));
-        SP_TRY(transform_columns(Cm_, SORTED_COLS));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_aux_, 0));
-        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side2_aux_, 0));
-        SP_TRY(cairo_aux_permutation_columns(c_->stream, auxws_, n_, aux_out));
-        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_HIP_CHECK(hipMemcpyAsync(&flag_pre, d_flag_side_ + 2, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-        SP_TRY(transform_columns(Cm_ + SORTED_COLS, Ca_ - SORTED_COLS));
-        // batch_commit straight from the column-major LDE; its read-back of the root waits for everything above (the flags too)
-        SP_TRY(commit_columns(d_lde_ + (uint64_t)Cm_ * Nl_, Nl_, Ca_, tree_aux_, root_out));
-        if (!flag) flag = flag_pre;
-        if (flag) { sp_set_error("commit_aux_cairo: malformed trace (address >= 2^64, offset >= 2^16 or zero permutation denominator)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
-        stage_ = 3;
-        return SP_OK;
-    }
     SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, rap, aux_out, c_->d_flag,
                                   side_stream_, ev_side_fork_, ev_side_aux_, pre));
     SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));

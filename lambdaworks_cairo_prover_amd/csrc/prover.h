@@ -249,9 +249,6 @@ class StarkProver : public sp_deletable {
     //   * DEEP denominators 1 / (x - z g^k), 1 / (x - z^2) of round 4 (known once z is sampled): during round 3;
     //   * the range-check half of the Cairo auxiliary trace beside its memory half.
     hipStream_t side_stream_ = nullptr;
-    hipStream_t side2_stream_ = nullptr;   // the memory-permutation chain of the auxiliary trace (the range-check chain is on side_stream_)
-    hipEvent_t ev_side2_aux_ = nullptr;
-    int transform_columns(uint32_t col, uint32_t count);
     hipEvent_t ev_side_fork_ = nullptr, ev_side_deep_ = nullptr, ev_side_bnd_ = nullptr, ev_side_aux_ = nullptr;
     int* d_flag_side_ = nullptr;            // [4] flags of the side-stream work: DEEP inverses, boundary inverses, presort
     int ensure_side();
