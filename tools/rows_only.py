@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The row-major host path alone (for a kernel trace of it).  usage: rows_only.py [fib=149000] [blowup=8] [iterations=5] [path=rows|dev]"""
+"""The row-major host path alone (for a kernel trace of it).  usage: rows_only.py [fib=149000] [blowup=8] [iterations=5] [path=rows|dev|run]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,6 +18,8 @@ for it in range(iters):
     t0 = time.perf_counter()
     if path == "rows":
         ctx.cairo_prove(tr, run.public_inputs_c, opt)
+    elif path == "run":
+        ctx.cairo_prove_run(run, opt)
     else:
         ctx.cairo_prove_dev(dev.data_ptr(), tr.shape[0], tr.shape[1], run.public_inputs_c, opt)
-    print(f"[{it}] {path} {1e3 * (time.perf_counter() - t0):.1f} ms rounds {['%.1f' % x for x in ctx.last_round_ms()[1:]]} {ctx.last_upload_stats() if path == 'rows' else ''}", flush=True)
+    print(f"[{it}] {path} {1e3 * (time.perf_counter() - t0):.1f} ms rounds {['%.1f' % x for x in ctx.last_round_ms()[1:]]} {ctx.last_upload_stats() if path != 'dev' else ''}", flush=True)
