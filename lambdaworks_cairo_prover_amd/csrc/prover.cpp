@@ -580,7 +580,8 @@ int StarkProver::commit_trace_built(const TraceBuildInput& in, uint8_t root_out[
     (void)I.try_pin();          // a run built before this process had a context: page-locked from here on
     bool image_pinned = false;
     const uint8_t* image = I.current(&image_pinned);
-    SP_TRY(ensure_upload(1));
+    constexpr uint32_t REG_CHUNKS = 4;
+    SP_TRY(ensure_upload(REG_CHUNKS));
     if (!h_wide_ && hipHostMalloc(reinterpret_cast<void**>(&h_wide_), 64, hipHostMallocDefault) != hipSuccess) { h_wide_ = nullptr; sp_set_error("pinned flag slot: allocation failed"); return SP_E_ALLOC; }
     // staging: the image and the builder's scratch sit in this segment's (not yet written) LDE area when they fit
     const size_t need = (size_t)I.bytes + main_trace_scratch_bytes(P.steps);
@@ -591,12 +592,12 @@ int StarkProver::commit_trace_built(const TraceBuildInput& in, uint8_t root_out[
         if (hipMalloc(&tmp.p, need) != hipSuccess) { (void)hipGetLastError(); sp_set_error("commit_trace: staging allocation failed"); return SP_E_ALLOC; }
         stage = static_cast<uint8_t*>(tmp.p);
     }
+    // The memory (and the two hole lists behind it) first, then the register states in four chunks on the copy stream: the rows of a
+    // chunk's steps are written while the next chunk crosses PCIe - what stays exposed is the memory (29 MB: 0.5 ms at 2^20 rows) and
+    // one chunk of registers (6 MB) instead of the whole image (54 MB: 0.96 ms).
     const double t0 = wall_ms();
-    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));
-    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma0, c_->stream));
-    SP_HIP_CHECK(hipMemcpyAsync(stage, image, I.bytes, hipMemcpyHostToDevice, c_->stream));
-    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma1, c_->stream));
-    SP_HIP_CHECK(hipEventRecord(up_ev_[0].ready, c_->stream));
+    SP_HIP_CHECK(hipEventRecord(up_start_, c_->stream));             // the staging area's previous users are behind this point
+    SP_HIP_CHECK(hipStreamWaitEvent(copy_stream_, up_start_, 0));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     MainTraceArgs a{};
     a.regs = reinterpret_cast<const uint64_t*>(stage + I.off_regs);
@@ -605,14 +606,32 @@ int StarkProver::commit_trace_built(const TraceBuildInput& in, uint8_t root_out[
     a.holes = reinterpret_cast<const uint64_t*>(stage + I.off_holes);
     a.steps = P.steps; a.cells = P.mem_cells; a.n = n_; a.r_rc = P.r_rc; a.r_holes = P.r_holes; a.r_dummy = P.r_dummy; a.n_holes = P.holes.size();
     a.rc_start = P.rc_start; a.rc_count = P.rc_count; a.cols = Cm_; a.trace = d_trace_;
-    SP_TRY(cairo_main_trace_device(c_->stream, a, stage + I.bytes, c_->d_flag));
+    SP_HIP_CHECK(hipEventRecord(up_ev_[0].dma0, copy_stream_));
+    SP_HIP_CHECK(hipMemcpyAsync(stage + I.off_mem, image + I.off_mem, I.bytes - I.off_mem, hipMemcpyHostToDevice, copy_stream_));
+    const uint64_t per = ((P.steps + REG_CHUNKS - 1) / REG_CHUNKS + 255) & ~(uint64_t)255;
+    uint32_t chunks_used = 0;
+    for (uint32_t k = 0; k < REG_CHUNKS; ++k) {
+        const uint64_t s0 = std::min<uint64_t>(P.steps, k * per), s1 = std::min<uint64_t>(P.steps, (k + 1) * per);
+        if (s0 == s1) break;
+        // (one copy in flight at a time: a copy enqueued while the engine is busy may be given a second SDMA engine, and a stream
+        // hopping between two ran at 27 - 37 GB/s instead of 56 - see commit_trace_columns)
+        SP_HIP_CHECK(hipStreamSynchronize(copy_stream_));
+        if (k) SP_HIP_CHECK(hipEventRecord(up_ev_[k].dma0, copy_stream_));
+        SP_HIP_CHECK(hipMemcpyAsync(stage + I.off_regs + 24 * s0, image + I.off_regs + 24 * s0, 24 * (s1 - s0), hipMemcpyHostToDevice, copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[k].dma1, copy_stream_));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[k].ready, copy_stream_));
+        SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, up_ev_[k].ready, 0));
+        SP_TRY(cairo_main_trace_steps(c_->stream, a, stage + I.bytes, c_->d_flag, s0, s1));
+        SP_HIP_CHECK(hipEventRecord(up_ev_[k].done, c_->stream));
+        chunks_used = k + 1;
+    }
+    SP_TRY(cairo_main_trace_finish(c_->stream, a, stage + I.bytes, c_->d_flag));
     SP_HIP_CHECK(hipMemcpyAsync(h_wide_ + 4, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(hipEventRecord(up_ev_[0].done, c_->stream));
     const double host_ms = wall_ms() - t0;
     SP_TRY(launch_aux_presort());
     SP_TRY(commit_segment_resident(0, Cm_, root_out));        // (its read-back of the root waits for everything above)
     if (h_wide_[4]) { sp_set_error("commit_trace: a trace row reads beyond the run's memory image"); return SP_E_INVALID_ARG; }
-    return finish_upload_stats(1, I.bytes, 0.0, host_ms, image_pinned ? 4 : 5);
+    return finish_upload_stats(chunks_used, I.bytes, 0.0, host_ms, image_pinned ? 4 : 5);
 }
 
 // Second half of interpolate_and_commit: the segment's columns sit in natural order in d_trace_.

@@ -24,5 +24,10 @@ struct MainTraceArgs {
 // *flag_dev is set when a row reads beyond `cells` (cannot happen for a plan the host validated).
 static inline size_t main_trace_scratch_bytes(uint64_t steps) { return (size_t)steps * (2 * sizeof(fe) + 1) + 256; }
 int cairo_main_trace_device(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev);
+// The same in pieces, for a caller that uploads the register states in chunks behind the memory: the rows of the steps [s0, s1) (needs
+// the whole memory and regs[s0 .. s1)), then - once every step has its row - the jnz inverses, the builtin columns and the rows
+// behind the steps.
+int cairo_main_trace_steps(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev, uint64_t s0, uint64_t s1);
+int cairo_main_trace_finish(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev);
 
 }  // namespace sp

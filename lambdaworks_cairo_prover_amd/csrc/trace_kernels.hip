@@ -33,9 +33,9 @@ constexpr int TK_THREADS = 256;
 // build_cairo_execution_trace (execution_trace.rs:261-356): decode (instruction_flags.rs:1-77, instruction_offsets.rs:18-56), the
 // three operand addresses, res (compute_res, :382-440), update_values (:572-592), t0 / t1 / mul, the selector column.
 // jnz rows with dst != 0 need dst^-1: the denominator goes to inv[i] (1 elsewhere), the row is marked, jnz_fix_kernel finishes it.
-__global__ void __launch_bounds__(TK_THREADS) step_rows_kernel(MainTraceArgs a, fe* inv, uint8_t* deferred_mask, int* flag) {
-    const uint64_t i = (uint64_t)blockIdx.x * TK_THREADS + threadIdx.x;
-    if (i >= a.steps) return;
+__global__ void __launch_bounds__(TK_THREADS) step_rows_kernel(MainTraceArgs a, fe* inv, uint8_t* deferred_mask, int* flag, uint64_t s0, uint64_t s1) {
+    const uint64_t i = s0 + (uint64_t)blockIdx.x * TK_THREADS + threadIdx.x;
+    if (i >= s1) return;
     const uint64_t ap = a.regs[3 * i], fp = a.regs[3 * i + 1], pc = a.regs[3 * i + 2];
     const fe inst = tk_cell(a, pc, flag);
     const uint64_t w = tk_low64(inst);
@@ -129,19 +129,34 @@ __global__ void __launch_bounds__(TK_THREADS) tail_rows_kernel(MainTraceArgs a) 
 
 }  // namespace
 
-int cairo_main_trace_device(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev) {
-    if (!a.regs || !a.mem || !a.trace || !scratch || !flag_dev || a.steps == 0 || a.steps > a.n || (a.cols != 34 && a.cols != 43)) return SP_E_INVALID_ARG;
+static bool tk_args_ok(const MainTraceArgs& a, const void* scratch, const int* flag_dev) {
+    return a.regs && a.mem && a.trace && scratch && flag_dev && a.steps != 0 && a.steps <= a.n && (a.cols == 34 || a.cols == 43);
+}
+int cairo_main_trace_steps(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev, uint64_t s0, uint64_t s1) {
+    if (!tk_args_ok(a, scratch, flag_dev) || s0 > s1 || s1 > a.steps) return SP_E_INVALID_ARG;
+    if (s0 == s1) return SP_OK;
+    fe* inv = static_cast<fe*>(scratch);
+    uint8_t* mask = reinterpret_cast<uint8_t*>(inv + 2 * a.steps);
+    hipLaunchKernelGGL(step_rows_kernel, dim3((uint32_t)((s1 - s0 + TK_THREADS - 1) / TK_THREADS)), dim3(TK_THREADS), 0, st, a, inv, mask, flag_dev, s0, s1);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+int cairo_main_trace_finish(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev) {
+    if (!tk_args_ok(a, scratch, flag_dev)) return SP_E_INVALID_ARG;
     fe* inv = static_cast<fe*>(scratch);
     fe* inv_scratch = inv + a.steps;
     uint8_t* mask = reinterpret_cast<uint8_t*>(inv_scratch + a.steps);
     const uint32_t blocks = (uint32_t)((a.steps + TK_THREADS - 1) / TK_THREADS);
-    hipLaunchKernelGGL(step_rows_kernel, dim3(blocks), dim3(TK_THREADS), 0, st, a, inv, mask, flag_dev);
     SP_TRY(batch_inverse(st, inv, inv_scratch, a.steps, flag_dev));        // (no element is zero: rows without a jnz carry a one)
     hipLaunchKernelGGL(jnz_fix_kernel, dim3(blocks), dim3(TK_THREADS), 0, st, a, inv, mask);
     if (a.rc_count) hipLaunchKernelGGL(rc_builtin_kernel, dim3((uint32_t)((a.rc_count + TK_THREADS - 1) / TK_THREADS)), dim3(TK_THREADS), 0, st, a, flag_dev);
     if (a.n > a.steps) hipLaunchKernelGGL(tail_rows_kernel, dim3((uint32_t)((a.n - a.steps + TK_THREADS - 1) / TK_THREADS)), dim3(TK_THREADS), 0, st, a);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
+}
+int cairo_main_trace_device(hipStream_t st, const MainTraceArgs& a, void* scratch, int* flag_dev) {
+    SP_TRY(cairo_main_trace_steps(st, a, scratch, flag_dev, 0, a.steps));
+    return cairo_main_trace_finish(st, a, scratch, flag_dev);
 }
 
 }  // namespace sp
