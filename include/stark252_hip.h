@@ -393,6 +393,16 @@ int sp_cairo_run_fibonacci(uint64_t fib_index, sp_cairo_run** out);
  * cairo_mem.rs:35-61), program occupying addresses 1..program_size. */
 int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint8_t* memory, uint64_t memory_len,
                             uint64_t program_size, sp_cairo_run** out);
+/* The same from what cairo-vm hands the reference IN MEMORY (run_program, reference src/cairo/runner/run.rs:64-240): regs = steps x
+ * (ap, fp, pc) relocated register states, (addrs[k], values[k]) = the n_cells relocated memory cells (values 32 bytes each in
+ * `fe_encoding`), and the builtin segments run.rs:211-222 reads back (seg_types: 0 = RangeCheck, 1 = Output; seg_ranges: (start, end)
+ * pairs) - generate_prover_args (run.rs:242-263) without the binary dump files.  For a shim that keeps cairo-vm (hints, Cairo 1). */
+int sp_cairo_run_from_arrays(const uint64_t* regs, uint64_t steps, const uint64_t* addrs, const uint8_t* values, int fe_encoding, uint64_t n_cells,
+                             uint64_t program_size, const uint8_t* seg_types, const uint64_t* seg_ranges, uint32_t n_segments, sp_cairo_run** out);
+/* The register states and the memory of a run in that form (cells in increasing address order): call with null buffers for the
+ * two counts, then with buffers of steps x 3 words, n_cells words and n_cells x 32 bytes. */
+int sp_cairo_run_export(const sp_cairo_run* run, int fe_encoding, uint64_t* steps_out, uint64_t* n_cells_out, uint64_t* regs_out, uint64_t* addrs_out,
+                        uint8_t* values_out);
 void sp_cairo_run_free(sp_cairo_run* run);
 /* Where the front-end's time went, in ms: out = {the VM (0 for runs read from dumps), the shape pass of build_main_trace (addresses,
  * offsets, range-check and memory holes, every validity check), the upload image for the device-side trace builder, the n x cols

@@ -315,6 +315,34 @@ class CairoRun:
                                           ctypes.c_uint64(len(memory_bytes)), ctypes.c_uint64(program_size), ctypes.byref(h)))
         return CairoRun(h)
 
+    @staticmethod
+    def from_arrays(regs, addrs, values, program_size, segments=(), fe_encoding=SP_FE_CANON_BE):
+        """sp_cairo_run_from_arrays: regs (steps, 3) uint64 rows (ap, fp, pc); addrs (n,) uint64; values (n, 32) uint8 in `fe_encoding`;
+        segments: (type, start, end) triples (0 RangeCheck, 1 Output) - cairo-vm's relocated outputs as the reference receives them."""
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        r = np.ascontiguousarray(regs, dtype=np.uint64).reshape(-1, 3)
+        a = np.ascontiguousarray(addrs, dtype=np.uint64)
+        v = np.ascontiguousarray(values, dtype=np.uint8).reshape(-1, 32)
+        st = np.array([s[0] for s in segments], dtype=np.uint8)
+        sr = np.array([x for s in segments for x in s[1:]], dtype=np.uint64)
+        check(lib.sp_cairo_run_from_arrays(r.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), ctypes.c_uint64(r.shape[0]),
+                                           a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _u8p(v), int(fe_encoding), ctypes.c_uint64(a.shape[0]),
+                                           ctypes.c_uint64(program_size), _u8p(st) if len(segments) else None,
+                                           sr.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)) if len(segments) else None, ctypes.c_uint32(len(segments)), ctypes.byref(h)))
+        return CairoRun(h)
+
+    def export(self, fe_encoding=SP_FE_CANON_BE):
+        """sp_cairo_run_export: (regs (steps, 3) uint64, addrs (n,) uint64, values (n, 32) uint8) of this run."""
+        steps, cells = ctypes.c_uint64(), ctypes.c_uint64()
+        check(self._lib.sp_cairo_run_export(self._h, int(fe_encoding), ctypes.byref(steps), ctypes.byref(cells), None, None, None))
+        regs = np.empty((steps.value, 3), dtype=np.uint64)
+        addrs = np.empty(cells.value, dtype=np.uint64)
+        values = np.empty((cells.value, 32), dtype=np.uint8)
+        check(self._lib.sp_cairo_run_export(self._h, int(fe_encoding), None, None, regs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                            addrs.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), _u8p(values)))
+        return regs, addrs, values
+
     def main_trace(self, fe_encoding=SP_FE_CANON_BE):
         out = np.empty((self.n_rows, self.n_cols, 32), dtype=np.uint8)
         check(self._lib.sp_cairo_run_main_trace(self._h, fe_encoding, _u8p(out)))

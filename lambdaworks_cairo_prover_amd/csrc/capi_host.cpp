@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <stdexcept>
 #include <string>
+#include <algorithm>
 #include <chrono>
 #include <mutex>
 #include <exception>
@@ -182,6 +183,56 @@ int sp_cairo_run_from_dumps(const uint8_t* trace, uint64_t trace_len, const uint
         if (!sp::parse_memory_le(memory, memory_len, r->mem)) throw std::runtime_error("IncorrectNumberOfBytes (memory)");
         return finish_run(r, program_size, out);
     } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+// generate_prover_args (reference src/cairo/runner/run.rs:242-263) from what cairo-vm hands the reference in memory - the relocated
+// register states and memory of `run_program` (run.rs:64-240) and the builtin segments it reads back (run.rs:211-222) - without the
+// detour through the binary dump files: what a Rust shim that keeps cairo-vm (hints, Cairo 1) calls.
+int sp_cairo_run_from_arrays(const uint64_t* regs, uint64_t steps, const uint64_t* addrs, const uint8_t* values, int enc, uint64_t n_cells,
+                             uint64_t program_size, const uint8_t* seg_types, const uint64_t* seg_ranges, uint32_t n_segments, sp_cairo_run** out) {
+    if (!regs || !addrs || !values || !out || steps == 0 || n_cells == 0 || (n_segments && (!seg_types || !seg_ranges)) ||
+        (enc != SP_FE_CANON_BE && enc != SP_FE_MONT_LIMBS)) return SP_E_INVALID_ARG;
+    sp_cairo_run* r = new sp_cairo_run();
+    try {
+        r->regs.resize(steps);
+        for (uint64_t i = 0; i < steps; ++i) r->regs[i] = sp::RegisterState{regs[3 * i], regs[3 * i + 1], regs[3 * i + 2]};
+        for (uint64_t k = 0; k < n_cells; ++k) {
+            fe v;
+            if (enc == SP_FE_CANON_BE) v = fe_from_bytes_be(values + 32 * k);
+            else { uint64_t l[4]; std::memcpy(l, values + 32 * k, 32); v = fe_from_lw_limbs(l); }
+            r->mem.set(addrs[k], v);
+        }
+        std::vector<sp::MemorySegment> segs;
+        for (uint32_t i = 0; i < n_segments; ++i) {
+            if (seg_types[i] > 1 || seg_ranges[2 * i + 1] < seg_ranges[2 * i]) throw std::runtime_error("malformed memory segment");
+            segs.push_back(sp::MemorySegment{seg_types[i], seg_ranges[2 * i], seg_ranges[2 * i + 1]});
+        }
+        return finish_run(r, program_size, out, segs);
+    } catch (const std::exception& e) { sp_set_error(e.what()); delete r; return SP_E_PROGRAM; }
+}
+
+// The register states and the memory of a run as arrays (the inverse of sp_cairo_run_from_arrays; cells in increasing address order).
+// Call with null pointers for the counts, then with buffers of steps x 3 and n_cells (x 32 bytes) entries.
+int sp_cairo_run_export(const sp_cairo_run* run, int enc, uint64_t* steps_out, uint64_t* n_cells_out, uint64_t* regs_out, uint64_t* addrs_out, uint8_t* values_out) {
+    if (!run || (enc != SP_FE_CANON_BE && enc != SP_FE_MONT_LIMBS)) return SP_E_INVALID_ARG;
+    std::vector<uint64_t> addrs;
+    for (uint64_t a = 0; a < run->mem.dense.size(); ++a) if (run->mem.present[a]) addrs.push_back(a);
+    std::vector<uint64_t> far;
+    for (auto& kv : run->mem.sparse) far.push_back(kv.first);
+    std::sort(far.begin(), far.end());
+    addrs.insert(addrs.end(), far.begin(), far.end());
+    if (steps_out) *steps_out = run->regs.size();
+    if (n_cells_out) *n_cells_out = addrs.size();
+    if (regs_out)
+        for (size_t i = 0; i < run->regs.size(); ++i) { regs_out[3 * i] = run->regs[i].ap; regs_out[3 * i + 1] = run->regs[i].fp; regs_out[3 * i + 2] = run->regs[i].pc; }
+    if (addrs_out && values_out)
+        for (size_t k = 0; k < addrs.size(); ++k) {
+            addrs_out[k] = addrs[k];
+            const fe& v = *run->mem.get(addrs[k]);
+            if (enc == SP_FE_CANON_BE) fe_to_bytes_be(v, values_out + 32 * k);
+            else { uint64_t l[4]; fe_to_lw_limbs(v, l); std::memcpy(values_out + 32 * k, l, 32); }
+        }
+    return SP_OK;
 }
 
 void sp_cairo_run_free(sp_cairo_run* run) { delete run; }

@@ -105,3 +105,16 @@ def test_rc_builtin_proofs_through_the_device_built_trace(hip_ctx, oracle):
         want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
         assert hip_ctx.cairo_prove_run(run, api.ProofOptions(*options)) == want, name
         assert hip_ctx.last_upload_stats()["kind"].startswith("run image")
+
+
+def test_a_run_rebuilt_from_in_memory_arrays_proves_the_same_bytes(hip_ctx, oracle):
+    """sp_cairo_run_from_arrays (cairo-vm's relocated outputs as the reference receives them, lambdaworks limbs) -> sp_cairo_prove_run."""
+    from test_rc_builtin import run_of, segments_of
+    run = run_of("output_and_rc")
+    regs, addrs, values = run.export(api.SP_FE_MONT_LIMBS)
+    program_size = run.public_inputs_c.n_public_memory - sum(e - s for t, s, e in segments_of(run) if t == 1)
+    again = api.CairoRun.from_arrays(regs, addrs, values, program_size, segments_of(run), api.SP_FE_MONT_LIMBS)
+    options = (4, 3, 3, 1)
+    want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+    assert hip_ctx.cairo_prove_run(again, api.ProofOptions(*options)) == want
+    _same(again, hip_ctx)

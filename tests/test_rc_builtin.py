@@ -91,3 +91,28 @@ def test_oracle_proves_and_both_verifiers_accept(oracle, hip_lib, name, options)
     bad = bytearray(proof)
     bad[len(bad) // 2] ^= 1
     assert not api.cairo_verify(bytes(bad), run.public_inputs_c, api.ProofOptions(*options))
+
+
+def test_runs_round_trip_through_the_in_memory_arrays(hip_lib):
+    """sp_cairo_run_export / sp_cairo_run_from_arrays - the form in which cairo-vm hands its relocated register states, memory and
+    builtin segments to the reference (run.rs:64-263): a run rebuilt from its own arrays has the same shape, public inputs and main
+    trace, in both encodings, with and without builtin segments; malformed inputs are rejected."""
+    import numpy as np
+    for name in ("rc_program", "output_and_rc", "rc_loop_20"):
+        run = run_of(name)
+        for enc in (api.SP_FE_CANON_BE, api.SP_FE_MONT_LIMBS):
+            regs, addrs, values = run.export(enc)
+            assert regs.shape == (run.num_steps, 3) and len(addrs) == len(values) and (np.diff(addrs.astype(np.int64)) > 0).all()
+            program_size = run.public_inputs_c.n_public_memory - sum(e - s for t, s, e in segments_of(run) if t == 1)
+            again = api.CairoRun.from_arrays(regs, addrs, values, program_size, segments_of(run), enc)
+            assert (again.n_rows, again.n_cols, again.num_steps) == (run.n_rows, run.n_cols, run.num_steps)
+            assert again.public_memory() == run.public_memory() and segments_of(again) == segments_of(run)
+            assert np.array_equal(again.main_trace(), run.main_trace())
+    plain = api.CairoRun.fibonacci(50)
+    regs, addrs, values = plain.export()
+    again = api.CairoRun.from_arrays(regs, addrs, values, 22)
+    assert np.array_equal(again.main_trace(), plain.main_trace())
+    with pytest.raises(api.SpError):        # a cell the trace reads is missing
+        api.CairoRun.from_arrays(regs, addrs[:-30], values[:-30], 22)
+    with pytest.raises(api.SpError):        # a segment that ends before it starts
+        api.CairoRun.from_arrays(regs, addrs, values, 22, [(0, 100, 90)])
