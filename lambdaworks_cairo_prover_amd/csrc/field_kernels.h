@@ -12,5 +12,7 @@ int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n
 int pull_copy(hipStream_t st, const void* src_pinned_host, void* dst_dev, size_t bytes);
 int encode_elements(hipStream_t st, int enc, const fe* in, uint64_t n, uint8_t* out_dev);
 int decode_elements(hipStream_t st, int enc, const uint8_t* in_dev, uint64_t n, fe* out);
+// `cols` columns of n cells each (n a multiple of 64) given as bitmaps of n / 64 words per column -> field elements 0 / 1, column-major
+int expand_bit_columns(hipStream_t st, const uint64_t* bits_dev, uint64_t n, uint32_t cols, fe* out);
 
 }  // namespace sp

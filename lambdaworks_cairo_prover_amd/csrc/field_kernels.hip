@@ -226,4 +226,22 @@ int decode_elements(hipStream_t st, int enc, const uint8_t* in_dev, uint64_t n, 
     return SP_OK;
 }
 
+// out[c][i] = bit i of column c's bitmap ? 1 : 0 (Montgomery form): the sixteen flag columns of a Cairo main trace cross PCIe as
+// one bit per cell (prover_upload.cpp) and become field elements here
+__global__ void __launch_bounds__(256) expand_bit_columns_kernel(const uint64_t* __restrict__ bits, uint64_t n, uint64_t total, fe* out) {
+    const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const uint64_t c = e / n, i = e - c * n;
+    const uint64_t w = bits[c * (n >> 6) + (i >> 6)];
+    fk_st(out + e, ((w >> (i & 63)) & 1ULL) ? fe_one() : fe_zero());
+}
+int expand_bit_columns(hipStream_t st, const uint64_t* bits_dev, uint64_t n, uint32_t cols, fe* out) {
+    if (!bits_dev || !out || n < 64 || (n & 63)) return SP_E_INVALID_ARG;
+    const uint64_t total = n * cols;
+    if (!total) return SP_OK;
+    hipLaunchKernelGGL(expand_bit_columns_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, bits_dev, n, total, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 }  // namespace sp

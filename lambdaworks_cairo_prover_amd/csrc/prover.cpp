@@ -521,10 +521,19 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     }
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
     static const uint64_t pipeline_min_bytes = [] { const char* e = std::getenv("SP_UPLOAD_MIN_MB"); return (uint64_t)(e ? std::max(0, std::atoi(e)) : 64) << 20; }();
-    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes)
-        return drained(commit_trace_pipelined(segment, rows_host, cols, root_out));
-    if (!rows_on_device && G_ > 1 && cols >= 2 * G_ && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes)
-        return drained(commit_trace_rows_sharded(segment, rows_host, cols, root_out));
+    static const bool no_pack = std::getenv("SP_UPLOAD_NO_FLAG_PACK") != nullptr;      // (A/B switch)
+    const uint32_t binary_cols = (segment == 0 && !no_pack && (n_ & 63) == 0) ? std::min(binary_cols_hint_, cols) : 0u;
+    binary_cols_hint_ = 0;
+    if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes) {
+        int rc = drained(commit_trace_pipelined(segment, rows_host, cols, root_out, 0, 0, false, binary_cols));
+        if (rc == SP_RETRY_RAW_UPLOAD) rc = drained(commit_trace_pipelined(segment, rows_host, cols, root_out));   // (not a trace with 0 / 1 flags)
+        return rc;
+    }
+    if (!rows_on_device && G_ > 1 && cols >= 2 * G_ && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes) {
+        int rc = drained(commit_trace_rows_sharded(segment, rows_host, cols, root_out, binary_cols));
+        if (rc == SP_RETRY_RAW_UPLOAD) rc = drained(commit_trace_rows_sharded(segment, rows_host, cols, root_out, 0));
+        return rc;
+    }
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     // staging: the raw rows sit in this segment's (not yet written) LDE area: cols*N*32 >= cols*n*32 bytes
     uint8_t* raw = reinterpret_cast<uint8_t*>(d_lde_ + (uint64_t)col0 * std::max<uint64_t>(Nl_, n_));
@@ -547,12 +556,26 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
 // model) instead of G times that through the host (20 ms of PCIe per rank, and the host's memory bandwidth shared by all).
 // Every rank needs the whole trace anyway - the auxiliary trace and the exact constraint check read it - so the all-gather carries
 // trace VALUES and the interpolation follows as configured (SP_OPT_SHARD_INTERPOLATION).
-int StarkProver::commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]) {
+int StarkProver::commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], uint32_t binary_cols) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     const uint32_t cpr = (cols + G_ - 1) / G_;
     auto first_col = [&](uint32_t role) { return std::min(role * cpr, cols - cpr); };
     fe* trace = d_trace_ + (uint64_t)col0 * n_;
-    SP_TRY(commit_trace_pipelined(segment, rows_host, cols, root_out, first_col(rank_), cpr, true));
+    {
+        // (a rank whose window holds a cell that breaks the 0 / 1 hint must not leave the others waiting in the all-gather: the verdict
+        // of the window upload is agreed on first - one flag per rank through the same all-gather)
+        int rc = commit_trace_pipelined(segment, rows_host, cols, root_out, first_col(rank_), cpr, true, binary_cols);
+        if (rc != SP_OK && rc != SP_RETRY_RAW_UPLOAD) return rc;
+        if (binary_cols) {
+            if (!d_flags_all_) SP_TRY(alloc((void**)&d_flags_all_, sizeof(int) * world_));
+            const int mine = rc == SP_RETRY_RAW_UPLOAD ? 1 : 0;
+            SP_HIP_CHECK(hipMemcpyAsync(c_->d_flag, &mine, sizeof(int), hipMemcpyHostToDevice, c_->stream));
+            SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int)));
+            std::vector<int> flags(world_, 0);
+            SP_HIP_CHECK(hipMemcpy(flags.data(), d_flags_all_, sizeof(int) * world_, hipMemcpyDeviceToHost));
+            for (int f : flags) if (f) return SP_RETRY_RAW_UPLOAD;
+        }
+    }
     // (the LDE area of this segment is free until the transforms below: landing zone of the all-gather)
     const uint64_t block = (uint64_t)cpr * n_;
     fe* stage = nullptr;

@@ -134,9 +134,15 @@ class StarkProver : public sp_deletable {
     }
     int commit_segment_resident(int segment, uint32_t cols, uint8_t root_out[32]);
     int commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t table_cols, uint8_t root_out[32], uint32_t c_begin = 0, uint32_t c_count = 0,
-                               bool window_only = false);
+                               bool window_only = false, uint32_t binary_cols = 0);
+    // The first `binary_cols` columns of the main segment hold only 0 and 1 (the sixteen instruction flags of a Cairo trace, reference
+    // src/cairo/air.rs:29-46: 47 % of the table): the row-major upload sends them as one bit per cell.  A hint, checked cell by cell by
+    // the gather threads - a table that breaks it (an invalid trace) is uploaded again in full, so the bytes never depend on it.
+    uint32_t binary_cols_hint_ = 0;
+    uint64_t* d_flagbits_ = nullptr; uint64_t flagbits_words_ = 0;
+    static constexpr int SP_RETRY_RAW_UPLOAD = 1000;   // internal: the packed upload met a cell that is neither 0 nor 1
     // several ranks, row-major host table: every rank uploads the columns of its role only, the trace columns are all-gathered
-    int commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32]);
+    int commit_trace_rows_sharded(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], uint32_t binary_cols = 0);
     uint32_t pending_up_groups_ = 0; uint64_t pending_up_bytes_ = 0; double pending_up_gather_ms_ = 0, pending_up_host_ms_ = 0;
     int shard_mode_ = 2;
     bool shard_interp_ = false;    // this shape interpolates by column and all-gathers coefficients (SP_OPT_SHARD_INTERPOLATION, setup())
@@ -268,6 +274,8 @@ class StarkProver : public sp_deletable {
     int prefetch_boundary_inverses(const std::vector<uint64_t>& steps);
     // optional, before commit_trace(0, ..) of a Cairo proof: sort the memory accesses and the offsets while round 1 runs
     void request_aux_presort(const PublicInputs& pub) { presort_pub_ = &pub; }
+    // optional, before commit_trace(0, ..) from a row-major host table: columns [0, count) are 0 / 1 in a valid trace
+    void hint_binary_columns(uint32_t count) { binary_cols_hint_ = count; }
   private:
     fe* d_memcols_ = nullptr;               // natural-order main-trace columns 19..29 kept for the auxiliary trace
     void* d_auxws_ = nullptr; size_t auxws_bytes_ = 0; uint64_t auxws_pm_cap_ = 0;

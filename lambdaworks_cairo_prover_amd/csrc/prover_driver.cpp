@@ -148,6 +148,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         P->request_aux_presort(pub);                    // the sorts of the auxiliary trace: beside round 1 too
         if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
             SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
+        P->hint_binary_columns(16);                     // the instruction flags (air.rs:29-46): one bit per cell over PCIe from a row-major host table
         SP_TRY(P->commit_trace(0, main_trace, cols, root, src, col_enc, col_stride));
         uint8_t main_root[32]; std::memcpy(main_root, root, 32);
         SP_TIMEPOINT("r1 commit main (H2D+iNTT+LDE+Merkle)");

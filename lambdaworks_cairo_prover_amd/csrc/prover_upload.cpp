@@ -323,6 +323,33 @@ static void host_gather_block(const uint8_t* src, uint64_t n, size_t row_bytes, 
         for (uint32_t u = 0; u < cw; ++u) __builtin_memcpy(dst + ((size_t)u * n + i) * 32, s + 32 * (size_t)u, 32);
 }
 
+// The same block for columns that hold only 0 and 1 (the instruction flags of a Cairo trace): one BIT per cell instead of 32 bytes -
+// column u's bitmap at dst + u * (n / 8), row i of the chunk at bit i (little-endian 64-bit words; r0 and r1 are multiples of 64).
+// A cell that is neither `zero` nor `one` (32-byte images in the table's encoding) sets *dirty: the caller uploads the table again in full.
+static void host_pack_bits_block(const uint8_t* src, uint64_t n, size_t row_bytes, size_t off, uint32_t cw, uint8_t* dst, uint64_t r0, uint64_t r1,
+                                 const uint64_t zero[4], const uint64_t one[4], std::atomic<bool>& dirty) {
+    constexpr size_t PF_ROWS = 24;
+    bool bad = false;
+    for (uint64_t i = r0; i < r1; i += 64) {
+        uint64_t words[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const uint64_t lim = std::min<uint64_t>(64, r1 - i);
+        const uint8_t* s = src + i * row_bytes + off;
+        for (uint64_t k = 0; k < lim; ++k, s += row_bytes) {
+            __builtin_prefetch(s + PF_ROWS * row_bytes, 0, 0);
+            for (uint32_t u = 0; u < cw; ++u) {
+                uint64_t v[4];
+                __builtin_memcpy(v, s + 32 * (size_t)u, 32);
+                const bool is_one = ((v[0] ^ one[0]) | (v[1] ^ one[1]) | (v[2] ^ one[2]) | (v[3] ^ one[3])) == 0;
+                const bool is_zero = ((v[0] ^ zero[0]) | (v[1] ^ zero[1]) | (v[2] ^ zero[2]) | (v[3] ^ zero[3])) == 0;
+                bad |= !(is_one | is_zero);
+                words[u] |= (uint64_t)is_one << k;
+            }
+        }
+        for (uint32_t u = 0; u < cw; ++u) __builtin_memcpy(dst + (size_t)u * (n / 8) + (i / 64) * 8, &words[u], 8);
+    }
+    if (bad) dirty.store(true, std::memory_order_relaxed);
+}
+
 static size_t upload_chunk_bytes() {
     static const size_t chunk_mb = [] { const char* e = std::getenv("SP_UPLOAD_CHUNK_MB"); return e ? (size_t)std::min(64, std::max(1, std::atoi(e))) : (size_t)32; }();
     return chunk_mb << 20;
@@ -353,8 +380,10 @@ int StarkProver::ensure_ring_and_pool() {
 // did (56 ms of a first proof at 2^20 rows).
 // window_only: several ranks - only the columns [c_begin, c_begin + c_count) of the table (the block this rank's role contributes to
 // the all-gather of the trace, commit_trace_rows_sharded) are gathered, uploaded and decoded; no transforms, no commitment.
+// binary_cols: columns [0, binary_cols) of the table hold only 0 and 1 in a valid trace (StarkProver::hint_binary_columns): groups
+// that lie inside them cross PCIe as bitmaps and are expanded on the device; returns SP_RETRY_RAW_UPLOAD when a cell breaks the hint.
 int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, uint32_t table_cols, uint8_t root_out[32], uint32_t c_begin, uint32_t c_count,
-                                        bool window_only) {
+                                        bool window_only, uint32_t binary_cols) {
     const uint32_t col0 = segment == 0 ? 0 : Cm_;
     const uint32_t cols = window_only ? c_count : table_cols;
     if (!window_only) { c_begin = 0; c_count = table_cols; }
@@ -408,7 +437,19 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     SP_TIMEPOINT("  upload: threads, streams, pinned slots");
     // The chunks of the whole segment, in upload order: a block of rows of one column group, one ring slot (32 MB) at most; the
     // gather reads w x 32 contiguous bytes of every row (the wider the group, the better it streams).
-    struct Chunk { uint32_t g, c, cw, slot; uint64_t r0, rows, first_block, blocks; bool last_of_group; };
+    struct Chunk { uint32_t g, c, cw, slot; uint64_t r0, rows, first_block, blocks; bool last_of_group, packed; };
+    if (binary_cols) {
+        const uint64_t words = (uint64_t)binary_cols * (n_ >> 6);
+        if (flagbits_words_ < words) { SP_TRY(alloc((void**)&d_flagbits_, words * 8)); flagbits_words_ = words; }
+    }
+    uint64_t zero_img[4] = {0, 0, 0, 0}, one_img[4] = {0, 0, 0, 0};      // 0 and 1 as the table encodes them
+    {
+        const fe one = fe_one();
+        if (c_->enc == SP_FE_CANON_BE) { uint8_t b[32]; fe_to_bytes_be(one, b); std::memcpy(one_img, b, 32); }
+        else fe_to_lw_limbs(one, one_img);
+    }
+    std::atomic<bool> dirty{false};
+    uint64_t dma_bytes = 0;
     std::vector<Chunk> chunks;
     uint64_t n_blocks = 0;
     {
@@ -423,7 +464,9 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
             for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
                 const uint64_t blocks = (rows + block_rows - 1) / block_rows;
-                chunks.push_back(Chunk{g, c, cw, (uint32_t)(chunks.size() % UPLOAD_SLOTS), r0, rows, n_blocks, blocks, r0 + rows >= n_});
+                const bool packed = c + cw <= binary_cols;
+                dma_bytes += packed ? (uint64_t)cw * rows / 8 : (uint64_t)cw * rows * 32;
+                chunks.push_back(Chunk{g, c, cw, (uint32_t)(chunks.size() % UPLOAD_SLOTS), r0, rows, n_blocks, blocks, r0 + rows >= n_, packed});
                 n_blocks += blocks;
             }
         }
@@ -453,6 +496,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         uint64_t idle_spins = 0;
         double idle_since = 0.0;
         while (k < n_chunks) {
+            if (dirty.load(std::memory_order_acquire)) return SP_RETRY_RAW_UPLOAD;   // a cell broke the 0 / 1 hint: stop, the caller uploads in full
             bool progress = false;
             if (d < k) {
                 const hipError_t q = hipEventQuery(ev_dma_[chunks[d].slot]);
@@ -468,6 +512,11 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
             const Chunk& ck = chunks[k];
             if (blocks_done[k].load(std::memory_order_acquire) == ck.blocks) {
                 uint8_t* slot = static_cast<uint8_t*>(h_stage_[ck.slot]);
+                if (ck.packed) {
+                    for (uint32_t j = 0; j < ck.cw; ++j)   // a column's bits of this chunk: rows / 8 bytes
+                        SP_HIP_CHECK(hipMemcpyAsync(d_flagbits_ + ((uint64_t)(ck.c + j) * n_ + ck.r0) / 64, slot + (size_t)j * (ck.rows / 8), (size_t)ck.rows / 8,
+                                                    hipMemcpyHostToDevice, copy_stream_));
+                } else
                 for (uint32_t j = 0; j < ck.cw; ++j)   // column by column, straight into the trace area (host encoding; decoded in place below)
                     SP_HIP_CHECK(hipMemcpyAsync(trace + (uint64_t)(ck.c + j) * n_ + ck.r0, slot + (size_t)j * ck.rows * 32, (size_t)ck.rows * 32, hipMemcpyHostToDevice, copy_stream_));
                 SP_HIP_CHECK(hipEventRecord(ev_dma_[ck.slot], copy_stream_));
@@ -480,6 +529,8 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                     // host encoding -> device layout, in place, in front of the group's transforms on the compute stream (an ordinary
                     // kernel of the proof: the rows -> columns kernels this replaces ran on a highest-priority stream beside the
                     // transforms and made those 1.3 - 2.2 x slower for as long as the upload lasted - tools/upload_interference.py)
+                    if (ck.packed) SP_TRY(expand_bit_columns(c_->stream, d_flagbits_ + (uint64_t)gc0 * (n_ >> 6), n_, w, trace + (uint64_t)gc0 * n_));
+                    else
                     SP_TRY(decode_elements(c_->stream, c_->enc, reinterpret_cast<const uint8_t*>(trace + (uint64_t)gc0 * n_), (uint64_t)w * n_, trace + (uint64_t)gc0 * n_));
                     if (!window_only) {
                         // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
@@ -511,7 +562,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
         size_t k = 0;
         for (;;) {
             const uint64_t b = next_block.fetch_add(1, std::memory_order_relaxed);
-            if (b >= n_blocks) return;
+            if (b >= n_blocks || dirty.load(std::memory_order_relaxed)) return;
             while (b >= chunks[k].first_block + chunks[k].blocks) ++k;
             const Chunk& ck = chunks[k];
             for (unsigned spin = 0; k >= writable.load(std::memory_order_acquire); ++spin) {   // the slot is still crossing PCIe
@@ -520,17 +571,22 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
             }
             const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)ck.cw * 32)) & ~(uint64_t)1;
             const uint64_t br0 = (b - ck.first_block) * block_rows;
+            if (ck.packed)
+                host_pack_bits_block(rows_host + ck.r0 * (size_t)table_cols * 32, ck.rows, (size_t)table_cols * 32, (size_t)ck.c * 32, ck.cw,
+                                     static_cast<uint8_t*>(h_stage_[ck.slot]), br0, std::min<uint64_t>(ck.rows, br0 + block_rows), zero_img, one_img, dirty);
+            else
             host_gather_block(rows_host + ck.r0 * (size_t)table_cols * 32, ck.rows, (size_t)table_cols * 32, (size_t)ck.c * 32, ck.cw, static_cast<uint8_t*>(h_stage_[ck.slot]),
                               br0, std::min<uint64_t>(ck.rows, br0 + block_rows));
             blocks_done[k].fetch_add(1, std::memory_order_acq_rel);
         }
     });
-    if (rc_upload != SP_OK) return rc_upload;
+    if (rc_upload != SP_OK) return rc_upload;     // (SP_RETRY_RAW_UPLOAD included: everything queued so far is overwritten by the full upload that follows)
+    if (dirty.load(std::memory_order_acquire)) return SP_RETRY_RAW_UPLOAD;
     const double gather_ms = gather_end - t0;
     const double host_ms = wall_ms() - t0;
     SP_TIMEPOINT("  upload + transforms of the groups");
     if (window_only) {   // (the caller finishes the statistics once the compute stream has been waited for)
-        pending_up_groups_ = groups; pending_up_bytes_ = (uint64_t)cols * n_ * 32; pending_up_gather_ms_ = gather_ms; pending_up_host_ms_ = host_ms;
+        pending_up_groups_ = groups; pending_up_bytes_ = dma_bytes; pending_up_gather_ms_ = gather_ms; pending_up_host_ms_ = host_ms;
         return SP_OK;
     }
     if (segment == 0) SP_TRY(launch_aux_presort());   // every group has been turned into columns behind this point of the compute stream
@@ -538,7 +594,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     SP_TRY(commit_columns(lde, Nl_, cols, segment == 0 ? tree_main_ : tree_aux_, root_out));
     SP_TIMEPOINT("  leaf hashing + tree");
     stage_ = segment == 0 ? 2 : 3;
-    return finish_upload_stats(groups, (uint64_t)cols * n_ * 32, gather_ms, host_ms, 1);
+    return finish_upload_stats(groups, dma_bytes, gather_ms, host_ms, 1);
 }
 
 }  // namespace sp

@@ -143,7 +143,8 @@ def test_run_columns_and_host_rows_give_the_same_bytes(hip_ctx, oracle):
     rows = hip_ctx.cairo_prove(trace, run.public_inputs_c, opt)
     st_rows = hip_ctx.last_upload_stats()
     assert rows == want
-    assert st_rows["kind"].startswith("row-major") and st_rows["groups"] > 3 and st_rows["bytes"] == trace.nbytes
+    # (the sixteen flag columns cross PCIe as one bit per cell)
+    assert st_rows["kind"].startswith("row-major") and st_rows["groups"] > 3 and st_rows["bytes"] == trace.nbytes - 16 * run.n_rows * 32 + 16 * run.n_rows // 8
     assert hip_ctx.cairo_prove_run(run, opt) == want               # (default: the trace built on the device from the run)
     assert hip_ctx.last_upload_stats()["kind"].startswith("run image")
     hip_ctx.set_option(api.SP_OPT_DEVICE_TRACE, 0)
@@ -240,3 +241,21 @@ def test_prewarm_then_prove_gives_the_same_bytes(hip_lib, oracle):
         ctx.prewarm(1 << 7, 34, 18, False, api.ProofOptions(2, 3, 3, 1))
         tiny = api.CairoRun.fibonacci(10)
         assert ctx.cairo_prove_run(tiny, api.ProofOptions(2, 3, 3, 1)) == oracle.cairo_prove(tiny.main_trace(), tiny.public_inputs_c, (2, 3, 3, 1))
+
+
+def test_row_major_upload_with_flag_cells_that_are_not_bits(hip_ctx, oracle):
+    """The row-major upload sends the sixteen flag columns as bitmaps; a table whose flag cells are not all 0 / 1 (an invalid trace,
+    which the reference still proves) is detected by the gather threads and uploaded again in full: the oracle's bytes either way."""
+    run = api.CairoRun.fibonacci(9000)          # 2^16 rows x 34 columns = 71 MB: the pipelined upload
+    opts = (4, 3, 3, 1)
+    opt = api.ProofOptions(*opts)
+    for row, col, byte in ((12345, 3, 31), (65535, 15, 0), (0, 0, 17)):
+        trace = run.main_trace().copy()
+        trace[row, col, byte] ^= 2              # neither 0 nor 1 any more
+        want = oracle.cairo_prove(trace, run.public_inputs_c, opts)
+        assert hip_ctx.cairo_prove(trace, run.public_inputs_c, opt) == want
+        st = hip_ctx.last_upload_stats()
+        assert st["kind"].startswith("row-major") and st["bytes"] == trace.nbytes          # (the full upload that followed)
+    trace = run.main_trace()
+    assert hip_ctx.cairo_prove(trace, run.public_inputs_c, opt) == oracle.cairo_prove(trace, run.public_inputs_c, opts)
+    assert hip_ctx.last_upload_stats()["bytes"] < 0.6 * trace.nbytes
