@@ -460,7 +460,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
             // instead of 0.65, and the compute stream gets its first column that much earlier)
             const size_t chunk_g = g < 2 ? chunk / 4 : chunk;
             const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk_g / ((size_t)cw * 32)) & ~(uint64_t)255);
-            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)cw * 32)) & ~(uint64_t)1;   // ~256 KB written per block
+            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)cw * 32)) & ~(uint64_t)63;   // ~256 KB written per block
             for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
                 const uint64_t blocks = (rows + block_rows - 1) / block_rows;
@@ -569,7 +569,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                 if (abort_upload.load(std::memory_order_acquire)) return;
                 if (spin < 2000) __builtin_ia32_pause(); else std::this_thread::yield();
             }
-            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)ck.cw * 32)) & ~(uint64_t)1;
+            const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)ck.cw * 32)) & ~(uint64_t)63;
             const uint64_t br0 = (b - ck.first_block) * block_rows;
             if (ck.packed)
                 host_pack_bits_block(rows_host + ck.r0 * (size_t)table_cols * 32, ck.rows, (size_t)table_cols * 32, (size_t)ck.c * 32, ck.cw,
