@@ -602,10 +602,17 @@ def project_ranks(api, fib, blowup, ranks, single_gpu_ms, single_rows_ms=None, s
         ctx.init_null(ranks, 0)
         ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
         chosen = "sharded_interpolation" if ctx.last_proof_info()["interpolation_sharded"] else "replicated_interpolation"
-        rows_ms, rows_per = leg(ctx, lambda: ctx.cairo_prove(trace, run.public_inputs_c, opt))
-        rows_up = ctx.last_upload_stats()
         run_ms, run_per = leg(ctx, lambda: ctx.cairo_prove_run(run, opt))
         run_up = ctx.last_upload_stats()
+    finally:
+        ctx.close()
+    # the row-major table: the LAST rank's share - its window of the table holds none of the flag columns that cross PCIe as bitmaps,
+    # so it is the rank the others wait for in the all-gather of the trace
+    ctx = api.Context(device=torch.cuda.current_device())
+    try:
+        ctx.init_null(ranks, ranks - 1)
+        rows_ms, rows_per = leg(ctx, lambda: ctx.cairo_prove(trace, run.public_inputs_c, opt))
+        rows_up = ctx.last_upload_stats()
     finally:
         ctx.close()
     out["default_mode"] = chosen
