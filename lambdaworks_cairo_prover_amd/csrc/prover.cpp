@@ -499,6 +499,8 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_HIP_CHECK(hipSetDevice(c_->device));
     for (double& x : c_->upload_stats) x = 0.0;
     leaf_head_done_ = false;
+    const uint32_t binary_hint = binary_cols_hint_;   // (one call only: a later table on this prover need not be a Cairo trace)
+    binary_cols_hint_ = 0;
     // An upload that fails half-way must not return while copies from the caller's buffer are still in flight (the caller is free
     // to release it): every non-OK exit of the host paths waits for the copy and the compute stream first.
     auto drained = [this](int rc) {
@@ -522,8 +524,7 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     const bool rows_on_device = src == TRACE_DEVICE_ROWS;
     static const uint64_t pipeline_min_bytes = [] { const char* e = std::getenv("SP_UPLOAD_MIN_MB"); return (uint64_t)(e ? std::max(0, std::atoi(e)) : 64) << 20; }();
     static const bool no_pack = std::getenv("SP_UPLOAD_NO_FLAG_PACK") != nullptr;      // (A/B switch)
-    const uint32_t binary_cols = (segment == 0 && !no_pack && (n_ & 63) == 0) ? std::min(binary_cols_hint_, cols) : 0u;
-    binary_cols_hint_ = 0;
+    const uint32_t binary_cols = (segment == 0 && !no_pack && (n_ & 63) == 0) ? std::min(binary_hint, cols) : 0u;
     if (!rows_on_device && G_ == 1 && cols >= 8 && (uint64_t)n_ * cols * 32 >= pipeline_min_bytes) {
         int rc = drained(commit_trace_pipelined(segment, rows_host, cols, root_out, 0, 0, false, binary_cols));
         if (rc == SP_RETRY_RAW_UPLOAD) rc = drained(commit_trace_pipelined(segment, rows_host, cols, root_out));   // (not a trace with 0 / 1 flags)
