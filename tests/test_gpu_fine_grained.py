@@ -203,8 +203,10 @@ def test_lde_extreme_coefficients(hip_ctx, oracle):
 
 
 def test_plain_c_caller_runs_on_the_gpu(hip_ctx, tmp_path):
-    """examples/c_abi_smoke.c: a C99 program through the C ABI - an NTT round trip on the device."""
+    """examples/c_abi_smoke.c: a C99 program through the C ABI - an NTT round trip on the device, then the whole path of the reference's
+    CLI (run a program, pre-warm, prove from the run with the trace built on the device, verify, frame the proof file)."""
     import subprocess
     from test_capi import _build_c_example
     out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "ntt round trip: rc 0, identical" in out.stdout, out.stdout + out.stderr
+    assert "cairo proof: rc 0 (ok), 709 steps, 1024 x 34 trace" in out.stdout and "verifier accepts" in out.stdout, out.stdout + out.stderr
