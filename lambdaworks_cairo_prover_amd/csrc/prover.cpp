@@ -565,17 +565,20 @@ int StarkProver::commit_trace_rows_sharded(int segment, const uint8_t* rows_host
     {
         // (a rank whose window holds a cell that breaks the 0 / 1 hint must not leave the others waiting in the all-gather: the verdict
         // of the window upload is agreed on first - one flag per rank through the same all-gather)
-        int rc = commit_trace_pipelined(segment, rows_host, cols, root_out, first_col(rank_), cpr, true, binary_cols);
+        // The verdict of the window upload is agreed on before the all-gather of the trace - one word per rank through the same
+        // transport - so that a rank whose window breaks the 0 / 1 hint, or whose upload failed, does not leave the others waiting.
+        const int rc = commit_trace_pipelined(segment, rows_host, cols, root_out, first_col(rank_), cpr, true, binary_cols);
+        if (!d_flags_all_) SP_TRY(alloc((void**)&d_flags_all_, sizeof(int) * world_));
+        const int mine = rc == SP_OK ? 0 : (rc == SP_RETRY_RAW_UPLOAD ? 1 : 2);
+        SP_HIP_CHECK(hipMemcpyAsync(c_->d_flag, &mine, sizeof(int), hipMemcpyHostToDevice, c_->stream));
+        SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int)));
+        std::vector<int> flags(world_, 0);
+        SP_HIP_CHECK(hipMemcpy(flags.data(), d_flags_all_, sizeof(int) * world_, hipMemcpyDeviceToHost));
         if (rc != SP_OK && rc != SP_RETRY_RAW_UPLOAD) return rc;
-        if (binary_cols) {
-            if (!d_flags_all_) SP_TRY(alloc((void**)&d_flags_all_, sizeof(int) * world_));
-            const int mine = rc == SP_RETRY_RAW_UPLOAD ? 1 : 0;
-            SP_HIP_CHECK(hipMemcpyAsync(c_->d_flag, &mine, sizeof(int), hipMemcpyHostToDevice, c_->stream));
-            SP_TRY(all_gather(c_->d_flag, d_flags_all_, sizeof(int)));
-            std::vector<int> flags(world_, 0);
-            SP_HIP_CHECK(hipMemcpy(flags.data(), d_flags_all_, sizeof(int) * world_, hipMemcpyDeviceToHost));
-            for (int f : flags) if (f) return SP_RETRY_RAW_UPLOAD;
-        }
+        int worst = 0;
+        for (int f : flags) worst = std::max(worst, f);
+        if (worst == 2) { sp_set_error("commit_trace: the upload of another rank failed"); return SP_E_HIP; }
+        if (worst == 1) return SP_RETRY_RAW_UPLOAD;
     }
     // (the LDE area of this segment is free until the transforms below: landing zone of the all-gather)
     const uint64_t block = (uint64_t)cpr * n_;
