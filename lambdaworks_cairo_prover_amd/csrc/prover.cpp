@@ -1387,12 +1387,18 @@ int StarkProver::deep_fri_begin(const fe& gamma, const fe& gamma_p, const std::v
             SP_TRY(coset_minus_points(c_->stream, inv, n_, logn_, roots_n, hp, pts, npts, ShardMap{0, 0, 0}));
             SP_TRY(batch_inverse(c_->stream, inv, inv_scratch, (uint64_t)npts * n_, c_->d_flag));
         }
+        if (fri_sharded(0) && logb_ == logG_) {
+            // one coset per rank and a sharded layer 0: the n points of that coset in natural order ARE this rank's share of the layer
+            // (local index = row of the coset), so the quotient form is written there and nothing is interpolated or extended
+            SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, d_fri_evals_[0], lde_order(), R));
+        } else {
         SP_TRY(deep_composition(c_->stream, d_lde_, d_h12_, d_h12_ + Nl_, n_, Nl_, shift, d_deep_consts_, inv, p0n, lde_order(), R));
         // coefficients c_j h^j in bit-reversed order: inverse DFT over the coset, times n^-1 w_N^(-c0 j)
         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(p0n, (int)logn_, 1, n_, d_post_deep_));   // n^-1 w_N^(-c0 j): setup()
         // FRI layer 0: the evaluations this rank holds (local natural order) when the layer is sharded, the whole domain otherwise
         if (fri_sharded(0)) SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, Nl_, (int)logG_, (int)rank_));
         else SP_TRY(c_->ntt->lde_from_bitrev(p0n, d_fri_evals_[0], (int)logn_, (int)logb_, 1, n_, N_));
+        }
     } else {
         // deg H >= 2n (constraint-violating trace): the quotient form on every LDE point this rank holds
         fe* inv = d_scratch_;
