@@ -1571,13 +1571,13 @@ int StarkProver::grind(const uint8_t challenge[32], uint8_t factor, uint64_t* no
 // ranks the blocks are all-gathered once and the copy of the rank that owns the item is kept: LDE rows and sharded FRI values
 // live on the rank with role index mod G, the lower levels of a sharded tree on the rank whose contiguous leaf range holds
 // the index, the top log2 G levels everywhere.
-int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
+int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o, bool values_canonical_be) {
     if (stage_ != 7) { sp_set_error("open: FRI commit phase not finished"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const uint32_t q = (uint32_t)iotas.size();
     if (q == 0 || q > 1024) return SP_E_INVALID_ARG;
     const uint32_t L = logn_, d0 = logN_;
-    o.n_queries = q; o.n_layers = L; o.n_cols = C_; o.depth0 = d0;
+    o.n_queries = q; o.n_layers = L; o.n_cols = C_; o.depth0 = d0; o.values_canonical_be = values_canonical_be;
     hipStream_t st = c_->stream;
     const LdeOrder ord = lde_order();
     struct TreeJob { const TreeBuf* t; std::vector<uint64_t> idx; size_t lower_off = 0, upper_off = 0, ipos = 0, iown = 0; uint32_t dl = 0, du = 0; };
@@ -1609,6 +1609,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     // staging layout (32-byte items) and the index array (uint64)
     size_t items = 0, nidx = 0;
     for (auto& v : vj) { v.off = items; items += v.idx.size() * v.ncols; v.ipos = nidx; nidx += v.idx.size(); }
+    const size_t value_items = items;        // the field elements come first in the staging block, the digests behind them
     for (auto& t : tj) {
         t.dl = (uint32_t)sp_log2_exact(t.t->sub_leaves); t.du = t.t->top == t.t->sub ? 0u : logG_;
         t.lower_off = items; items += t.idx.size() * t.dl;
@@ -1657,6 +1658,7 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o) {
     std::memcpy(up.data() + idx_bytes, jobs.data(), jobs.size() * sizeof(GatherJob));
     SP_HIP_CHECK(hipMemcpyAsync(base, up.data(), up.size(), hipMemcpyHostToDevice, st));
     SP_TRY(gather_jobs(st, d_jobs, (uint32_t)jobs.size(), max_items, d_idx, blk));
+    if (values_canonical_be) SP_TRY(encode_elements(st, SP_FE_CANON_BE, blk, value_items, reinterpret_cast<uint8_t*>(blk)));   // in place, element by element
     std::vector<fe> host(items * (G_ > 1 ? world_ : 1));
     if (G_ > 1) {
         SP_TRY(all_gather(blk, all_dev, blk_bytes, true));

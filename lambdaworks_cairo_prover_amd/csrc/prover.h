@@ -31,6 +31,7 @@ struct AirDescHost {
 
 struct Openings {
     uint32_t n_queries = 0, n_layers = 0, n_cols = 0, depth0 = 0;
+    bool values_canonical_be = false;                            // the four value arrays hold wire-format bytes, not Montgomery limbs
     std::vector<fe> trace_evals, comp_evals;                     // [q][C], [q][2]
     std::vector<digest32> main_paths, aux_paths, comp_paths;     // [q][depth0]
     std::vector<fe> fri_evals, fri_evals_sym;                    // [q][L]
@@ -85,7 +86,10 @@ class StarkProver : public sp_deletable {
     bool fri_chain_available() const { return stage_ == 6 && logn_ >= 2 && fri_layer_ >= 1 && (!fri_sharded(fri_layer_ - 1) || comm_async()); }
     int fri_commit_chain(const fe& zeta0, const uint8_t state32[32], std::vector<std::array<uint8_t, 32>>& roots_out, fe* last_value);
     int grind(const uint8_t challenge[32], uint8_t factor, uint64_t* nonce_out);
-    int open(const std::vector<uint64_t>& iotas, Openings& out);
+    // values_canonical_be: the opened field elements come back as their canonical 32-byte big-endian encodings (the proof's wire format,
+    // written by the gather's launch-mate on the device) in the same `fe`-sized slots - for the whole-proof drivers, whose serializer
+    // then copies bytes instead of converting 7 - 8 thousand elements on one host thread.  The round-level ABI keeps Montgomery values.
+    int open(const std::vector<uint64_t>& iotas, Openings& out, bool values_canonical_be = false);
 
     // sp_prewarm (capi_prove.cpp): host-side plumbing of a first proof, and round 1's kernels at the real shape on arena contents
     int warm_plumbing(bool host_rows);

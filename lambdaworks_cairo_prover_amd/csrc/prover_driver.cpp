@@ -4,6 +4,8 @@
 #include "keccak.h"
 #include <array>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
 #include <stdexcept>
 
 namespace sp {
@@ -38,14 +40,17 @@ struct HostTranscript {
     }
 };
 
+// Writes the proof in one pass into a buffer of its final size (every length of the format is known before the first byte).
 struct ProofWriter {
     std::vector<uint8_t> b;
-    void u64(uint64_t v) { for (int i = 7; i >= 0; --i) b.push_back((uint8_t)(v >> (8 * i))); }
-    void felt(const fe& x) { uint8_t t[32]; fe_to_bytes_be(x, t); b.insert(b.end(), t, t + 32); }
-    void digest(const digest32& d) { const uint8_t* p = reinterpret_cast<const uint8_t*>(d.w); b.insert(b.end(), p, p + 32); }
-    void raw(const uint8_t* p, size_t n) { b.insert(b.end(), p, p + n); }
-    void path(const digest32* p, uint32_t depth) { u64(depth); for (uint32_t i = 0; i < depth; ++i) digest(p[i]); }
-    void bytes(const std::vector<uint8_t>& v) { b.insert(b.end(), v.begin(), v.end()); }
+    size_t at = 0;
+    explicit ProofWriter(size_t total) : b(total) {}
+    void u64(uint64_t v) { for (int i = 7; i >= 0; --i) b[at++] = (uint8_t)(v >> (8 * i)); }
+    void felt(const fe& x) { fe_to_bytes_be(x, &b[at]); at += 32; }
+    // an opened value: Montgomery limbs, or already the 32 wire bytes (Openings::values_canonical_be)
+    void opened(const fe& x, bool canonical_be) { if (canonical_be) { std::memcpy(&b[at], &x, 32); at += 32; } else felt(x); }
+    void raw(const void* p, size_t n) { std::memcpy(&b[at], p, n); at += n; }
+    void path(const digest32* p, uint32_t depth) { u64(depth); raw(p, (size_t)depth * 32); }
 };
 
 bool z_in_domains(const fe& z, const fe& hinv, uint32_t logn, uint32_t logN) {  // transcript.rs:53-69
@@ -64,54 +69,58 @@ static void serialize_proof(uint64_t n, const std::vector<std::array<uint8_t, 32
                             const fe& last_value, const std::vector<uint64_t>& iotas, const Openings& o, uint64_t nonce,
                             std::vector<uint8_t>& proof_out) {
     const uint32_t L = o.n_layers, d0 = o.depth0;
-    ProofWriter w;
+    const bool be = o.values_canonical_be;
+    const size_t Q = iotas.size(), R = roots.size();
+    size_t path_total = 0;
+    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
+    // sizes of the nested records (each is preceded by its byte length)
+    const size_t frame_bytes = 16 + 32 * ood.size() + 8;
+    const size_t paths_bytes = (size_t)L * 8 + path_total * 32;                       // L paths: depth word + digests
+    const size_t query_bytes = 8 + paths_bytes + 8 + 8 + (size_t)L * 32 + 8 + (size_t)L * 32 + 8 + paths_bytes;
+    const size_t opening_bytes = (8 + (size_t)d0 * 32) + 8 + 64 + 8 + R * (8 + (size_t)d0 * 32) + 8 + (size_t)C * 32;
+    const size_t total = 8 + 8 + R * 32 + 8 + frame_bytes + 32 + 8 + 64 + 8 + fri_roots.size() * 32 + 32 + 8 + Q * (8 + query_bytes) + 8 + Q * (8 + opening_bytes) + 8;
+    ProofWriter w(total);
     w.u64(n);
-    w.u64(roots.size());
+    w.u64(R);
     for (auto& r : roots) w.raw(r.data(), 32);
-    {
-        ProofWriter f;
-        f.u64(ood.size()); f.u64(32);
-        for (auto& e : ood) f.felt(e);
-        f.u64(C);
-        w.u64(f.b.size()); w.bytes(f.b);
-    }
+    w.u64(frame_bytes);
+    w.u64(ood.size()); w.u64(32);
+    for (auto& e : ood) w.felt(e);
+    w.u64(C);
     w.raw(comp_root, 32);
     w.u64(32); w.felt(h1z); w.felt(h2z);
     w.u64(fri_roots.size());
     for (auto& r : fri_roots) w.raw(r.data(), 32);
     w.felt(last_value);
-    size_t path_total = 0;
-    for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
-    w.u64(iotas.size());
-    for (size_t s = 0; s < iotas.size(); ++s) {
-        ProofWriter qw;
-        qw.u64(L);
+    w.u64(Q);
+    for (size_t s = 0; s < Q; ++s) {
+        w.u64(query_bytes);
+        w.u64(L);
         size_t po = 0;
-        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
-        qw.u64(32);
-        qw.u64(L);
-        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals_sym[s * L + k]);
-        qw.u64(L);
-        for (uint32_t k = 0; k < L; ++k) qw.felt(o.fri_evals[s * L + k]);
-        qw.u64(L);
+        for (uint32_t k = 0; k < L; ++k) { w.path(&o.fri_paths_sym[s * path_total + po], d0 - k); po += d0 - k; }
+        w.u64(32);
+        w.u64(L);
+        for (uint32_t k = 0; k < L; ++k) w.opened(o.fri_evals_sym[s * L + k], be);
+        w.u64(L);
+        for (uint32_t k = 0; k < L; ++k) w.opened(o.fri_evals[s * L + k], be);
+        w.u64(L);
         po = 0;
-        for (uint32_t k = 0; k < L; ++k) { qw.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
-        w.u64(qw.b.size()); w.bytes(qw.b);
+        for (uint32_t k = 0; k < L; ++k) { w.path(&o.fri_paths[s * path_total + po], d0 - k); po += d0 - k; }
     }
-    w.u64(iotas.size());
-    for (size_t s = 0; s < iotas.size(); ++s) {
-        ProofWriter ow;
-        ow.path(&o.comp_paths[s * d0], d0);
-        ow.u64(32);
-        ow.felt(o.comp_evals[s * 2]); ow.felt(o.comp_evals[s * 2 + 1]);
-        ow.u64(roots.size());
-        ow.path(&o.main_paths[s * d0], d0);
-        if (roots.size() > 1) ow.path(&o.aux_paths[s * d0], d0);
-        ow.u64(C);
-        for (uint32_t j = 0; j < C; ++j) ow.felt(o.trace_evals[s * C + j]);
-        w.u64(ow.b.size()); w.bytes(ow.b);
+    w.u64(Q);
+    for (size_t s = 0; s < Q; ++s) {
+        w.u64(opening_bytes);
+        w.path(&o.comp_paths[s * d0], d0);
+        w.u64(32);
+        w.opened(o.comp_evals[s * 2], be); w.opened(o.comp_evals[s * 2 + 1], be);
+        w.u64(R);
+        w.path(&o.main_paths[s * d0], d0);
+        if (R > 1) w.path(&o.aux_paths[s * d0], d0);
+        w.u64(C);
+        for (uint32_t j = 0; j < C; ++j) w.opened(o.trace_evals[s * C + j], be);
     }
     w.u64(nonce);
+    if (w.at != total) throw std::runtime_error("serialize_proof: size bookkeeping is off");
     proof_out.swap(w.b);
 }
 
@@ -139,12 +148,15 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         hipEvent_t* ev = evs.e;
         for (auto& e : evs.e) SP_HIP_CHECK(hipEventCreate(&e));
         double _tp = wall_ms();
+        static const bool tail_timing = std::getenv("SP_TAIL_TIMING") != nullptr;
+        const double t_entry = wall_ms();
         SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
         SP_TIMEPOINT("setup (alloc + tables)");
         HostTranscript tr;
         uint8_t root[32];
         // ---- round 1 (reference prover.rs:187-224)
         SP_HIP_CHECK(hipEventRecord(ev[0], ctx->stream));
+        const double t_ev0 = wall_ms();
         P->request_aux_presort(pub);                    // the sorts of the auxiliary trace: beside round 1 too
         if (pub.num_steps >= 1 && pub.num_steps <= n)   // round 2's boundary denominators need no challenge: beside round 1
             SP_TRY(P->prefetch_boundary_inverses({0, pub.num_steps - 1, n - 1}));
@@ -229,8 +241,9 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings o;
-        SP_TRY(P->open(iotas, o));
+        SP_TRY(P->open(iotas, o, true));   // opened values as wire bytes (encoded on the device)
         SP_TIMEPOINT("r4 openings");
+        const double t_open = wall_ms();
         SP_HIP_CHECK(hipEventRecord(ev[4], ctx->stream));
         SP_HIP_CHECK(hipEventSynchronize(ev[4]));
         if (round_ms) {
@@ -239,7 +252,10 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         }
         std::vector<std::array<uint8_t, 32>> roots(2);
         std::memcpy(roots[0].data(), main_root, 32); std::memcpy(roots[1].data(), aux_root, 32);
+        const double t_ser0 = wall_ms();
         serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
+        if (tail_timing) std::fprintf(stderr, "[sp_tail] before the first event %.3f ms, events + bookkeeping after open() %.3f ms, serialize %.3f ms\n", t_ev0 - t_entry,
+                                      t_ser0 - t_open, wall_ms() - t_ser0);
         return SP_OK;
     } catch (const std::exception& e) {
         sp_set_error(std::string("cairo_prove: ") + e.what());
@@ -363,7 +379,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings o;
-        SP_TRY(P->open(iotas, o));
+        SP_TRY(P->open(iotas, o, true));   // opened values as wire bytes (encoded on the device)
         SP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
         return SP_OK;
