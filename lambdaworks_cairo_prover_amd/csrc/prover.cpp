@@ -28,6 +28,7 @@ StarkProver::~StarkProver() {
     if (pool_) host_pool_delete(pool_);
     for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
     if (h_pin_) (void)hipHostFree(h_pin_);
+    if (h_open_pin_) (void)hipHostFree(h_open_pin_);
     if (h_wide_) (void)hipHostFree(h_wide_);
     for (hipEvent_t e : {ev_side_fork_, ev_side_deep_, ev_side_bnd_, ev_side_aux_, ev_side_presort_}) if (e) (void)hipEventDestroy(e);
     if (side_stream_) (void)hipStreamDestroy(side_stream_);
@@ -1659,15 +1660,24 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o, bool valu
     SP_HIP_CHECK(hipMemcpyAsync(base, up.data(), up.size(), hipMemcpyHostToDevice, st));
     SP_TRY(gather_jobs(st, d_jobs, (uint32_t)jobs.size(), max_items, d_idx, blk));
     if (values_canonical_be) SP_TRY(encode_elements(st, SP_FE_CANON_BE, blk, value_items, reinterpret_cast<uint8_t*>(blk)));   // in place, element by element
-    std::vector<fe> host(items * (G_ > 1 ? world_ : 1));
+    // the download lands in a page-locked buffer kept across proofs (a pageable destination is staged by the runtime: ~2 MB per proof)
+    const size_t host_items = items * (G_ > 1 ? world_ : 1);
+    if (h_open_cap_ < host_items * sizeof(fe)) {
+        if (h_open_pin_) (void)hipHostFree(h_open_pin_);
+        h_open_pin_ = nullptr; h_open_cap_ = 0;
+        const size_t cap = host_items * sizeof(fe) + (host_items * sizeof(fe)) / 4;
+        if (hipHostMalloc(&h_open_pin_, cap, hipHostMallocDefault) != hipSuccess) { h_open_pin_ = nullptr; (void)hipGetLastError(); sp_set_error("open: page-locked download buffer: allocation failed"); return SP_E_ALLOC; }
+        h_open_cap_ = cap;
+    }
+    const fe* host = static_cast<const fe*>(h_open_pin_);
     if (G_ > 1) {
         SP_TRY(all_gather(blk, all_dev, blk_bytes, true));
-        SP_HIP_CHECK(hipMemcpyAsync(host.data(), all_dev, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
+        SP_HIP_CHECK(hipMemcpyAsync(h_open_pin_, all_dev, host_items * sizeof(fe), hipMemcpyDeviceToHost, st));
     } else {
-        SP_HIP_CHECK(hipMemcpyAsync(host.data(), blk, host.size() * sizeof(fe), hipMemcpyDeviceToHost, st));
+        SP_HIP_CHECK(hipMemcpyAsync(h_open_pin_, blk, host_items * sizeof(fe), hipMemcpyDeviceToHost, st));
     }
     SP_HIP_CHECK(sp_stream_wait_polling(st));   // (hidx is a local)
-    auto slot = [&](uint32_t owner) -> const fe* { return host.data() + (G_ > 1 ? (size_t)owner * items : 0); };
+    auto slot = [&](uint32_t owner) -> const fe* { return host + (G_ > 1 ? (size_t)owner * items : 0); };
     auto take_values = [&](const ValJob& v, size_t s, fe* dst) {
         const uint32_t owner = v.sharded ? (uint32_t)(v.idx[s] & (G_ - 1)) : rank_;
         const fe* src = slot(owner) + v.off + s * v.ncols;
@@ -1678,12 +1688,15 @@ int StarkProver::open(const std::vector<uint64_t>& iotas, Openings& o, bool valu
         std::memcpy(dst, slot(owner) + t.lower_off + s * t.dl, (size_t)t.dl * 32);
         if (t.du) std::memcpy(dst + t.dl, slot(rank_) + t.upper_off + s * t.du, (size_t)t.du * 32);
     };
+    // (every entry is written below: no zero fill of arrays an Openings object reused across proofs already has at this size;
+    // the auxiliary paths of an AIR without an auxiliary segment are the exception)
     o.trace_evals.resize((size_t)q * C_); o.comp_evals.resize((size_t)q * 2);
-    o.main_paths.assign((size_t)q * d0, digest32{}); o.aux_paths.assign((size_t)q * d0, digest32{}); o.comp_paths.assign((size_t)q * d0, digest32{});
+    o.main_paths.resize((size_t)q * d0); o.comp_paths.resize((size_t)q * d0);
+    if (Ca_) o.aux_paths.resize((size_t)q * d0); else o.aux_paths.assign((size_t)q * d0, digest32{});
     size_t path_total = 0;
     for (uint32_t k = 0; k < L; ++k) path_total += d0 - k;
-    o.fri_evals.assign((size_t)q * L, fe_zero()); o.fri_evals_sym.assign((size_t)q * L, fe_zero());
-    o.fri_paths.assign((size_t)q * path_total, digest32{}); o.fri_paths_sym.assign((size_t)q * path_total, digest32{});
+    o.fri_evals.resize((size_t)q * L); o.fri_evals_sym.resize((size_t)q * L);
+    o.fri_paths.resize((size_t)q * path_total); o.fri_paths_sym.resize((size_t)q * path_total);
     size_t ti = 0;
     const TreeJob& jm = tj[ti++];
     const TreeJob* ja = Ca_ ? &tj[ti++] : nullptr;

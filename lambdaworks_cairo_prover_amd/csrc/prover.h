@@ -252,6 +252,7 @@ class StarkProver : public sp_deletable {
     unsigned long long* d_nonce_ = nullptr;
     uint8_t* d_fri_chain_ = nullptr; uint32_t fri_chain_layers_ = 0;   // [state 32 B][L x constants][L x zeta constants][L x roots]
     void* h_pin_ = nullptr;   // 4 KB of pinned host memory for readback()
+    void* h_open_pin_ = nullptr; size_t h_open_cap_ = 0;   // page-locked landing zone of the openings' download (kept across proofs)
     int* h_wide_ = nullptr;   // pinned: the presort's "wide address" flag, copied behind the sorts on the side stream
     // Side stream: latency-bound work that does not wait for the next challenge runs beside the compute stream instead of in
     // its way - a batch inversion is one chain of ~260 dependent field products (~0.3 ms whatever the size).

@@ -240,7 +240,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         SP_TIMEPOINT("r4 grinding");
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
-        Openings o;
+        Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)
         SP_TRY(P->open(iotas, o, true));   // opened values as wire bytes (encoded on the device)
         SP_TIMEPOINT("r4 openings");
         const double t_open = wall_ms();
@@ -378,7 +378,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
         }
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
-        Openings o;
+        Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)
         SP_TRY(P->open(iotas, o, true));   // opened values as wire bytes (encoded on the device)
         SP_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         serialize_proof(n, roots, P->cols(), ood, comp_root, h1z, h2z, fri_roots, last_value, iotas, o, nonce, proof_out);
