@@ -195,12 +195,27 @@ int sp_cairo_run_from_arrays(const uint64_t* regs, uint64_t steps, const uint64_
     sp_cairo_run* r = new sp_cairo_run();
     try {
         r->regs.resize(steps);
-        for (uint64_t i = 0; i < steps; ++i) r->regs[i] = sp::RegisterState{regs[3 * i], regs[3 * i + 1], regs[3 * i + 2]};
-        for (uint64_t k = 0; k < n_cells; ++k) {
+        sp::host_parallel_for(steps, 1 << 16, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) r->regs[i] = sp::RegisterState{regs[3 * i], regs[3 * i + 1], regs[3 * i + 2]};
+        });
+        auto cell = [&](uint64_t k) {
             fe v;
             if (enc == SP_FE_CANON_BE) v = fe_from_bytes_be(values + 32 * k);
             else { uint64_t l[4]; std::memcpy(l, values + 32 * k, 32); v = fe_from_lw_limbs(l); }
-            r->mem.set(addrs[k], v);
+            return v;
+        };
+        // a relocated memory is one run of addresses from 1 on: the flat array is sized once and filled by all threads (the wire
+        // encoding costs a Montgomery product per cell); anything else goes cell by cell through CairoMemory::set
+        uint64_t hi = 0;
+        for (uint64_t k = 0; k < n_cells; ++k) hi = std::max(hi, addrs[k]);
+        if (hi < 8 * n_cells + 1024 && hi + 1 < (1ULL << 32)) {
+            r->mem.dense.assign(hi + 1, fe_zero());
+            r->mem.present.assign(hi + 1, 0);
+            sp::host_parallel_for(n_cells, 1 << 14, [&](size_t b, size_t e) {
+                for (size_t k = b; k < e; ++k) { r->mem.dense[addrs[k]] = cell(k); r->mem.present[addrs[k]] = 1; }   // (a duplicate address: last writer wins, as with set)
+            });
+        } else {
+            for (uint64_t k = 0; k < n_cells; ++k) r->mem.set(addrs[k], cell(k));
         }
         std::vector<sp::MemorySegment> segs;
         for (uint32_t i = 0; i < n_segments; ++i) {
