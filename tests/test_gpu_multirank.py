@@ -73,6 +73,8 @@ def _worker(rank, world, port, case, options, knobs, q):
             ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, knobs["shard_interp"])
         if knobs.get("poseidon"):
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
+        if knobs.get("prewarm"):   # every rank pre-warms (its small proofs are sharded proofs over the same transport)
+            ctx.prewarm(trace.shape[0], trace.shape[1], 18, trace.shape[1] == 43, api.ProofOptions(*options))
         proof = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
         proof2 = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))  # buffer reuse path
         stats = ctx.comm_stats()
@@ -129,6 +131,9 @@ CASES = [
     (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 4, "async": True}),
     (8, FIB(100), (8, 4, 3, 1), {"fri_min_log": 5, "async": True, "async_a2a": False}),
     (2, RND(128, 19), (4, 3, 3, 1), {"fri_min_log": 4, "async": True}),
+    # sp_prewarm on every rank before the proof (blocking and stream-ordered transport)
+    (4, FIB(200), (8, 4, 3, 1), {"fri_min_log": 5, "prewarm": True}),
+    (2, FIB(100), (4, 3, 3, 1), {"fri_min_log": 5, "prewarm": True, "async": True, "shard_interp": 1}),
     # the exact trace check of round 2 is split by rows over the ranks (n >= 256 world): a violation in the last rank's slice only
     (2, {"kind": "fib_flip", "fib": 100, "row": 700, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
     (4, {"kind": "fib_flip", "fib": 100, "row": 3, "col": 24}, (4, 3, 3, 1), {"fri_min_log": 5}),
