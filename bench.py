@@ -197,10 +197,21 @@ def cpu_proof_child(args):
     run = api.CairoRun.fibonacci(fib)
     trace = run.main_trace()
     t0 = time.perf_counter()
-    proof = oracle.cairo_prove(trace, run.public_inputs_c, (blowup, 80, 3, 20))
+    proof, rounds = oracle.cairo_prove(trace, run.public_inputs_c, (blowup, 80, 3, 20), want_timings=True)
     ms = (time.perf_counter() - t0) * 1e3
+    # kernel-level CPU rate beside the whole proof: Keccak-f permutations per second of the oracle's
+    # Merkle build on a 2^16-leaf x 34-column tree (9 permutations a leaf - 1088 bytes + padding over a 136-byte rate - and one a node)
+    import numpy as np
+    leaves = np.random.default_rng(5).integers(0, 256, size=(1 << 16, 34, 32), dtype=np.uint8)
+    leaves[:, :, 0] &= 0x07
+    t1 = time.perf_counter()
+    oracle.merkle_build(leaves)
+    keccak_s = time.perf_counter() - t1
+    perms = (1 << 16) * 9 + (1 << 16) - 1
     with open(args.cpu_proof_child, "w") as f:
-        json.dump({"cpu_ms": ms, "cores": cores, "nproc": os.cpu_count() or 1, "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof), "trace_rows": run.n_rows}, f)
+        json.dump({"cpu_ms": ms, "cpu_round_ms": [round(x * 1e3, 1) for x in rounds], "cores": cores, "nproc": os.cpu_count() or 1,
+                   "cpu_keccak_f_per_s": perms / keccak_s, "proof_sha256": hashlib.sha256(proof).hexdigest(), "proof_bytes": len(proof),
+                   "trace_rows": run.n_rows}, f)
 
 
 def cpu_proof_cfg4(args, device_proof):
@@ -486,7 +497,7 @@ def compact_line(full):
     if isinstance(cb, dict):
         c4 = cb.get("proof_cfg4")
         if isinstance(c4, dict) and "cpu_ms" in c4 and "cfg4" in summ:
-            summ["cfg4"].update(cpu_ms=_r(c4["cpu_ms"], 0), cpu_cores=c4.get("cores"), cpu_identical=c4.get("identical_bytes"))
+            summ["cfg4"].update(cpu_ms=_r(c4["cpu_ms"], 0), cpu_round_ms=c4.get("cpu_round_ms"), cpu_cores=c4.get("cores"), cpu_identical=c4.get("identical_bytes"))
         c3 = cb.get("proof_cfg3_extrapolated")
         if isinstance(c3, dict) and "cpu_ms" in c3 and "cfg3" in summ:
             summ["cfg3"].update(cpu_ms_extrapolated=_r(c3["cpu_ms"], 0), cpu_cores=c3.get("cores"))
