@@ -335,7 +335,7 @@ static void host_pack_bits_block(const uint8_t* src, uint64_t n, size_t row_byte
         const uint64_t lim = std::min<uint64_t>(64, r1 - i);
         const uint8_t* s = src + i * row_bytes + off;
         for (uint64_t k = 0; k < lim; ++k, s += row_bytes) {
-            __builtin_prefetch(s + PF_ROWS * row_bytes, 0, 0);
+            for (uint32_t l = 0; l < cw * 32; l += 64) __builtin_prefetch(s + PF_ROWS * row_bytes + l, 0, 0);
             for (uint32_t u = 0; u < cw; ++u) {
                 uint64_t v[4];
                 __builtin_memcpy(v, s + 32 * (size_t)u, 32);
@@ -394,14 +394,45 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // column (host_gather_block) wider groups no longer stream better either - four-column groups: 30.1 ms at config #4, pairs 29.3.
     static const uint32_t maxw_env = [] { const char* e = std::getenv("SP_UPLOAD_MAXW"); return e ? (uint32_t)std::min(8, std::max(2, std::atoi(e))) : 0u; }();
     const uint32_t maxw = maxw_env ? maxw_env : 2u;
-    std::vector<uint32_t> gsize;
-    for (uint32_t done = 0; done < cols;) {
-        uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done + 1) / 2)));
-        if (cols - done <= w + 1) w = cols - done;     // no one-column tail
-        gsize.push_back(w);
-        done += w;
+    // Columns that cross as bitmaps go eight at a time: the threads read 256 contiguous bytes of every row per pass instead of one
+    // 64-byte line (tools/experiments/gather_bench.cpp on an MI355X host, 24 threads, 16 flag columns of 2^19 rows: 3.5 ms as eight
+    // pair-wide passes, 1.8 ms as two 8-wide ones, 1.6 ms as one) and the link carries next to nothing for them either way.  In the
+    // proof (tools/rows_tail.py, config #4 / #3): gather 8.0 -> 5.9 ms / 21.9 -> 13.8 ms, host CPU time 256 -> 209 / 656 -> 484 ms,
+    // the proof itself within the box spread (24.7 - 25.3 ms either way: the transforms are the bound by then).  Sixteen at a time
+    // would put 1.6 ms of gathering in front of the compute stream's first cheap columns.  SP_UPLOAD_PACKW=1..8 overrides.
+    static const uint32_t packw = [] { const char* e = std::getenv("SP_UPLOAD_PACKW"); return e ? (uint32_t)std::min(8, std::max(1, std::atoi(e))) : 8u; }();
+    struct Group { uint32_t c, w; };
+    std::vector<Group> packed_g, wide_g;
+    {
+        const uint32_t c_end = c_begin + cols, p_end = std::min(c_end, std::max(c_begin, binary_cols));
+        for (uint32_t c = c_begin; c < p_end;) { const uint32_t w = std::min(packw, p_end - c); packed_g.push_back(Group{c, w}); c += w; }
+        for (uint32_t done = 0, left = c_end - p_end; done < left;) {
+            uint32_t w = done < 2 ? 1u : std::min<uint32_t>(maxw, std::max<uint32_t>(2, 2 * ((done + 1) / 2)));
+            if (left - done <= w + 1) w = left - done;     // no one-column tail
+            wide_g.push_back(Group{p_end + done, w});
+            done += w;
+        }
     }
-    const uint32_t groups = (uint32_t)gsize.size();
+    const uint32_t groups = (uint32_t)(packed_g.size() + wide_g.size());
+    // Upload order.  A bitmap group costs the gather threads their share of the table's bytes and the link nothing; a group of
+    // full-width columns costs the link more than the threads (0.6 ms of DMA against 0.5 ms of gathering per pair of 2^19 rows), and
+    // the transforms of a column take less than its DMA at blowup 4.  All bitmaps first leave the link idle while they are gathered and
+    // make it the bound afterwards; all last starve the compute stream, which gets a column every 0.3 ms and needs 0.25.  Taken in
+    // turns - a wide group, a bitmap group, ... - the DMA of a wide group runs beside the gather of the next bitmap group, and the
+    // eight cheap columns of a bitmap group keep the compute stream busy while the next wide ones cross.  SP_UPLOAD_ORDER=seq: table order.
+    std::vector<Group> order;
+    {
+        static const bool seq = [] { const char* e = std::getenv("SP_UPLOAD_ORDER"); return e && e[0] == 's'; }();
+        size_t ip = 0, iw = 0;
+        if (seq || window_only || packed_g.empty() || wide_g.empty()) { order = packed_g; order.insert(order.end(), wide_g.begin(), wide_g.end()); }
+        else
+            while (ip < packed_g.size() || iw < wide_g.size()) {
+                if (iw < wide_g.size()) order.push_back(wide_g[iw++]);
+                if (ip < packed_g.size()) order.push_back(packed_g[ip++]);
+            }
+    }
+    std::vector<uint8_t> extended(cols, 0);      // columns whose transforms are queued (the leaf head wants a whole prefix of them)
+    uint32_t extended_prefix = 0;
     const size_t chunk = upload_chunk_bytes();   // bytes per ring slot
     double _tp = wall_ms();
     sp_ctx* ctx = c_;
@@ -453,18 +484,17 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     std::vector<Chunk> chunks;
     uint64_t n_blocks = 0;
     {
-        uint32_t c = c_begin;
-        for (uint32_t g = 0; g < groups; c += gsize[g], ++g) {
-            const uint32_t cw = gsize[g];
+        for (uint32_t g = 0; g < groups; ++g) {
+            const uint32_t c = order[g].c, cw = order[g].w;
             // (the two single columns that start the pipeline in quarter-size chunks: the first DMA leaves after 0.16 ms of gathering
             // instead of 0.65, and the compute stream gets its first column that much earlier)
-            const size_t chunk_g = g < 2 ? chunk / 4 : chunk;
+            const size_t chunk_g = g < 2 && cw == 1 ? chunk / 4 : chunk;
             const uint64_t rows_per_chunk = std::max<uint64_t>(256, (chunk_g / ((size_t)cw * 32)) & ~(uint64_t)255);
             const uint64_t block_rows = std::max<uint64_t>(256, (256u << 10) / ((size_t)cw * 32)) & ~(uint64_t)63;   // ~256 KB written per block
             for (uint64_t r0 = 0; r0 < n_; r0 += rows_per_chunk) {
                 const uint64_t rows = std::min<uint64_t>(rows_per_chunk, n_ - r0);
                 const uint64_t blocks = (rows + block_rows - 1) / block_rows;
-                const bool packed = c + cw <= binary_cols;
+                const bool packed = c + cw <= binary_cols && c >= c_begin;
                 dma_bytes += packed ? (uint64_t)cw * rows / 8 : (uint64_t)cw * rows * 32;
                 chunks.push_back(Chunk{g, c, cw, (uint32_t)(chunks.size() % UPLOAD_SLOTS), r0, rows, n_blocks, blocks, r0 + rows >= n_, packed});
                 n_blocks += blocks;
@@ -536,7 +566,9 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                         // interpolate_fft + evaluate_offset_fft of this group (reference trace.rs:104-110, prover.rs:161-185)
                         SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(coeffs + (uint64_t)gc0 * n_, (int)logn_, w, n_, d_t1_, trace + (uint64_t)gc0 * n_));
                         SP_TRY(c_->ntt->lde_coset_major(coeffs + (uint64_t)gc0 * n_, lde + (uint64_t)gc0 * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, 0, 0));
-                        if (segment == 0) SP_TRY(maybe_leaf_head(cols, gc0 + w, lde));
+                        for (uint32_t j = 0; j < w; ++j) extended[gc0 - c_begin + j] = 1;
+                        while (extended_prefix < cols && extended[extended_prefix]) ++extended_prefix;
+                        if (segment == 0) SP_TRY(maybe_leaf_head(cols, extended_prefix, lde));
                     }
                     SP_HIP_CHECK(hipEventRecord(up_ev_[g].done, c_->stream));
                 }
