@@ -1,6 +1,7 @@
 // C ABI: round-level prover entry points and the whole-proof call. See include/stark252_hip.h.
 #include "prover.h"
 #include "cairo_host.h"
+#include "prover_internal.h"
 #include <cstdlib>
 #include <cstring>
 
@@ -47,24 +48,42 @@ static int warm_small_proofs(sp_ctx* c, const ProofOptionsHost& o) {
         const uint32_t cols = (uint32_t)T.n_cols;
         std::vector<uint8_t> bytes;
         float ms[5];
+        // Three of the four input forms only as far as their commitment (round 1 of the main trace: what differs between them);
+        // the fourth as a whole proof.
+        CairoAirInfo air = cairo_air_info(pub);
+        auto commit_only = [&](const uint8_t* p, StarkProver::TraceSource src, int col_enc, uint64_t col_stride) -> int {
+            StarkProver* P = &prover_holder(c, true)->prover;
+            SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, o));
+            uint8_t root[32];
+            return P->commit_trace(0, p, cols, root, src, col_enc, col_stride);
+        };
         // (1) host columns in the device layout: DMA per column group on the copy stream
-        SP_TRY(cairo_prove(c, reinterpret_cast<const uint8_t*>(T.data), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_COLUMNS, -1, n));
+        SP_TRY(commit_only(reinterpret_cast<const uint8_t*>(T.data), StarkProver::TRACE_HOST_COLUMNS, -1, n));
         // (2) host columns in the context encoding: the in-place decode in front of the transforms (what the row-major pipeline runs too)
-        std::vector<uint8_t> enc_cols((size_t)n * cols * 32);
-        SP_TRY(sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(T.data), n * cols, enc_cols.data()));
-        SP_TRY(cairo_prove(c, enc_cols.data(), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_COLUMNS, c->enc, n));
+        // (the two tables below in page-locked memory: a pageable buffer of this size is registered with the driver for the copy, and
+        // giving it back to the system afterwards - the first munmap of a process - evicts the process' queues: the next launch
+        // waited 20 - 28 ms, tools/prewarm_split.py)
+        struct Pinned {
+            uint8_t* p = nullptr;
+            explicit Pinned(size_t bytes) { if (hipHostMalloc(reinterpret_cast<void**>(&p), bytes, hipHostMallocDefault) != hipSuccess) { p = nullptr; (void)hipGetLastError(); } }
+            ~Pinned() { if (p) (void)hipHostFree(p); }
+        };
+        Pinned enc_cols((size_t)n * cols * 32), rows((size_t)n * cols * 32);
+        if (!enc_cols.p || !rows.p) { sp_set_error("sp_prewarm: page-locked allocation failed"); return SP_E_ALLOC; }
+        SP_TRY(sp_fe_from_device(c->enc, reinterpret_cast<const uint8_t*>(T.data), n * cols, enc_cols.p));
+        SP_TRY(commit_only(enc_cols.p, StarkProver::TRACE_HOST_COLUMNS, c->enc, n));
         // (3) a row-major table (below the pipeline's threshold: one copy + rows -> columns, the kernel of sp_cairo_prove_dev)
-        std::vector<uint8_t> rows((size_t)n * cols * 32);
         for (uint64_t i = 0; i < n; ++i)
-            for (uint32_t j = 0; j < cols; ++j) std::memcpy(&rows[(i * cols + j) * 32], &enc_cols[((size_t)j * n + i) * 32], 32);
-        SP_TRY(cairo_prove(c, rows.data(), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_ROWS));
+            for (uint32_t j = 0; j < cols; ++j) std::memcpy(&rows.p[(i * cols + j) * 32], &enc_cols.p[((size_t)j * n + i) * 32], 32);
+        SP_TRY(commit_only(rows.p, StarkProver::TRACE_HOST_ROWS, 0, 0));
         // (4) the run itself: register states + memory up, the table written by the device (sp_cairo_prove_run's default)
         TraceImage image;
         image.build(regs, mem, plan);
         if (image.base) {
             StarkProver::TraceBuildInput in{&plan, &image};
             SP_TRY(cairo_prove(c, reinterpret_cast<const uint8_t*>(&in), n, cols, pub, o, bytes, ms, StarkProver::TRACE_DEVICE_BUILD));
-        }
+        } else
+            SP_TRY(cairo_prove(c, reinterpret_cast<const uint8_t*>(T.data), n, cols, pub, o, bytes, ms, StarkProver::TRACE_HOST_COLUMNS, -1, n));
         return SP_OK;
     } catch (const std::exception& e) { sp_set_error(std::string("sp_prewarm: ") + e.what()); return SP_E_INVALID_ARG; }
 }
@@ -75,16 +94,25 @@ int sp_prewarm(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int
     ProverHolder* h = holder(c, true);
     ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
     // the shape first: ONE arena allocation of the real size (the small proofs below are carved out of it, nothing is re-allocated)
+    sp_ctx* ctx = c;
+    double _tp = wall_ms();
     SP_TRY(h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o));
+    SP_TIMEPOINT("prewarm: setup");
+    // (the page-locked ring and its parked threads on a thread of their own, beside the launches below, made the prewarm 10 ms shorter
+    // when nothing else ran and the first proof from a row-major table 4 - 14 ms slower in three runs of three: inline it is)
     SP_TRY(h->prover.warm_plumbing((flags & SP_PREWARM_HOST_ROWS) != 0));
+    SP_TIMEPOINT("prewarm: streams, events, ring");
     if (flags & SP_PREWARM_KERNELS) {
         ProofOptionsHost small = o;
         small.fri_number_of_queries = std::min<uint64_t>(std::max<uint64_t>(o.fri_number_of_queries, 1), 64);
         small.grinding_factor = std::min<uint8_t>(o.grinding_factor, 16);
         SP_TRY(warm_small_proofs(c, small));
+        SP_TIMEPOINT("prewarm: small proofs");
         SP_TRY(h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o));
+        SP_TIMEPOINT("prewarm: setup again");
     }
     if (flags & SP_PREWARM_CLOCKS) SP_TRY(h->prover.warm_round1());
+    SP_TIMEPOINT("prewarm: round 1 at the real shape");
     return SP_OK;
 }
 

@@ -262,7 +262,6 @@ int StarkProver::warm_plumbing(bool host_rows) {
     if (host_rows) SP_TRY(ensure_ring_and_pool());
     return SP_OK;
 }
-
 // sp_prewarm, second half: round 1's kernel sequence at the REAL shape on whatever the arena holds (the transforms have no
 // data-dependent control flow and accept any 256-bit operand; the hash kernels convert and absorb whatever they read) - the
 // size-specific kernel variants take their first launch here, and the device reaches its clocks before the trace exists.
