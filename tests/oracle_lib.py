@@ -35,9 +35,31 @@ def build():
     subprocess.check_call(["make", "-s", "-C", ORACLE_DIR])
 
 
+def usable_cpus():
+    """CPUs this process can really have: the affinity mask cut down by the cgroup's CPU quota (the GPU boxes give a container
+    16 CPUs' worth of time on a 256-thread host; an OpenMP team of 256 spinning threads there makes a 128-row proof take 5 s)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def load():
     global _lib
     if _lib is None:
+        # the oracle's OpenMP team: no larger than the CPUs there are, and sleeping rather than spinning between parallel regions
+        os.environ.setdefault("OMP_NUM_THREADS", str(usable_cpus()))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         if not os.path.exists(LIB_PATH):
             build()
         try:
@@ -45,6 +67,11 @@ def load():
         except OSError:
             build()
             _lib = ctypes.CDLL(LIB_PATH)
+        if "SP_ORACLE_THREADS_SET" not in os.environ:          # (libgomp may have been loaded - by torch - before the defaults above were set)
+            try:
+                ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(os.environ.get("OMP_NUM_THREADS", "0")) or usable_cpus())
+            except (OSError, ValueError):
+                pass
         _lib.oracle_grinding_nonce.restype = ctypes.c_uint64
         _lib.oracle_transcript_new.restype = ctypes.c_void_p
         _lib.oracle_transcript_to_usize.restype = ctypes.c_uint64

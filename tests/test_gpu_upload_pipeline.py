@@ -26,10 +26,14 @@ from lambdaworks_cairo_prover_amd import api
 from test_rc_builtin import run_of
 out = []
 def case(name, ctx, trace, pub, options, expect_kind="row-major host buffer, gathered by host threads"):
+    import time
+    t0 = time.perf_counter()
     want = oracle.cairo_prove(trace, pub, options)
+    t1 = time.perf_counter()
     got = ctx.cairo_prove(trace, pub, api.ProofOptions(*options))
+    t2 = time.perf_counter()
     st = ctx.last_upload_stats()
-    out.append({"case": name, "same_bytes": got == want, "kind": st["kind"], "kind_ok": st["kind"] == expect_kind, "groups": st["groups"], "bytes": st["bytes"]})
+    out.append({"case": name, "oracle_s": round(t1 - t0, 2), "device_s": round(t2 - t1, 2), "same_bytes": got == want, "kind": st["kind"], "kind_ok": st["kind"] == expect_kind, "groups": st["groups"], "bytes": st["bytes"]})
 with api.Context(device=0) as ctx:
     for fib, options in ((100, (4, 3, 3, 1)), (10, (2, 3, 3, 1)), (3, (4, 3, 3, 1)), (300, (8, 5, 3, 2)), (4000, (2, 3, 3, 1))):      # fib(3): 64 rows; fib(4000): 2^15 rows, several chunks a group at SP_UPLOAD_CHUNK_MB=1
         run = api.CairoRun.fibonacci(fib)
