@@ -277,6 +277,7 @@ def cold_child(args):
         run = api.CairoRun.fibonacci(fib)
         t_run = (time.perf_counter() - t0) * 1e3
         trace = run.main_trace() if rows else None        # (the caller's row-major table exists before the proof call, like the run)
+        ctx.prewarm_cancel()                              # the trace exists: whatever is left of the clock ramp is cut short
         th.join()
         t_both = (time.perf_counter() - t0) * 1e3
         t_setup = box.get("ms")

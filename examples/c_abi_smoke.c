@@ -39,7 +39,8 @@ int main(void) {
     rc = sp_cairo_run_fibonacci(100, &run);          /* 709 steps -> 2^10 rows x 34 columns */
     uint64_t rows = 0, steps = 0; uint32_t cols = 0;
     if (rc == 0) rc = sp_cairo_run_shape(run, &rows, &cols, &steps);
-    if (rc == 0) rc = sp_prewarm(ctx, rows, cols, 18, 0, &opt, 0);            /* optional: a caller does this beside its VM */
+    if (rc == 0) rc = sp_prewarm_cancel(ctx);                                 /* the trace already exists here: no clock ramp (a caller with a VM to run calls this when the VM is done) */
+    if (rc == 0) rc = sp_prewarm(ctx, rows, cols, 18, 0, &opt, 0);            /* optional: a caller does this on a thread beside its VM */
     uint8_t* proof = NULL; uint64_t proof_len = 0;
     if (rc == 0) rc = sp_cairo_prove_run(ctx, run, &opt, &proof, &proof_len);
     sp_cairo_public_inputs pub;

@@ -174,6 +174,10 @@ class Context:
         check(self._lib.sp_prewarm(self._h, ctypes.c_uint64(n_rows), ctypes.c_uint32(main_cols), ctypes.c_uint32(aux_cols), int(bool(has_rc_builtin)),
                                    ctypes.byref(opt), ctypes.c_uint32(flags)))
 
+    def prewarm_cancel(self):
+        """sp_prewarm_cancel: from any thread - the prewarm running (or about to run) on this context skips the rest of its clock ramp."""
+        check(self._lib.sp_prewarm_cancel(self._h))
+
     def last_upload_stats(self):
         """sp_last_upload_stats of the last proof's main-trace upload."""
         v = (ctypes.c_double * 10)()

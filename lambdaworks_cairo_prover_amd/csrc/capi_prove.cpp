@@ -111,8 +111,16 @@ int sp_prewarm(sp_ctx* c, uint64_t n, uint32_t main_cols, uint32_t aux_cols, int
         SP_TRY(h->prover.setup(n, main_cols, aux_cols, has_rc != 0, o));
         SP_TIMEPOINT("prewarm: setup again");
     }
-    if (flags & SP_PREWARM_CLOCKS) SP_TRY(h->prover.warm_round1());
+    int rc = SP_OK;
+    if (flags & SP_PREWARM_CLOCKS) rc = h->prover.warm_round1();
     SP_TIMEPOINT("prewarm: round 1 at the real shape");
+    c->prewarm_cancel.store(0, std::memory_order_release);      // (a request is spent on the call it reaches)
+    return rc;
+}
+
+int sp_prewarm_cancel(sp_ctx* c) {
+    if (!c) return SP_E_INVALID_ARG;
+    c->prewarm_cancel.store(1, std::memory_order_release);
     return SP_OK;
 }
 

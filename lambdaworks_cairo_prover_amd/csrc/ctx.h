@@ -1,5 +1,6 @@
 // Context object behind the C ABI (one per proof / per caller thread).
 #pragma once
+#include <atomic>
 #include "common.h"
 #include "ntt.h"
 #include "merkle.h"
@@ -40,6 +41,7 @@ struct sp_ctx {
     uint32_t opt_upload_threads = 24;
     int opt_merkle_backend = SP_MERKLE_KECCAK256;
     bool opt_device_trace = true;             // sp_cairo_prove_run builds the main trace on the device from the run's registers and memory
+    std::atomic<int> prewarm_cancel{0};       // sp_prewarm_cancel: a running (or coming) sp_prewarm cuts its clock ramp short
     bool opt_merkle_one_column_rows = false;   // sp_merkle_build* with fe_per_leaf == 1 under Poseidon: row tree instead of the FRI-layer tree
     sp_deletable* comm_holder = nullptr;  // RCCL communicator when sp_comm_init_rccl is used
 };

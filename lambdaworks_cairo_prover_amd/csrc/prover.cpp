@@ -269,18 +269,24 @@ int StarkProver::warm_round1() {
     if (!ready_ || stage_ != 1) return SP_E_STATE;
     SP_HIP_CHECK(hipSetDevice(c_->device));
     SP_HIP_CHECK(hipMemsetAsync(d_trace_, 0, sizeof(fe) * n_ * C_, c_->stream));
-    // A fifth of the columns through the transforms (and the first segment's hashing): the size-specific kernel variants take their
-    // first launch and the clocks start up; the rest of the ramp costs the first proof 1 ms (74.0 - 74.7 against 72.9 - 74.3 ms at
-    // config #3, 25.3 - 25.6 against 25.0 - 25.6 at config #4) and the whole of round 1 here cost 35 / 12 ms more, which a short
-    // front-end run does not cover (tools/experiments/ab_prewarm_r1.sh; SP_PREWARM_R1_FRAC overrides).
-    static const double frac = [] { const char* e = std::getenv("SP_PREWARM_R1_FRAC"); return e ? std::min(1.0, std::max(0.0, std::atof(e))) : 0.2; }();
-    for (int seg = 0; seg < 2; ++seg) {
+    // Column slice by column slice, with a look at sp_prewarm_cancel's flag between slices: a caller whose trace is ready does not wait
+    // for the rest of the ramp.  The whole of it costs 15 ms at config #4's shape and 50 ms at config #3's and makes the first proof
+    // 1 - 2 ms faster than a fifth of it does (tools/experiments/ab_prewarm_r1.sh; SP_PREWARM_R1_FRAC bounds it for experiments).
+    static const double frac = [] { const char* e = std::getenv("SP_PREWARM_R1_FRAC"); return e ? std::min(1.0, std::max(0.0, std::atof(e))) : 1.0; }();
+    auto cancelled = [this] { return c_->prewarm_cancel.load(std::memory_order_acquire) != 0; };
+    bool stop = false;
+    for (int seg = 0; seg < 2 && !stop; ++seg) {
         const uint32_t col0 = seg ? Cm_ : 0, cols = seg ? Ca_ : Cm_;
         if (!cols) continue;
-        const uint32_t tc = std::max<uint32_t>(1, (uint32_t)(cols * frac));
-        SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(d_coeffs_ + (uint64_t)col0 * n_, (int)logn_, tc, n_, d_t1_, d_trace_ + (uint64_t)col0 * n_));
-        SP_TRY(c_->ntt->lde_coset_major(d_coeffs_ + (uint64_t)col0 * n_, d_lde_ + (uint64_t)col0 * Nl_, (int)logn_, (int)logb_, tc, n_, Nl_, (int)logG_, (int)rank_));
-        if (frac < 0.5 && seg == 1) continue;
+        const uint32_t tc = std::max<uint32_t>(1, (uint32_t)(cols * frac)), slice = std::max<uint32_t>(1, cols / 8);
+        for (uint32_t c0 = 0; c0 < tc && !stop; c0 += slice) {
+            const uint32_t w = std::min(slice, tc - c0);
+            SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(d_coeffs_ + (uint64_t)(col0 + c0) * n_, (int)logn_, w, n_, d_t1_, d_trace_ + (uint64_t)(col0 + c0) * n_));
+            SP_TRY(c_->ntt->lde_coset_major(d_coeffs_ + (uint64_t)(col0 + c0) * n_, d_lde_ + (uint64_t)(col0 + c0) * Nl_, (int)logn_, (int)logb_, w, n_, Nl_, (int)logG_, (int)rank_));
+            SP_TRY(wait_stream());
+            stop = cancelled();
+        }
+        if (stop || tc < cols) break;
         TreeBuf& t = seg ? tree_aux_ : tree_main_;
         const MerkleHash mh = merkle_hash(false);
         if (t.top == t.sub) {
@@ -290,6 +296,8 @@ int StarkProver::warm_round1() {
             SP_TRY(merkle_hash_leaves_flat(c_->stream, d_lde_ + (uint64_t)col0 * Nl_, Nl_, cols, Nl_, reinterpret_cast<digest32*>(d_local_), lde_order(), mh));
             SP_TRY(merkle_reduce(c_->stream, t.sub, t.sub_leaves, nullptr, mh));
         }
+        SP_TRY(wait_stream());
+        stop = cancelled();
     }
     // the composition columns' shape too: two columns, the 2n-point inverse transform
     SP_TRY(c_->ntt->dif_natural_to_bitrev_inverse(d_h12s_, (int)logn_ + 1, 1, 2 * n_, d_post_comp_));

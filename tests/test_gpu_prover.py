@@ -243,6 +243,38 @@ def test_prewarm_then_prove_gives_the_same_bytes(hip_lib, oracle):
         assert ctx.cairo_prove_run(tiny, api.ProofOptions(2, 3, 3, 1)) == oracle.cairo_prove(tiny.main_trace(), tiny.public_inputs_c, (2, 3, 3, 1))
 
 
+def test_prewarm_cancelled_from_another_thread(hip_lib, oracle):
+    """sp_prewarm_cancel: the prewarm of the reference's one-proof-per-process shape runs on a thread beside the VM and is told to stop
+    its clock ramp when the trace exists - at whatever point that reaches it (before it starts, in the middle, after it has returned),
+    the proof that follows is the oracle's, and a request is spent on the call it reaches (the next prewarm ramps in full again)."""
+    import threading
+    import time
+    opts = (8, 5, 3, 4)
+    opt = api.ProofOptions(*opts)
+    run = api.CairoRun.fibonacci(9000)           # 2^16 rows x blowup 8: a ramp of several slices
+    want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, opts)
+    for delay_ms in (None, 0.0, 30.0, 60.0, 400.0):
+        with api.Context(device=0) as ctx:
+            if delay_ms is None:
+                ctx.prewarm_cancel()             # before the prewarm exists: it reaches the next one
+            th = threading.Thread(target=lambda: ctx.prewarm(run.n_rows, 34, 18, False, opt))
+            th.start()
+            if delay_ms is not None:
+                time.sleep(delay_ms * 1e-3)
+                ctx.prewarm_cancel()
+            th.join()
+            assert ctx.cairo_prove_run(run, opt) == want
+            t0 = time.perf_counter()
+            ctx.prewarm(run.n_rows, 34, 18, False, opt, api.SP_PREWARM_CLOCKS)
+            full = time.perf_counter() - t0
+            ctx.prewarm_cancel()
+            t0 = time.perf_counter()
+            ctx.prewarm(run.n_rows, 34, 18, False, opt, api.SP_PREWARM_CLOCKS)
+            cut = time.perf_counter() - t0
+            assert cut < 1.2 * full + 0.002, (cut, full)       # one slice of the transforms instead of both segments and their hashing
+            assert ctx.cairo_prove_run(run, opt) == want
+
+
 def test_row_major_upload_with_flag_cells_that_are_not_bits(hip_ctx, oracle):
     """The row-major upload sends the sixteen flag columns as bitmaps; a table whose flag cells are not all 0 / 1 (an invalid trace,
     which the reference still proves) is detected by the gather threads and uploaded again in full: the oracle's bytes either way."""
