@@ -254,8 +254,10 @@ def cold_child(args):
     t_imp = (time.perf_counter() - t_imp) * 1e3
     fib, blowup = args.cold_shape
     opt = api.ProofOptions(blowup, 80, 3, 20)
+    t_start = time.perf_counter()                # the one-shot wall clock: from here to the first proof's bytes
+    ctx_on_thread = "+ctx" in args.cold_path     # 'run+ctx+prewarm': sp_ctx_create on the pre-warm's thread too, beside the VM
     t0 = time.perf_counter()
-    ctx = api.Context()
+    ctx = None if ctx_on_thread else api.Context()
     t_ctx = (time.perf_counter() - t0) * 1e3
     t_setup = None
     rows = args.cold_path.startswith("rows")
@@ -266,9 +268,18 @@ def cold_child(args):
         n_rows = 1 << (7 * fib + 9).bit_length()   # 7 fib + 9 steps and a little padding: 2^20 for 149000, 2^19 for 70000
         box = {}
 
+        box["cancel"] = False
+
         def warm():
             t = time.perf_counter()
-            ctx.prewarm(n_rows, 34, 18, False, opt, api.SP_PREWARM_ALL if rows else (api.SP_PREWARM_KERNELS | api.SP_PREWARM_CLOCKS))
+            if ctx_on_thread:
+                box["ctx"] = api.Context()
+                box["ctx_ms"] = (time.perf_counter() - t) * 1e3
+                if box["cancel"]:                         # (the VM was done before the context existed)
+                    box["ctx"].prewarm_cancel()
+            c = box["ctx"] if ctx_on_thread else ctx
+            t = time.perf_counter()
+            c.prewarm(n_rows, 34, 18, False, opt, api.SP_PREWARM_ALL if rows else (api.SP_PREWARM_KERNELS | api.SP_PREWARM_CLOCKS))
             box["ms"] = (time.perf_counter() - t) * 1e3
 
         th = threading.Thread(target=warm)
@@ -277,8 +288,13 @@ def cold_child(args):
         run = api.CairoRun.fibonacci(fib)
         t_run = (time.perf_counter() - t0) * 1e3
         trace = run.main_trace() if rows else None        # (the caller's row-major table exists before the proof call, like the run)
-        ctx.prewarm_cancel()                              # the trace exists: whatever is left of the clock ramp is cut short
+        box["cancel"] = True
+        c = box.get("ctx") if ctx_on_thread else ctx
+        if c is not None:
+            c.prewarm_cancel()                            # the trace exists: whatever is left of the clock ramp is cut short
         th.join()
+        if ctx_on_thread:
+            ctx, t_ctx = box["ctx"], box.get("ctx_ms")
         t_both = (time.perf_counter() - t0) * 1e3
         t_setup = box.get("ms")
     else:
@@ -288,14 +304,17 @@ def cold_child(args):
         t_run = (time.perf_counter() - t0) * 1e3
         trace = run.main_trace() if rows else None
     ms = []
+    t_one_shot = None
     for _ in range(4):
         t0 = time.perf_counter()
         proof = ctx.cairo_prove(trace, run.public_inputs_c, opt) if rows else ctx.cairo_prove_run(run, opt)
         ms.append((time.perf_counter() - t0) * 1e3)
+        if t_one_shot is None:
+            t_one_shot = (time.perf_counter() - t_start) * 1e3
     ms = [ms[0], ms[1], min(ms[2:])]
     with open(args.cold_child, "w") as f:
         json.dump({"first_call_ms": ms[0], "second_call_ms": ms[1], "third_call_ms": ms[2], "context_create_ms": t_ctx, "prewarm_ms": t_setup,
-                   "front_end_and_prewarm_ms": t_both,
+                   "front_end_and_prewarm_ms": t_both, "context_to_first_proof_ms": t_one_shot,
                    "trace_rows": run.n_rows, "front_end_run_ms": t_run, "front_end_split": run.timings(), "import_torch_and_library_ms": t_imp,
                    "proof_sha256": hashlib.sha256(proof).hexdigest()}, f)
     ctx.close()
@@ -493,7 +512,9 @@ def compact_line(full):
              "resident_ms": _med_min(p.get("proof_gen_ms_all")), "from_rows_ms": _med_min(p.get("proof_gen_ms_from_host_buffer_all")),
              "from_run_ms": _med_min(p.get("proof_gen_ms_from_run_all")), "from_run_host_table_ms": _med_min(p.get("proof_gen_ms_from_run_host_table_all")),
              "first_call_ms": _r(p.get("first_call_ms")), "prewarmed_first_call_ms": _r(p.get("prewarmed_first_call_ms")),
-             "warm_same_child_ms": _r(p.get("prewarmed_child_warm_ms")), "sha": (p.get("proof_sha256") or "")[:8]}
+             "warm_same_child_ms": _r(p.get("prewarmed_child_warm_ms")),
+             "one_shot_ms": [_r(x, 0) for x in p["one_shot_ms"]] if isinstance(p.get("one_shot_ms"), list) else None,
+             "sha": (p.get("proof_sha256") or "")[:8]}
         summ[name] = {k: v for k, v in s.items() if v is not None}
     if isinstance(cb, dict):
         c4 = cb.get("proof_cfg4")
@@ -937,12 +958,14 @@ def main():
                             out["projected"][key] = {"error": repr(e)}
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
-                        order = ["run", "rows", "run+prewarm", "rows+prewarm"]
+                        order = ["run", "rows", "run+prewarm", "rows+prewarm", "run+ctx+prewarm"]
                         runs = {path: dict(cold_start(args, fib, blowup, path), path=path) for path in order}
                         out[key]["first_call_ms"] = runs["rows"].get("first_call_ms")
                         pw = runs["run+prewarm"]
                         out[key]["prewarmed_first_call_ms"] = pw.get("first_call_ms")
                         out[key]["prewarmed_child_warm_ms"] = pw.get("third_call_ms")
+                        # sp_ctx_create -> VM -> first proof's bytes: everything in sequence / pre-warm beside the VM / context and pre-warm beside the VM
+                        out[key]["one_shot_ms"] = [runs[p].get("context_to_first_proof_ms") for p in ("run", "run+prewarm", "run+ctx+prewarm")]
                         out[key]["first_call"] = dict(runs, note=(
                             "fresh child processes, one entry point each (rows: sp_cairo_prove on a pageable row-major table, run: "
                             "sp_cairo_prove_run); '+prewarm': sp_prewarm on a thread of its own while the front-end runs the program, then "
