@@ -93,3 +93,71 @@ def holes_program():
     main += [word(OP0_FP | OP1_IMM | PC_JNZ, -62, -1, 1), 2]                     # jmp rel 2 if [ap - 62] != 0  ([ap-62] = 0: not taken)
     main += ret()
     return main, 1
+
+
+def random_program(seed, length=40):
+    """A random hint-free, builtin-free program: pushes of immediates (0, 1, small, near p), sums and products of earlier cells
+    (ap-based op0 / op1 and immediates), `ap += k` (memory holes; far offsets make range-check holes), taken and not-taken forward
+    `jnz`s over words that are never executed, and calls of a two-instruction function.  The generator tracks ap and every value it
+    wrote, so it knows which way each jump goes and what the following offsets mean.  Returns (words, entry_pc)."""
+    import random
+    rng = random.Random(seed)
+    func = push_fp_plus(-3, 7) + [word(OP1_AP | RES_MUL | AP_ADD1 | ASSERT, 0, -1, -1)] + ret()   # f(x): [ap] = x + 7; [ap] = [ap-1]^2; ret
+    func_at = 1
+    main_at = func_at + len(func)
+    main = []
+    cells = []                                     # values at fp + 0 .. (cells[i] is None for a cell the run never writes)
+
+    def val(back):
+        return cells[len(cells) - back]
+
+    def usable(limit=100):
+        return [b for b in range(1, min(limit, len(cells)) + 1) if isinstance(val(b), int)]
+
+    def pick_imm():
+        return rng.choice([0, 1, 2, rng.randrange(1 << 16), rng.randrange(P), P - 1, P - rng.randrange(1, 1 << 20)])
+
+    main += push_imm(rng.randrange(1, 1 << 30)); cells.append(main[-1])
+    main += push_imm(rng.randrange(P)); cells.append(main[-1])
+    for _ in range(length):
+        kind = rng.choice(["imm", "add", "mul", "addi", "muli", "hole", "jnz", "call", "add", "mul"])
+        u = usable()
+        if kind == "imm" or not u:
+            v = pick_imm()
+            main += push_imm(v); cells.append(v % P)
+        elif kind in ("add", "mul"):
+            i, j = rng.choice(u), rng.choice(u)
+            main += [word(OP1_AP | (RES_ADD if kind == "add" else RES_MUL) | AP_ADD1 | ASSERT, 0, -i, -j)]
+            cells.append((val(i) + val(j)) % P if kind == "add" else (val(i) * val(j)) % P)
+        elif kind in ("addi", "muli"):
+            i, v = rng.choice(u), pick_imm()
+            main += [word(OP1_IMM | (RES_ADD if kind == "addi" else RES_MUL) | AP_ADD1 | ASSERT, 0, -i, 1), v % P]
+            cells.append((val(i) + v) % P if kind == "addi" else (val(i) * v) % P)
+        elif kind == "hole":
+            i, k = rng.choice(u), rng.choice([1, 2, 3, 17, 60])
+            main += [word(OP1_IMM | AP_ADD, -i, -i, 1), k]                     # ap += k  (dst and op0: a cell that exists)
+            cells.extend([None] * k)
+        elif kind == "jnz":
+            if not isinstance(val(1), int):                                    # (the fall-through doubles [ap - 1]: it has to be a value)
+                continue
+            i, j = rng.choice(u), rng.choice(u)
+            skipped = rng.randrange(1, 4)
+            main += [word(OP1_IMM | PC_JNZ, -i, -j, 1), 2 + skipped]           # jmp rel 2 + skipped if [ap - i] != 0
+            junk = [word(OP1_AP | RES_ADD | AP_ADD1 | ASSERT, 0, -1, -1)] * skipped
+            if val(i) != 0:
+                main += junk                                                   # jumped over: never executed
+            else:
+                main += junk                                                   # not taken: these DO run ([ap] = 2 [ap-1], skipped times)
+                for _ in range(skipped):
+                    cells.append((2 * val(1)) % P)
+        elif kind == "call":
+            i = rng.choice(u)
+            main += [word(OP1_AP | AP_ADD1 | ASSERT, 0, -i, -i)]               # [ap] = [ap - i] (the argument; op0 is read and not used)
+            x = val(i); cells.append(x)
+            here = main_at + len(main)
+            main += call_rel(func_at - here)
+            cells.extend(["fp", "pc"])                                         # the frame: caller's fp, return pc (never used as operands below)
+            y = (x + 7) % P
+            cells.extend([y, (y * y) % P])
+    main += ret()
+    return func + main, main_at
