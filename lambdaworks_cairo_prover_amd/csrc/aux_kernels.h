@@ -34,13 +34,15 @@ void aux_workspace_carve(AuxWorkspace& w, void* base, uint64_t n, uint64_t pm_ca
 // off_dst, off_op0, off_op1), column k at mem_cols + k*n.  pm_addr_host/pm_val_host: the public-memory (address, value)
 // list in the order of get_pub_memory_addrs (air.rs:500-517).  rap = alpha_memory, z_memory, z_range_check.
 // aux_cols_out: 18 natural-order columns at stride n (sorted offsets 0-2, sorted addresses 3-6, sorted values 7-10,
-// memory permutation 11-14, range-check permutation 15-17).  *flag_dev is set on malformed input (address >= 2^64,
-// offset >= 2^16, zero denominator).
+// memory permutation 11-14, range-check permutation 15-17).  *flag_dev: 1 = a zero permutation denominator (the reference's batch
+// inversion fails there too), 2 = an address beyond 2^64 met by the 64-bit sort - the caller repeats the call with all_limbs = true
+// (four stable 64-bit sorts, least significant limb first: the reference's stable sort by the 256-bit value, air.rs:519-523).
+// Offsets enter the range-check sort as their low 16 bits whatever the cell holds (air.rs:689-692).
 // side / ev_fork / ev_join: when side is not null the range-check half (sort of the offsets, its table of inverses, its prefix
 // product) is queued there - two chains of dependent latencies (a batch inversion each) side by side instead of in a row.
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
                            uint64_t pm, const fe rap[3], fe* aux_cols_out, int* flag_dev, hipStream_t side = nullptr,
-                           hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr, bool presorted = false);
+                           hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr, bool presorted = false, bool all_limbs = false);
 
 // The part of the auxiliary trace that needs no challenge, for a stream of its own while round 1 extends and hashes the main
 // trace: public-memory substitution, the stable sort of the 4n accesses by address with the gather of the sorted (address,

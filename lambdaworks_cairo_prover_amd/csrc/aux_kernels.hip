@@ -25,7 +25,7 @@ struct AuxConsts { fe z, alpha, zrc; };
 // ---- memory part -------------------------------------------------------------------------------------------
 // keys / sorted pairs first (they need no challenge: cairo_aux_presort), numerators and denominators once alpha and z are known
 __global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint64_t n, const fe* pm_addr, const fe* pm_val, uint64_t pm,
-                                                       fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag, uint32_t key_bits, int* wide_flag) {
+                                                       fe* a_aux, fe* v_aux, uint64_t* keys, uint32_t* idx, int* flag, uint32_t key_bits, int* wide_flag, int all_limbs) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= 4 * n) return;
     uint64_t i = e >> 2; uint32_t k = (uint32_t)e & 3;
@@ -39,11 +39,22 @@ __global__ void __launch_bounds__(256) aux_keys_kernel(const fe* mem_cols, uint6
     }
     ax_st(a_aux + e, a); ax_st(v_aux + e, v);
     fe raw = fe_from_mont(a);
-    if (raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 2);
+    // an address beyond 2^64 (no Cairo VM produces one; the reference sorts whatever the table holds by its 256-bit value,
+    // air.rs:519-523): flag 2 sends the caller to the four-limb sort below, which passes all_limbs = 1
+    if (!all_limbs && (raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7])) atomicExch(flag, 2);
     const uint64_t key = (uint64_t)raw.v[0] | ((uint64_t)raw.v[1] << 32);
     if (key_bits < 64 && (key >> key_bits)) atomicExch(wide_flag, 1);   // beyond the bits the presort looks at: the caller sorts again, all 64
     keys[e] = key;
     idx[e] = (uint32_t)e;
+}
+// limb `limb` (64 bits) of the addresses in the order the sort has reached so far: the next key of the four-limb LSD sort
+__global__ void __launch_bounds__(256) aux_limb_keys_kernel(const fe* a_aux, const uint32_t* order, uint64_t M, uint32_t limb, uint64_t* keys, uint32_t* idx) {
+    uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= M) return;
+    const uint32_t s = order[e];
+    const fe raw = fe_from_mont(ax_ld(a_aux + s));
+    keys[e] = (uint64_t)raw.v[2 * limb] | ((uint64_t)raw.v[2 * limb + 1] << 32);
+    idx[e] = s;
 }
 __global__ void __launch_bounds__(256) aux_gather_pairs_kernel(const fe* a_aux, const fe* v_aux, const uint32_t* idx, uint64_t M, fe* a_s, fe* v_s) {
     uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
@@ -151,8 +162,8 @@ __global__ void __launch_bounds__(256) rc_keys_kernel(const fe* off_cols, uint64
     if (e >= 3 * n) return;
     uint64_t i = e / 3; uint32_t k = (uint32_t)(e % 3);
     fe raw = fe_from_mont(ax_ld(off_cols + (uint64_t)k * n + i));
-    if ((raw.v[0] >> 16) | raw.v[1] | raw.v[2] | raw.v[3] | raw.v[4] | raw.v[5] | raw.v[6] | raw.v[7]) atomicExch(flag, 3);
-    keys[e] = (uint16_t)raw.v[0];
+    keys[e] = (uint16_t)raw.v[0];     // the low 16 bits whatever the cell holds, like the reference (air.rs:689-692: `representative().into()` to u16)
+    (void)flag;
 }
 __global__ void __launch_bounds__(256) rc_den_kernel(fe* den, AuxConsts K) {
     uint32_t v = blockIdx.x * 256 + threadIdx.x;
@@ -247,7 +258,7 @@ int cairo_aux_presort(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint6
     uint32_t key_bits = 4;
     while ((1ULL << key_bits) < 8 * n && key_bits < 64) ++key_bits;
     hipLaunchKernelGGL(aux_keys_kernel, blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag,
-                       key_bits, wide_flag);
+                       key_bits, wide_flag, 0);
     SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, key_bits, w.sort_tmp));
     hipLaunchKernelGGL(aux_gather_pairs_kernel, blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
     hipLaunchKernelGGL(rc_keys_kernel, blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
@@ -291,7 +302,7 @@ int cairo_aux_permutation_columns(hipStream_t st, AuxWorkspace& w, uint64_t n, f
 }
 
 int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, uint64_t n, const fe* pm_addr_host, const fe* pm_val_host,
-                           uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool presorted) {
+                           uint64_t pm, const fe rap[3], fe* out, int* flag, hipStream_t side, hipEvent_t ev_fork, hipEvent_t ev_join, bool presorted, bool all_limbs) {
     if (n != w.n || pm > w.pm_cap || pm > 4 * n) { sp_set_error("aux trace: workspace too small"); return SP_E_INVALID_ARG; }
     AuxConsts K; K.alpha = rap[0]; K.z = rap[1]; K.zrc = rap[2];
     const uint64_t M = 4 * n, M3 = 3 * n;
@@ -304,8 +315,15 @@ int cairo_aux_trace_device(hipStream_t st, AuxWorkspace& w, const fe* mem_cols, 
         }
         // memory: substitute, sort (stable, by address); range check: counting sort of the 3n 16-bit offsets
         int* no_wide = nullptr;
-        hipLaunchKernelGGL(aux_keys_kernel, ax_blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag, 64u, no_wide);
+        hipLaunchKernelGGL(aux_keys_kernel, ax_blocks(M), dim3(256), 0, st, mem_cols, n, w.pm_addr, w.pm_val, pm, w.a_aux, w.v_aux, w.keys_in, w.idx_in, flag, 64u, no_wide,
+                           all_limbs ? 1 : 0);
         SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, 64, w.sort_tmp));
+        // 256-bit addresses: three more stable sorts, by the next limb each, of the order reached so far (LSD over four 64-bit digits
+        // = the reference's stable sort by `representative()`)
+        for (uint32_t limb = 1; all_limbs && limb < 4; ++limb) {
+            hipLaunchKernelGGL(aux_limb_keys_kernel, ax_blocks(M), dim3(256), 0, st, w.a_aux, w.idx_out, M, limb, w.keys_in, w.idx_in);
+            SP_TRY(radix_sort_pairs_u64(st, w.keys_in, w.keys_out, w.idx_in, w.idx_out, M, 64, w.sort_tmp));
+        }
         hipLaunchKernelGGL(aux_gather_pairs_kernel, ax_blocks(M), dim3(256), 0, st, w.a_aux, w.v_aux, w.idx_out, M, w.a_s, w.v_s);
         hipLaunchKernelGGL(rc_keys_kernel, ax_blocks(M3), dim3(256), 0, st, mem_cols + 8 * n, n, w.rc_keys, flag);
         SP_TRY(counting_sort_u16(st, w.rc_keys, w.rc_sorted, M3, w.hist));

@@ -794,7 +794,7 @@ int StarkProver::launch_aux_presort() {
     SP_TRY(cairo_aux_presort(side_stream_, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, d_flag_side_ + 2, d_flag_side_ + 3));
     // the "address beyond the key bits" flag travels to the host behind the sorts: commit_aux_cairo reads it without a round trip of its own
     if (!h_wide_ && hipHostMalloc(reinterpret_cast<void**>(&h_wide_), 64, hipHostMallocDefault) != hipSuccess) { h_wide_ = nullptr; sp_set_error("pinned flag slot: allocation failed"); return SP_E_ALLOC; }
-    SP_HIP_CHECK(hipMemcpyAsync(h_wide_, d_flag_side_ + 3, sizeof(int), hipMemcpyDeviceToHost, side_stream_));
+    SP_HIP_CHECK(hipMemcpyAsync(h_wide_, d_flag_side_ + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, side_stream_));   // [0]: malformed-input flag, [1]: key beyond the presort's bits
     SP_HIP_CHECK(hipEventRecord(ev_side_presort_, side_stream_));
     presorted_ = true;
     return SP_OK;
@@ -804,11 +804,12 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     if (stage_ != 2 || Ca_ != 18 || Cm_ < 34) { sp_set_error("commit_aux_cairo: main segment not committed or not a Cairo layout"); return SP_E_STATE; }
     SP_HIP_CHECK(hipSetDevice(c_->device));
     bool pre = presorted_;
+    const bool presort_ran = presorted_;
     presorted_ = false;
     if (pre) {   // an address beyond the key bits the presort looked at (a trace with a discontinuous memory): sort again, all 64 bits
         SP_HIP_CHECK(hipStreamWaitEvent(c_->stream, ev_side_presort_, 0));
         SP_HIP_CHECK(hipEventSynchronize(ev_side_presort_));   // (the sorts ended beside round 1's transforms: no wait in practice)
-        if (*h_wide_) pre = false;
+        if (h_wide_[1] || h_wide_[0] == 2) pre = false;
     }
     else SP_TRY(public_memory_lists(pub));     // (the presort built them from the same public inputs)
     const uint64_t pm = pm_addr_h_.size();
@@ -819,13 +820,21 @@ int StarkProver::commit_aux_cairo(const PublicInputs& pub, const fe rap[3], uint
     SP_TRY(ensure_side());
     fe* aux_out = d_trace_ + (uint64_t)Cm_ * n_;
     int flag = 0, flag_pre = 0;
-    SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, rap, aux_out, c_->d_flag,
-                                  side_stream_, ev_side_fork_, ev_side_aux_, pre));
-    SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    if (pre) SP_HIP_CHECK(hipMemcpyAsync(&flag_pre, d_flag_side_ + 2, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
-    SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // flags
-    if (!flag) flag = flag_pre;
-    if (flag) { sp_set_error("commit_aux_cairo: malformed trace (address >= 2^64, offset >= 2^16 or zero permutation denominator)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
+    // An address beyond 2^64 (no VM writes one, but the reference proves whatever table it is given): the presort has already said so,
+    // or the 64-bit sort below does - then once more with the four-limb sort.
+    bool all_limbs = presort_ran && h_wide_[0] == 2;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        SP_TRY(cairo_aux_trace_device(c_->stream, auxws_, d_memcols_, n_, pm_addr_h_.data(), pm_val_h_.data(), pm, rap, aux_out, c_->d_flag,
+                                      side_stream_, ev_side_fork_, ev_side_aux_, pre, all_limbs));
+        SP_HIP_CHECK(hipMemcpyAsync(&flag, c_->d_flag, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        if (pre) SP_HIP_CHECK(hipMemcpyAsync(&flag_pre, d_flag_side_ + 2, sizeof(int), hipMemcpyDeviceToHost, c_->stream));
+        SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));  // flags
+        if (!flag) flag = flag_pre;
+        if (flag != 2 || all_limbs) break;
+        all_limbs = true; pre = false; flag = flag_pre = 0;
+        SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
+    }
+    if (flag) { sp_set_error("commit_aux_cairo: a permutation denominator of the auxiliary trace is zero (the reference's batch inversion fails on this trace and these challenges too)"); return flag == 1 ? SP_E_ZERO_INVERSE : SP_E_INVALID_ARG; }
     return commit_segment_resident(1, Ca_, root_out);
 }
 
