@@ -36,6 +36,16 @@ def _inputs(case):
         trace = run.main_trace().copy()
         trace[case["row"], case["col"], 31] ^= 1
         return trace, run.public_inputs_c, run
+    if kind == "prog":         # a random hint-free program (cairo_asm.random_program), optionally with one cell replaced
+        import cairo_asm as A
+        import numpy as np
+        words, entry = A.random_program(case["seed"], length=case.get("length", 40))
+        run = api.CairoRun.from_program(words, entry_pc=entry)
+        trace = run.main_trace().copy()
+        if "cell" in case:
+            r, c, v = case["cell"]
+            trace[r % trace.shape[0], c] = np.frombuffer(int(v).to_bytes(32, "big"), dtype=np.uint8)
+        return trace, run.public_inputs_c, run
     import oracle_lib as oracle
     from test_gpu_random_traces import random_trace
     rng = random.Random(case["seed"])
@@ -180,6 +190,29 @@ def test_sharded_proof_bytes_identical(world, case, options, knobs, oracle, hip_
             assert stats["allgather_calls"] >= 2 * (3 + 3)   # two proofs, each segment's coefficients in three or four blocks
         if knobs.get("rows_window"):
             assert stats["upload_kind"].startswith("row-major")   # (the one-copy path reports "single copy")
+
+
+PROG = lambda seed, cell=None, length=40: dict({"kind": "prog", "seed": seed, "length": length}, **({"cell": cell} if cell else {}))   # noqa: E731
+
+
+@pytest.mark.parametrize("world,case,options,knobs", [
+    (2, PROG(301), (4, 3, 3, 1), {"fri_min_log": 5}),                                              # a valid random program
+    (4, PROG(302, length=70), (8, 4, 3, 2), {"fri_min_log": 5, "async": True}),
+    (4, PROG(303, cell=(9, 20, (1 << 200) + 12345)), (4, 3, 3, 1), {"fri_min_log": 5, "async": True}),   # an address beyond 2^64: four-limb sort on every rank
+    (8, PROG(304, cell=(3, 28, (1 << 16) + 3)), (8, 3, 3, 1), {"fri_min_log": 6}),                  # an offset beyond 16 bits: its low 16 bits are sorted
+    (4, PROG(305, cell=(17, 21, 1 << 64)), (4, 3, 3, 1), {"fri_min_log": 5, "rows_window": True}),  # ... through the windowed row-major upload
+])
+def test_sharded_random_programs(world, case, options, knobs, oracle, hip_ctx):
+    """Random programs - valid, and with one address / offset cell outside anything a VM writes - through the sharded prover: every
+    rank gives the oracle's bytes (the auxiliary trace is built whole on every rank, wide-address fallback included)."""
+    trace, pub, keep = _inputs(case)
+    want = oracle.cairo_prove(trace, pub, options)
+    results = _run_world(world, case, options, knobs)
+    for r in range(world):
+        proof, stats = results[r]
+        assert proof == want, (r, proof[:300])
+        assert stats["composition_path"] == (1 if "cell" not in case else stats["composition_path"])
+        assert "cell" not in case or stats["composition_path"] != 1
 
 
 def _rccl_worker(rank, world, port, fib_index, options, q):
