@@ -60,6 +60,9 @@ int oracle_batch_inverse(uint8_t* data, uint64_t n) {
 // coset (nullable): forward -> evaluate on coset*<w> (coefficient k scaled by coset^k first);
 //                   inverse -> interpolate from coset evaluations (coefficient k scaled by coset^-k after).
 int oracle_ntt(uint8_t* data, uint64_t n, int inverse, const uint8_t* coset) {
+    // in place: the caller's buffer holds n elements, and the reference's evaluate_fft answers a length that is not a power of two
+    // with next_power_of_two(n) evaluations (interpolate_fft refuses it)
+    if (n == 0 || (n & (n - 1))) return -1;
     try {
         std::vector<Fp> a = load_felts(data, n);
         if (!inverse) {
@@ -103,6 +106,7 @@ int oracle_ntt_bench(const uint8_t* data, uint64_t n, uint32_t vectors, uint32_t
 
 // `evaluate_polynomial_on_lde_domain` of one column: n coefficients -> n*blowup evaluations on coset*<w_N>
 int oracle_lde(const uint8_t* coeffs, uint64_t n, uint32_t blowup, const uint8_t coset[32], uint8_t* out) {
+    if (n == 0 || (n & (n - 1)) || blowup == 0 || (blowup & (blowup - 1))) return -1;      // (out holds n x blowup elements)
     try {
         std::vector<Fp> a = load_felts(coeffs, n);
         Poly p(a.begin(), a.end()); trim(p);
