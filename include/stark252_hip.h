@@ -41,7 +41,7 @@ typedef enum { SP_FE_MONT_LIMBS = 0, SP_FE_CANON_BE = 1 } sp_fe_encoding;
 
 /* ProofOptions — reference src/starks/proof/options.rs:21-26 */
 typedef struct {
-    uint8_t blowup_factor;
+    uint8_t blowup_factor;            /* a power of two, 2 .. 128 (the reference's u8); n x blowup <= 2^30 */
     uint64_t fri_number_of_queries;
     uint64_t coset_offset;
     uint8_t grinding_factor;

@@ -106,7 +106,7 @@ int StarkProver::setup(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool h
 int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, bool has_rc, const ProofOptionsHost& opt) {
     offsets_ = {0, 1};
     int k = sp_log2_exact(n), lb = sp_log2_exact(opt.blowup_factor);
-    if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2..32)"); return SP_E_INVALID_ARG; }
+    if (k < 1 || lb < 1 || k + lb > 30 || (1u << lb) > CAIRO_MAX_BLOWUP) { sp_set_error("setup: trace length and blowup factor must be powers of two (blowup 2 .. 128, at most 2^30 LDE points)"); return SP_E_INVALID_ARG; }
     if (main_cols + aux_cols > 64) return SP_E_INVALID_ARG;
     SP_HIP_CHECK(hipSetDevice(c_->device));
     if (c_->world < 1 || (c_->world & (c_->world - 1)) || c_->rank < 0 || c_->rank >= c_->world) {
@@ -850,7 +850,7 @@ int StarkProver::composition_precheck(const fe rap[3], const std::vector<Boundar
     if (!d_comp_consts_chk_) SP_TRY(alloc((void**)&d_comp_consts_chk_, sizeof(CompositionConsts)));
     if (!h_comp_chk_) h_comp_chk_.reset(new CompositionConsts());
     CompositionConsts& K = *h_comp_chk_;
-    std::memset(&K, 0, sizeof(K));
+    std::memset(&K, 0, composition_consts_bytes(1u << logb_));   // (the per-coset tables only as far as this proof's blowup factor reaches)
     for (uint32_t j = 0; j < B; ++j) {
         if (bcs[j].col >= C_) return SP_E_INVALID_ARG;
         K.bcol[j] = bcs[j].col; K.bvalue[j] = bcs[j].value; K.bstep[j] = bcs[j].step;
@@ -860,7 +860,7 @@ int StarkProver::composition_precheck(const fe rap[3], const std::vector<Boundar
     K.two = fe_from_u64(2);
     K.b15 = fe_from_u64(1ULL << 15); K.b16 = fe_from_u64(1ULL << 16); K.b32 = fe_from_u64(1ULL << 32); K.b48 = fe_from_u64(1ULL << 48);
     K.n_boundary = B; K.n_transitions = n_transitions; K.main_cols = Cm_; K.has_rc_builtin = has_rc_ ? 1 : 0;
-    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_chk_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_chk_, &K, composition_consts_bytes(1u << logb_), hipMemcpyHostToDevice, c_->stream));
     SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     SP_TRY(cairo_trace_check(c_->stream, d_trace_, n_, d_comp_consts_chk_, c_->d_flag, check_row0(), check_rows()));
     check_pending_ = true;
@@ -881,7 +881,7 @@ int StarkProver::composition(const fe rap[3], const std::vector<BoundaryConstrai
     // --- boundary denominators: distinct steps -> points g^step
     std::vector<uint64_t> steps;
     CompositionConsts K;
-    std::memset(&K, 0, sizeof(K));
+    std::memset(&K, 0, composition_consts_bytes(1u << logb_));   // (the per-coset tables only as far as this proof's blowup factor reaches)
     for (uint32_t j = 0; j < B; ++j) {
         auto it = std::find(steps.begin(), steps.end(), bcs[j].step);
         if (it == steps.end()) { steps.push_back(bcs[j].step); it = steps.end() - 1; }
@@ -1052,7 +1052,7 @@ int StarkProver::composition_air(const AirDescHost& air, const std::vector<fe>& 
     // --- boundary data and per-coset constants
     std::vector<uint64_t> steps;
     CompositionConsts K;
-    std::memset(&K, 0, sizeof(K));
+    std::memset(&K, 0, composition_consts_bytes(1u << logb_));   // (the per-coset tables only as far as this proof's blowup factor reaches)
     for (uint32_t j = 0; j < B; ++j) {
         const BoundaryConstraint& bc = air.boundary[j];
         if (bc.col >= C_ || bc.step >= n_) return SP_E_INVALID_ARG;
@@ -1101,7 +1101,7 @@ int StarkProver::composition_core(const CompositionConsts& K, const std::vector<
     SP_HIP_CHECK(hipSetDevice(c_->device));
     const bool prechecked = check_pending_ && !prog_dev;   // composition_precheck queued the constraint check (and cleared the flag) already
     check_pending_ = false;
-    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, sizeof(K), hipMemcpyHostToDevice, c_->stream));
+    SP_HIP_CHECK(hipMemcpyAsync(d_comp_consts_, &K, composition_consts_bytes(1u << logb_), hipMemcpyHostToDevice, c_->stream));
     if (!prechecked) SP_HIP_CHECK(hipMemsetAsync(c_->d_flag, 0, sizeof(int), c_->stream));
     // A trace that satisfies its constraints gives deg H < 2n, and then 2n evaluations fix H.  Decide that EXACTLY by
     // checking the constraints on the trace itself (n rows, no divisions): clean -> evaluate the composition on the 2n

@@ -5,11 +5,14 @@
 #include "common.h"
 #include "merkle.h"
 
+#include <algorithm>
+#include <cstddef>
+
 namespace sp {
 
 constexpr int CAIRO_MAX_TRANSITIONS = 50;
 constexpr int CAIRO_MAX_BOUNDARY = 8;
-constexpr int CAIRO_MAX_BLOWUP = 32;
+constexpr int CAIRO_MAX_BLOWUP = 128;       // ProofOptions::blowup_factor is a u8 power of two (options.rs:21-26)
 // program AIRs (sp_air_desc): up to 64 transition constraints and 16 boundary constraints share the constant block below
 constexpr int COMP_MAX_BOUNDARY = 16;
 constexpr int COMP_MAX_TERMS = 64 + COMP_MAX_BOUNDARY;
@@ -35,14 +38,19 @@ struct CompositionConsts {
     fe rap[3];                  // alpha_memory, z_memory, z_range_check (reference src/cairo/air.rs:469-473)
     fe g_last;                  // g^(n-1): root of the single transition exemption X - g^(n-1) (traits.rs:49-79)
     fe b16, b32, b48, b15, two; // constants of the instruction-decoding constraints (air.rs:883-912)
-    fe zerofier[CAIRO_MAX_BLOWUP];                                          // 1/(x^n - 1) per coset (evaluator.rs:156-171)
-    fe coef[CAIRO_MAX_BLOWUP][COMP_MAX_TERMS];                              // alpha_k * x^(D-D_k) + beta_k per coset (transitions, then boundary)
     fe bvalue[COMP_MAX_BOUNDARY];                                           // boundary values
     uint32_t bcol[COMP_MAX_BOUNDARY];                                       // boundary columns
     uint32_t bden[COMP_MAX_BOUNDARY];                                       // index of the inverse-denominator array
     uint64_t bstep[COMP_MAX_BOUNDARY];                                      // boundary rows (trace check only)
     uint32_t n_boundary, n_transitions, main_cols, has_rc_builtin;
+    // the per-coset tables last: a proof uploads the block only as far as its blowup factor reaches (composition_consts_bytes)
+    fe zerofier[CAIRO_MAX_BLOWUP];                                          // 1/(x^n - 1) per coset (evaluator.rs:156-171)
+    fe coef[CAIRO_MAX_BLOWUP][COMP_MAX_TERMS];                              // alpha_k * x^(D-D_k) + beta_k per coset (transitions, then boundary)
 };
+// bytes of a CompositionConsts that a proof with `cosets` LDE cosets reads
+inline size_t composition_consts_bytes(uint32_t cosets) {
+    return offsetof(CompositionConsts, coef) + (size_t)std::min<uint32_t>(cosets, CAIRO_MAX_BLOWUP) * COMP_MAX_TERMS * sizeof(fe);
+}
 
 // ConstraintEvaluator::evaluate (reference src/starks/constraints/evaluator.rs:38-260) with CairoAIR::compute_transition
 // (src/cairo/air.rs:743-767, helpers :869-1160) fused per LDE point.  lde: column-major [C][col_len] natural order;

@@ -102,7 +102,11 @@ __device__ __forceinline__ uint32_t phase_gate(const fe& a, const fe& b) {
 #ifndef SP_COMP_WAVES
 #define SP_COMP_WAVES 3
 #endif
-template <bool CHECK>
+constexpr size_t COMP_LDS_LIMIT = 128u << 10;   // bytes of LDS the composition kernel may take for its per-coset coefficient table (160 KB a CU on gfx950)
+// STAGED: the per-coset coefficient table is copied into LDS first (every blowup factor up to 64); not STAGED (blowup 128: the table
+// would take 237 KB): read from the constant block in global memory.  A template parameter, not a run-time choice: a pointer that may
+// point into either address space becomes a flat pointer, and the flat accesses to LDS raised memory-aperture violations.
+template <bool CHECK, bool STAGED = !CHECK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SP_COMP_WAVES, SP_COMP_WAVES)))
 cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
                          const fe* __restrict__ roots, const CompositionConsts* __restrict__ K, const fe* __restrict__ binv,
@@ -111,7 +115,7 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
     fe* sh_coef = reinterpret_cast<fe*>(sh_raw);  // [b][T + B]
     const uint32_t b = 1u << logb;
     const uint32_t T = K->n_transitions, B = K->n_boundary, W = T + B;
-    if (!CHECK) {
+    if (STAGED) {
         for (uint32_t t = threadIdx.x; t < b * W; t += 256) {
             uint32_t c = t / W, k = t % W;
             sh_coef[t] = K->coef[c][k];
@@ -132,7 +136,7 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
     // the LDE columns are coset-major (the trace of CHECK mode is a plain array): e, enext = storage indices
     const LdeOrder ord{CHECK ? 0u : 1u, logb - shard_log, logN - logb};
     const uint64_t e = ord.at(el), enext = ord.at(elnext);
-    const fe* coef = sh_coef + c * W;
+    auto coef_at = [&](uint32_t k) -> fe { if (STAGED) return sh_coef[c * W + k]; else return K->coef[c][k]; };
     const uint32_t A = K->main_cols;
     uint32_t gate = 0;  // see phase_gate
     auto cur = [&](uint32_t col) { return sk_ld(cols + (uint64_t)col * col_len + e + gate); };
@@ -144,7 +148,7 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
     // CHECK mode: S_g.v[0] collects "some constraint of group g is non-zero here" instead of the weighted sum.
     auto acc = [&](fe& S, uint32_t k, const fe& v) {
         if (CHECK) { uint32_t o = 0; for (int l = 0; l < 8; ++l) o |= v.v[l]; S.v[0] |= o; }
-        else S = S + coef[k] * v;
+        else S = S + coef_at(k) * v;
     };
 
     // --- phase 0: flags (air.rs:869-881) and the instruction word (air.rs:883-896)
@@ -278,16 +282,20 @@ cairo_composition_kernel(const fe* __restrict__ cols, uint64_t count, uint64_t c
 #pragma unroll 1
     for (uint32_t j = 0; j < B; ++j) {
         fe num = cur(K->bcol[j]) - K->bvalue[j];
-        total = total + coef[T + j] * num * sk_ld(binv + (uint64_t)K->bden[j] * count + i);
+        total = total + coef_at(T + j) * num * sk_ld(binv + (uint64_t)K->bden[j] * count + i);
     }
     sk_st(out + i, total);
 }
 
 int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
                       const fe* roots_N, const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log, uint32_t shard_rank) {
-    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
+    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 128 unsupported"); return SP_E_UNSUPPORTED; }
     size_t lds = (size_t)(1u << logb) * (CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY) * sizeof(fe);
-    hipLaunchKernelGGL(cairo_composition_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), lds, st, lde, count, col_len, stride_log,
+    if (lds > COMP_LDS_LIMIT)
+        hipLaunchKernelGGL((cairo_composition_kernel<false, false>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, count, col_len, stride_log,
+                           logN, logb, roots_N, consts_dev, binv, out, (int*)nullptr, shard_log, shard_rank, (uint64_t)0, count);
+    else
+    hipLaunchKernelGGL((cairo_composition_kernel<false, true>), dim3((unsigned)((count + 255) / 256)), dim3(256), lds, st, lde, count, col_len, stride_log,
                        logN, logb, roots_N, consts_dev, binv, out, (int*)nullptr, shard_log, shard_rank, (uint64_t)0, count);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
@@ -297,7 +305,7 @@ int cairo_trace_check(hipStream_t st, const fe* trace, uint64_t n, const Composi
     if (rows == 0) rows = n - row0;
     if (row0 + rows > n) return SP_E_INVALID_ARG;
     // rows row0 .. row0 + rows - 1 (the frame's next row wraps modulo n as on the whole trace)
-    hipLaunchKernelGGL(cairo_composition_kernel<true>, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, trace, n, n, 0u, 0u, 0u,
+    hipLaunchKernelGGL((cairo_composition_kernel<true, false>), dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, trace, n, n, 0u, 0u, 0u,
                        (const fe*)nullptr, consts_dev, (const fe*)nullptr, (fe*)nullptr, flag_dev, 0u, 0u, row0, row0 + rows);
     SP_HIP_CHECK(hipGetLastError());
     return SP_OK;
@@ -647,7 +655,7 @@ __global__ void __launch_bounds__(256) air_composition_kernel(const fe* __restri
 int air_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t col_len, uint32_t stride_log, uint32_t logN, uint32_t logb,
                     const fe* roots_N, const CompositionConsts* consts_dev, const AirProgram* prog_dev, const fe* ex_roots,
                     const fe* binv, fe* out, uint32_t shard_log, uint32_t shard_rank) {
-    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 32 unsupported"); return SP_E_UNSUPPORTED; }
+    if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 128 unsupported"); return SP_E_UNSUPPORTED; }
     hipLaunchKernelGGL(air_composition_kernel<false>, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, count, col_len, stride_log,
                        logN, logb, roots_N, consts_dev, prog_dev, ex_roots, binv, out, (int*)nullptr, shard_log, shard_rank);
     SP_HIP_CHECK(hipGetLastError());

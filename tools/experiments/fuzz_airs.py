@@ -18,7 +18,7 @@ with api.Context(device=0) as ctx:
         kind = rng.choice(list(BUILD))
         length = rng.choice([4, 8, 16, 20, 32, 64, 100, 128, 256, 512, 1000, 2048])
         params = (rng.randrange(1, 50), rng.randrange(1, 50)) if kind in ("simple_fibonacci", "fibonacci_2_columns") else ((rng.randrange(2, 9), 0) if kind == "quadratic" else (1, 1))
-        options = (rng.choice([2, 4, 8, 16]), rng.choice([1, 3, 5, 20]), rng.choice([3, 7]), rng.choice([0, 1, 4]))
+        options = (rng.choice([2, 4, 8, 16, 32, 64, 128]), rng.choice([1, 3, 5, 20]), rng.choice([3, 7]), rng.choice([0, 1, 4]))
         try:
             trace = O.example_trace(kind, length, params).copy()
         except Exception:
