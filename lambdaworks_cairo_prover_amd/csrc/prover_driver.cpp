@@ -238,6 +238,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             tr.append(nb, 8);
         }
         SP_TIMEPOINT("r4 grinding");
+        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)
@@ -376,6 +377,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
             for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
             tr.append(nb, 8);
         }
+        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)
