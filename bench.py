@@ -959,6 +959,10 @@ def main():
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
                         order = ["run", "rows", "run+prewarm", "rows+prewarm", "run+ctx+prewarm"]
+                        if key == "proof":
+                            # (a GPU that has idled for seconds - the projection's host work just did that - costs the next fresh process
+                            # ~0.5 s once, whatever it runs: a throw-away child takes that instead of the first measured one)
+                            out[key]["first_child_after_idle_ms"] = cold_start(args, fib, blowup, "run").get("context_to_first_proof_ms")
                         runs = {path: dict(cold_start(args, fib, blowup, path), path=path) for path in order}
                         out[key]["first_call_ms"] = runs["rows"].get("first_call_ms")
                         pw = runs["run+prewarm"]
