@@ -102,40 +102,53 @@ struct Proof {
     uint64_t trace_length; std::vector<Dig> trace_roots; std::vector<fe> ood; uint64_t row_width; Dig comp_root; fe h1z, h2z;
     std::vector<Dig> fri_roots; fe fri_last; std::vector<FriDecommitment> queries; std::vector<Opening> openings; uint64_t nonce;
 };
+// The wire format of StarkProof::serialize (reference proof/stark.rs:161-218), accepted in exactly the form that function writes:
+// every length prefix must equal the bytes its part occupies, every element length must be 32, elements must be canonical (< p) and
+// the nonce must end the buffer.  The reference's own deserializer (stark.rs:225-440) parses each part inside the slice its prefix
+// announces and takes the nonce from the last eight bytes, so it tolerates padding inside and behind the parts; a proof that uses that
+// freedom is refused here.  What both refuse: a prefix that disagrees with its part.
 Proof parse(const uint8_t* data, size_t len) {
     Reader r(data, len);
     Proof p;
+    auto slice = [&](void) { const uint64_t l = r.u64(); r.need(l); return r.pos + (size_t)l; };          // end position of a length-prefixed part
+    auto close = [&](size_t end) { if (r.pos != end) throw std::runtime_error("a length prefix disagrees with its part"); };
+    auto felt_len = [&](void) { if (r.u64() != 32) throw std::runtime_error("element length is not 32"); };
     p.trace_length = r.u64();
     uint64_t nr = r.count(32);
     for (uint64_t i = 0; i < nr; ++i) p.trace_roots.push_back(r.dig());
-    r.u64();
-    uint64_t ne = r.count(32); r.u64();
-    for (uint64_t i = 0; i < ne; ++i) p.ood.push_back(r.felt());
-    p.row_width = r.u64();
-    p.comp_root = r.dig(); r.u64();
+    {
+        const size_t end = slice();                        // Frame (frame.rs:93-111): count, element length, elements, row width
+        uint64_t ne = r.count(32); felt_len();
+        for (uint64_t i = 0; i < ne; ++i) p.ood.push_back(r.felt());
+        p.row_width = r.u64();
+        close(end);
+    }
+    p.comp_root = r.dig(); felt_len();
     p.h1z = r.felt(); p.h2z = r.felt();
     uint64_t nf = r.count(32);
     for (uint64_t i = 0; i < nf; ++i) p.fri_roots.push_back(r.dig());
     p.fri_last = r.felt();
     uint64_t nq = r.count(8);
     for (uint64_t i = 0; i < nq; ++i) {
-        r.u64();
+        const size_t end = slice();                        // FriDecommitment (fri_decommit.rs:20-51)
         FriDecommitment q;
         uint64_t k = r.count(8); for (uint64_t j = 0; j < k; ++j) q.paths_sym.push_back(r.path());
-        r.u64();
+        felt_len();
         k = r.count(32); for (uint64_t j = 0; j < k; ++j) q.evals_sym.push_back(r.felt());
         k = r.count(32); for (uint64_t j = 0; j < k; ++j) q.evals.push_back(r.felt());
         k = r.count(8); for (uint64_t j = 0; j < k; ++j) q.paths.push_back(r.path());
+        close(end);
         p.queries.push_back(std::move(q));
     }
     uint64_t no = r.count(8);
     for (uint64_t i = 0; i < no; ++i) {
-        r.u64();
+        const size_t end = slice();                        // DeepPolynomialOpenings (stark.rs:49-82)
         Opening o;
-        o.comp_path = r.path(); r.u64();
+        o.comp_path = r.path(); felt_len();
         o.h1 = r.felt(); o.h2 = r.felt();
         uint64_t k = r.count(8); for (uint64_t j = 0; j < k; ++j) o.trace_paths.push_back(r.path());
         k = r.count(32); for (uint64_t j = 0; j < k; ++j) o.trace_evals.push_back(r.felt());
+        close(end);
         p.openings.push_back(std::move(o));
     }
     p.nonce = r.u64();
@@ -217,7 +230,9 @@ static int verify_host(const uint8_t* proof_bytes, size_t len, const VerifySpec&
     const uint32_t f = air.bound_factor;
     const size_t n_roots = air.aux_cols ? 2 : 1;
     const uint64_t N = n << lb;
-    if (pr.ood.size() != (size_t)R * C || pr.trace_roots.size() != n_roots || pr.fri_roots.size() != (size_t)k) return 0;
+    // (the reference slices the out-of-domain frame by the row width the PROOF states, verifier.rs:136-137, 533-541: any other width than
+    // the AIR's makes it replay a different transcript)
+    if (pr.ood.size() != (size_t)R * C || pr.row_width != C || pr.trace_roots.size() != n_roots || pr.fri_roots.size() != (size_t)k) return 0;
     for (uint32_t c = 0; c < T; ++c) if (air.degrees[c] < 1 || air.degrees[c] > f + 1 || air.exemptions[c] >= n) return 0;
     const fe h = fe_from_u64(coset_offset), hinv = fe_inv(h);
     auto root_of = [&](int order) { fe w = fe_from_bytes_be((const uint8_t*)"\x00\x52\x82\xdb\x87\x52\x9c\xfa\x3f\x04\x64\x51\x9c\x8b\x0f\xa5\xad\x18\x71\x48\xe1\x1a\x61\x61\x60\x70\x02\x4f\x42\xf8\xef\x94"); for (int i = order; i < 192; ++i) w = fe_sqr(w); return w; };

@@ -121,58 +121,81 @@ struct ByteReader {
     std::vector<Digest> path() { uint64_t k = u64(); if (k > n) throw std::runtime_error("bad len"); std::vector<Digest> v; for (uint64_t i = 0; i < k; ++i) v.push_back(digest()); return v; }
 };
 
+// StarkProof::deserialize (proof/stark.rs:225-440), with its sub-deserializers Frame::deserialize (frame.rs:113-156),
+// FriDecommitment::deserialize (fri/fri_decommit.rs:53-145) and the Merkle-path reader (stark.rs: deserialize_proof), statement by
+// statement: every length-prefixed part is parsed INSIDE the slice its prefix announces (bytes left over in a slice are ignored, a slice
+// that is too short is an error), a field element is the first 32 of `felt_len` bytes (fewer than 32: an error; lambdaworks'
+// UnsignedInteger::from_bytes_be reads `0..32`), and the nonce is the last eight bytes of whatever follows the openings.
+inline Fp read_felt(ByteReader& r, uint64_t felt_len) {
+    if (felt_len > r.n - r.pos) throw std::runtime_error("InvalidAmountOfBytes");
+    if (felt_len < 32) throw std::runtime_error("FromBEBytesError");
+    Fp x = Fp::from_bytes_be(r.p + r.pos);
+    r.pos += felt_len;
+    return x;
+}
+inline ByteReader sub_slice(ByteReader& r, uint64_t len) {
+    if (len > r.n - r.pos) throw std::runtime_error("InvalidAmountOfBytes");
+    ByteReader s(r.p + r.pos, (size_t)len);
+    r.pos += len;
+    return s;
+}
 inline StarkProof deserialize_proof(const uint8_t* data, size_t len) {
     ByteReader r(data, len);
     StarkProof p;
     p.trace_length = r.u64();
     uint64_t nroots = r.u64();
-    if (nroots > len) throw std::runtime_error("bad len");
+    if (nroots > len) throw std::runtime_error("InvalidAmountOfBytes");
     for (uint64_t i = 0; i < nroots; ++i) p.lde_trace_merkle_roots.push_back(r.digest());
-    r.u64();  // frame byte length
-    uint64_t nel = r.u64();
-    if (nel > len) throw std::runtime_error("bad len");
-    r.u64();  // felt_len
-    for (uint64_t i = 0; i < nel; ++i) p.trace_ood_frame_data.push_back(r.felt());
-    p.trace_ood_row_width = r.u64();
+    {   // Frame::deserialize on the announced slice
+        ByteReader f = sub_slice(r, r.u64());
+        uint64_t nel = f.u64();
+        uint64_t felt_len = f.u64();
+        if (nel > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t i = 0; i < nel; ++i) p.trace_ood_frame_data.push_back(read_felt(f, felt_len));
+        p.trace_ood_row_width = f.u64();
+    }
     p.composition_poly_root = r.digest();
-    r.u64();
-    p.composition_poly_even_ood_evaluation = r.felt();
-    p.composition_poly_odd_ood_evaluation = r.felt();
+    const uint64_t felt_len = r.u64();
+    p.composition_poly_even_ood_evaluation = read_felt(r, felt_len);
+    p.composition_poly_odd_ood_evaluation = read_felt(r, felt_len);
     uint64_t nfri = r.u64();
-    if (nfri > len) throw std::runtime_error("bad len");
+    if (nfri > len) throw std::runtime_error("InvalidAmountOfBytes");
     for (uint64_t i = 0; i < nfri; ++i) p.fri_layers_merkle_roots.push_back(r.digest());
-    p.fri_last_value = r.felt();
+    p.fri_last_value = read_felt(r, felt_len);
     uint64_t nq = r.u64();
-    if (nq > len) throw std::runtime_error("bad len");
+    if (nq > len) throw std::runtime_error("InvalidAmountOfBytes");
     for (uint64_t i = 0; i < nq; ++i) {
-        r.u64();
-        FriDecommitment q;
-        uint64_t k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) q.layers_auth_paths_sym.push_back(r.path());
-        r.u64();
-        k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) q.layers_evaluations_sym.push_back(r.felt());
-        k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) q.layers_evaluations.push_back(r.felt());
-        k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) q.layers_auth_paths.push_back(r.path());
-        p.query_list.push_back(q);
+        ByteReader q = sub_slice(r, r.u64());
+        FriDecommitment d;
+        uint64_t k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) d.layers_auth_paths_sym.push_back(q.path());
+        const uint64_t fl = q.u64();
+        k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) d.layers_evaluations_sym.push_back(read_felt(q, fl));
+        k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) d.layers_evaluations.push_back(read_felt(q, fl));
+        k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) d.layers_auth_paths.push_back(q.path());
+        p.query_list.push_back(d);
     }
     uint64_t no = r.u64();
-    if (no > len) throw std::runtime_error("bad len");
+    if (no > len) throw std::runtime_error("InvalidAmountOfBytes");
     for (uint64_t i = 0; i < no; ++i) {
-        r.u64();
+        ByteReader q = sub_slice(r, r.u64());
         DeepPolynomialOpenings o;
-        o.lde_composition_poly_proof = r.path();
-        r.u64();
-        o.lde_composition_poly_even_evaluation = r.felt();
-        o.lde_composition_poly_odd_evaluation = r.felt();
-        uint64_t k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) o.lde_trace_merkle_proofs.push_back(r.path());
-        k = r.u64(); if (k > len) throw std::runtime_error("bad len");
-        for (uint64_t j = 0; j < k; ++j) o.lde_trace_evaluations.push_back(r.felt());
+        o.lde_composition_poly_proof = q.path();
+        const uint64_t fl = q.u64();
+        o.lde_composition_poly_even_evaluation = read_felt(q, fl);
+        o.lde_composition_poly_odd_evaluation = read_felt(q, fl);
+        uint64_t k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) o.lde_trace_merkle_proofs.push_back(q.path());
+        k = q.u64(); if (k > len) throw std::runtime_error("InvalidAmountOfBytes");
+        for (uint64_t j = 0; j < k; ++j) o.lde_trace_evaluations.push_back(read_felt(q, fl));
         p.deep_poly_openings.push_back(o);
     }
+    // the nonce is the LAST eight bytes of what is left (stark.rs:410-422: `bytes.len() - 8 ..`), whatever lies between the openings and them
+    r.need(8);
+    r.pos = r.n - 8;
     p.nonce = r.u64();
     return p;
 }
@@ -565,6 +588,9 @@ inline bool verify(const Air& air, const StarkProof& proof) {
     const size_t n = air.trace_len, N = n * domain.blowup_factor, C = ctx.trace_columns;
     const size_t nofs = ctx.transition_offsets.size();
     if (proof.trace_ood_frame_data.size() != nofs * C || proof.lde_trace_merkle_roots.empty()) return false;
+    // the reference takes the frame's rows by the row width the proof states (verifier.rs:136-137, 237, 533-541): with any other width
+    // than the AIR's it replays a different transcript or indexes past a row - never an accepted proof
+    if (proof.trace_ood_row_width != C) return false;
     Transcript t;
     // step 1
     t.append_digest(proof.lde_trace_merkle_roots[0]);

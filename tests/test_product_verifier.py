@@ -38,7 +38,7 @@ def test_agrees_with_oracle_and_rejects_tampering(hip_lib, oracle):
         want = oracle.cairo_verify(bytes(bad), run.public_inputs_c, (4, 3, 3, 1))
         assert got == want
         flipped_rejected += (not got)
-    assert flipped_rejected >= 55  # almost every single-bit flip must be rejected (a few land in unused length fields)
+    assert flipped_rejected == 60  # every single-bit flip is rejected (length prefixes and the frame's row width included)
     # wrong options / public inputs
     assert not api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(4, 4, 3, 1))   # more queries than the proof holds
     assert not api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(4, 3, 3, 30))  # grinding not satisfied
@@ -80,3 +80,49 @@ def parse_proof_file_bytes(blob):
         return parse_proof_file(name)
     finally:
         os.unlink(name)
+
+
+def test_every_single_bit_of_a_proof_matters(hip_lib, oracle):
+    """Bits 0 and 7 of every byte of a valid proof, one at a time: the product's verifier and the oracle's reject each of the 2 x 21 664
+    mutants - including the length prefixes (frame, element, query and opening lengths) that the reference's deserializer slices by
+    (proof/stark.rs:225-440) and the out-of-domain frame's row width that its verifier takes the rows by (verifier.rs:136-137)."""
+    run = api.CairoRun.fibonacci(10)
+    options = (4, 3, 3, 1)
+    proof = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+    accepted_by_product, accepted_by_oracle = [], []
+    for pos in range(len(proof)):
+        for bit in (0, 7):
+            bad = bytearray(proof)
+            bad[pos] ^= 1 << bit
+            if api.cairo_verify(bytes(bad), run.public_inputs_c, OPT):
+                accepted_by_product.append((pos, bit))
+            if oracle.cairo_verify(bytes(bad), run.public_inputs_c, options):
+                accepted_by_oracle.append((pos, bit))
+    assert accepted_by_product == [] and accepted_by_oracle == []
+
+
+def test_padding_the_reference_deserializer_tolerates_is_refused(hip_lib, oracle):
+    """The reference parses every length-prefixed part inside the slice the prefix announces and reads the nonce from the last eight
+    bytes (stark.rs:225-440): bytes appended INSIDE the last opening's slice (prefix enlarged to match) leave every parsed value and
+    the nonce where they were - the oracle's verifier, which restates that parse, still accepts.  The product accepts the
+    serializer's framing only."""
+    run = api.CairoRun.fibonacci(10)
+    options = (4, 3, 3, 1)
+    proof = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+    assert oracle.cairo_verify(proof, run.public_inputs_c, options) and api.cairo_verify(proof, run.public_inputs_c, OPT)
+    # find the last opening's length prefix: walk the openings from the count field (three queries -> three openings of equal size)
+    nonce = proof[-8:]
+    body = proof[:-8]
+    n_open = 3
+    # the three openings have equal size s: [.. count=3][s][opening][s][opening][s][opening]; solve for s from the tail
+    for s in range(64, len(body)):
+        if struct.unpack(">Q", body[-s - 8:-s])[0] == s and struct.unpack(">Q", body[-2 * (s + 8) - 0: -2 * (s + 8) + 8])[0] == s:
+            break
+    else:
+        raise AssertionError("opening size not found")
+    assert struct.unpack(">Q", body[-n_open * (s + 8) - 8:-n_open * (s + 8)])[0] == n_open
+    pad = bytes(range(1, 25))
+    padded = body[:-s - 8] + struct.pack(">Q", s + len(pad)) + body[-s:] + pad + nonce
+    assert oracle.cairo_verify(padded, run.public_inputs_c, options)           # the reference's parse: padding inside a slice is ignored
+    assert not api.cairo_verify(padded, run.public_inputs_c, OPT)              # the product: a prefix must equal its part
+    assert not oracle.cairo_verify(body + pad + nonce[:-1] + bytes([nonce[-1] ^ 1]), run.public_inputs_c, options)   # (bytes behind the openings move nothing either - but a changed nonce never passes)
