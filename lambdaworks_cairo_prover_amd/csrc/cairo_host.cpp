@@ -82,7 +82,14 @@ struct Decoded {
     int dst_reg, op0_reg, op1_src, res_logic, pc_update, ap_update, opcode;
 };
 Decoded decode(const fe& word) {
+    // an instruction is a 63-bit word (whitepaper section 4.5; the AIR's constraint 15 wants flag 15 = 0 and constraint 16 rebuilds the
+    // cell from its 15 flags and three offsets): anything larger cannot be a row of a valid trace
+    {
+        const fe raw = fe_from_mont(word);
+        for (int l = 2; l < 8; ++l) if (raw.v[l]) throw std::runtime_error("instruction cell beyond 64 bits");
+    }
     uint64_t w = fe_low_u64(word);
+    if (w >> 63) throw std::runtime_error("InstructionNonZeroHighBit");
     Decoded d;
     d.off_dst = (uint32_t)(w & 0xffff); d.off_op0 = (uint32_t)((w >> 16) & 0xffff); d.off_op1 = (uint32_t)((w >> 32) & 0xffff);
     uint32_t f = (uint32_t)(w >> 48);
@@ -95,6 +102,10 @@ Decoded decode(const fe& word) {
     if (!one_hot_or_zero(d.pc_update)) throw std::runtime_error("InvalidPcUpdate");
     if (d.ap_update == 3) throw std::runtime_error("InvalidApUpdate");
     if (!one_hot_or_zero(d.opcode)) throw std::runtime_error("InvalidOpcode");
+    // call: the frame goes to [ap] and [ap + 1] and ap moves by two - the encoding cairo-lang asserts (dst = [ap + 0], op0 = [ap + 1],
+    // no other ap update); any other leaves the AIR's CALL_1 / CALL_2 / NEXT_AP constraints unsatisfied
+    if (d.opcode == 1 && (d.dst_reg != 0 || d.op0_reg != 0 || d.off_dst != 0x8000 || d.off_op0 != 0x8001 || d.ap_update != 0))
+        throw std::runtime_error("InvalidCallEncoding");
     return d;
 }
 inline uint64_t add_signed(uint64_t base, uint32_t biased_off) { return base + (uint64_t)biased_off - 0x8000ULL; }
@@ -508,12 +519,24 @@ void run_program_builtins(const std::vector<fe>& program, uint32_t builtins_mask
             uint64_t dst_addr = add_signed(d.dst_reg ? fp : ap, d.off_dst);
             uint64_t op0_addr = add_signed(d.op0_reg ? fp : ap, d.off_op0);
             if (d.opcode == 1) {  // call: [ap] = fp, [ap+1] = pc + size
-                mem.set(ap, fe_from_u64(fp));
-                mem.set(ap + 1, fe_from_u64(pc + size));
+                // (memory is write-once: a cell an earlier instruction has written with another value - `[ap + 4] = ...` ahead of a call -
+                // is an inconsistent run, cairo-vm's InconsistentMemory, not something to overwrite and prove)
+                auto write_once = [&](uint64_t addr, const fe& v) {
+                    const fe* old = mem.get(addr);
+                    if (old && !fe_eq(*old, v)) throw std::runtime_error("inconsistent memory: a call frame over a cell that holds another value");
+                    if (!old) mem.set(addr, v);
+                };
+                write_once(ap, fe_from_u64(fp));
+                write_once(ap + 1, fe_from_u64(pc + size));
             }
             const fe* op0p = mem.get(op0_addr);
             uint64_t op1_base;
-            if (d.op1_src == 0) { if (!op0p) throw std::runtime_error("op0 unknown"); op1_base = fe_low_u64(*op0p); }
+            if (d.op1_src == 0) {
+                if (!op0p) throw std::runtime_error("op0 unknown");
+                const fe raw = fe_from_mont(*op0p);      // [op0 + off]: op0 has to be an address
+                for (int l = 2; l < 8; ++l) if (raw.v[l]) throw std::runtime_error("op0 is not an address");
+                op1_base = fe_low_u64(*op0p);
+            }
             else op1_base = d.op1_src == 1 ? pc : d.op1_src == 2 ? fp : ap;
             uint64_t op1_addr = add_signed(op1_base, d.off_op1);
             const fe* op1p = mem.get(op1_addr);

@@ -32,3 +32,37 @@ def test_the_generator_reaches_holes_and_both_jump_directions():
         jumps_not += int((jnz & ~taken).sum())
         holes += int(run.n_rows > (1 << (steps - 1).bit_length()))
     assert jumps_taken > 0 and jumps_not > 0 and holes > 0
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_mutated_programs_are_refused_or_give_a_trace_that_verifies(oracle, block):
+    """Random bit flips in random programs, random flag words and plain garbage through the front-end's VM: it either reports an error
+    (an undecodable instruction - flag 15, a cell beyond 64 bits, a call that is not `[ap] = fp; [ap + 1] = pc + size; ap += 2` -,
+    an unknown operand, a failed assert, a call frame over a cell that already holds another value, the step limit) or returns a run
+    whose main trace the CPU oracle proves AND verifies.  A run that is accepted and does not verify is a VM that executed something
+    the AIR does not allow (found that way: call frames overwriting written cells, calls with a second ap update, calls whose operand
+    offsets point elsewhere)."""
+    import random
+    accepted = refused = 0
+    for seed in range(700 * block, 700 * block + 700):
+        rng = random.Random(seed)
+        mode = rng.choice(["garbage", "mutate", "mutate", "flags"])
+        if mode == "garbage":
+            words, entry = [rng.randrange(2**63) for _ in range(rng.randrange(1, 40))], 1
+        elif mode == "flags":
+            words, entry = [A.word(rng.randrange(1 << 15), rng.randrange(-5, 5), rng.randrange(-5, 5), rng.randrange(-5, 5)) for _ in range(rng.randrange(1, 30))], 1
+        else:
+            words, entry = A.random_program(seed, 20)
+            words = list(words)
+            for _ in range(rng.randrange(1, 4)):
+                j = rng.randrange(len(words))
+                words[j] = (words[j] ^ (1 << rng.randrange(63))) % A.P
+        try:
+            run = api.CairoRun.from_program(words, entry_pc=entry, max_steps=rng.choice([16, 256, 4096]))
+        except api.SpError:
+            refused += 1
+            continue
+        proof = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, OPTIONS)
+        assert oracle.cairo_verify(proof, run.public_inputs_c, OPTIONS), (seed, mode, run.num_steps)
+        accepted += 1
+    assert accepted > 20 and refused > 400
