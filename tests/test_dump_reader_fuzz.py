@@ -54,3 +54,54 @@ def test_damaged_dumps_give_an_error_or_a_well_formed_run(block):
         assert trace.shape[1] == 34 and trace.shape[0] == run.n_rows and run.n_rows & (run.n_rows - 1) == 0 and run.n_rows >= run.num_steps
         accepted += 1
     assert accepted > 0 and refused > 0
+
+
+def test_damaged_arrays_give_an_error_or_a_well_formed_run():
+    """sp_cairo_run_from_arrays (cairo-vm's relocated trace and memory handed over in memory): a shuffled or duplicated memory list
+    gives the very same main trace; flipped registers, addresses and values, dropped cells, huge addresses and impossible program sizes
+    give an error code or a well-formed run - never a crash."""
+    import numpy as np
+
+    import cairo_asm as A
+    base = []
+    for seed in range(4):
+        words, entry = A.random_program(seed, 25)
+        run = api.CairoRun.from_program(words, entry_pc=entry)
+        base.append((run, len(words)) + run.export())
+    same = accepted = refused = 0
+    for i in range(600):
+        rng = random.Random(i)
+        run0, psize, regs, addrs, vals = base[i % len(base)]
+        regs, addrs, vals, ps = regs.copy(), addrs.copy(), vals.copy(), psize
+        kind = rng.choice(["none", "reg", "addr", "val", "drop", "dup", "psize", "shuffle", "huge"])
+        if kind == "reg":
+            regs[rng.randrange(len(regs)), rng.randrange(3)] ^= np.uint64(1 << rng.randrange(20))
+        elif kind == "addr":
+            addrs[rng.randrange(len(addrs))] ^= np.uint64(1 << rng.randrange(12))
+        elif kind == "val":
+            vals[rng.randrange(len(vals)), rng.randrange(32)] ^= 1 << rng.randrange(8)
+        elif kind == "drop":
+            j = rng.randrange(len(addrs))
+            addrs, vals = np.delete(addrs, j), np.delete(vals, j, axis=0)
+        elif kind == "dup":
+            j = rng.randrange(len(addrs))
+            addrs, vals = np.append(addrs, addrs[j]), np.append(vals, vals[j:j + 1], axis=0)
+        elif kind == "psize":
+            ps = rng.choice([0, 1, psize + 3, 2**40])
+        elif kind == "shuffle":
+            perm = np.array(rng.sample(range(len(addrs)), len(addrs)))
+            addrs, vals = addrs[perm], vals[perm]
+        elif kind == "huge":
+            addrs[rng.randrange(len(addrs))] = np.uint64(rng.choice([2**40, 2**63, 2**64 - 1]))
+        try:
+            run = api.CairoRun.from_arrays(regs, addrs, vals, ps)
+        except api.SpError:
+            refused += 1
+            continue
+        trace = run.main_trace()
+        assert trace.shape[1] == 34 and trace.shape[0] & (trace.shape[0] - 1) == 0
+        accepted += 1
+        if kind in ("none", "shuffle", "dup"):
+            assert np.array_equal(trace, run0.main_trace()), (i, kind)
+            same += 1
+    assert same > 100 and refused > 100
