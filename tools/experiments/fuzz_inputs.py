@@ -27,7 +27,7 @@ with api.Context(device=0) as ctx:
             run = run_of(rng.choice(["rc_program", "rc_loop_20", "output_and_rc", "rc_loop_300"]))
         trace = run.main_trace().copy()
         n = trace.shape[0]
-        blowup = rng.choice([2, 4, 8, 16, 32, 64, 128])
+        blowup = rng.choice([2, 4, 8, 16, 32, 64, 128] if not os.environ.get("SP_FUZZ_SMALL_BLOWUP") else [2, 4, 8])
         options = (blowup, rng.choice([1, 2, 3, 5, 17, 40]), rng.choice([3, 3, 7, 5]), rng.choice([0, 1, 2, 5, 8]))
         pub = run.public_inputs_c
         what = []
