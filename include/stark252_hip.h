@@ -231,10 +231,11 @@ int sp_prove_setup(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_col
 /* Pre-warm for the reference's one-proof-per-process shape (src/main.rs:85-108: run the VM, prove once, exit): call it - on a
  * thread of its own, or before the VM starts - while the trace does not exist yet, with the shape the proof will have.  It does
  * sp_prove_setup's work and everything else a first proof would otherwise pay on its critical path:
- *   SP_PREWARM_KERNELS    three small valid Cairo proofs (2^13 rows, the three input forms) on this context: the first launch of every
- *                         kernel family, the side streams, the auxiliary-trace workspace;
- *   SP_PREWARM_CLOCKS     round 1's kernels once at the REAL shape on the arena's contents: the size-specific kernel variants, and the
- *                         device at its clocks when the trace arrives;
+ *   SP_PREWARM_KERNELS    a small valid Cairo proof (2^13 rows) from a device-built trace and the commitment of the same trace through
+ *                         the three other input forms, on this context: the first launch of every kernel family, the side streams, the
+ *                         auxiliary-trace workspace;
+ *   SP_PREWARM_CLOCKS     round 1's kernels at the REAL shape on the arena's contents, column slice by column slice: the size-specific
+ *                         kernel variants, and the device at its clocks when the trace arrives (sp_prewarm_cancel ends it early);
  *   SP_PREWARM_HOST_ROWS  the page-locked ring and the parked gather threads of the row-major entry points (sp_cairo_prove,
  *                         sp_commit_trace from host tables above 64 MB).
  * flags = 0 means all of them.  The proof that follows (any entry point, same n / columns / blowup / coset offset) then costs what a
