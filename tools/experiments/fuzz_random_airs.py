@@ -15,7 +15,8 @@ bad = refused = 0
 with api.Context(device=0) as ctx:
     for seed in range(seed0, seed0 + cases):
         rng = random.Random(seed)
-        cols, R, f = rng.randrange(1, 7), rng.randrange(1, 5), rng.choice([1, 2, 2, 3])
+        big = os.environ.get('SP_FUZZ_BIG_AIRS') is not None
+        cols, R, f = rng.randrange(1, 30 if big else 7), rng.randrange(1, 9 if big else 5), rng.choice([1, 2, 2, 3])
         n = 1 << rng.randrange(max(2, R.bit_length() + 1), 9)
         nex = rng.randrange(0, 3)
         b = air.AirBuilder(cols, list(range(R)), f, num_transition_exemptions=max(1, nex))
@@ -26,8 +27,8 @@ with api.Context(device=0) as ctx:
             op = rng.choice("+-*")
             if op == "*" and dx + dy > f + 1: op = "+"
             return (x + y, max(dx, dy)) if op == "+" else (x - y, max(dx, dy)) if op == "-" else (x * y, dx + dy)
-        for _ in range(rng.randrange(1, 9)):
-            v, d = expr(rng.randrange(1, 4))
+        for _ in range(rng.randrange(1, 65 if big else 9)):
+            v, d = expr(rng.randrange(1, 5 if big else 4))
             b.constraint(v, max(1, min(d, f + 1)) if rng.random() < 0.8 else rng.randrange(1, f + 2), rng.randrange(0, max(1, nex) + 1))
         for _ in range(rng.randrange(0, 4)):
             b.boundary(rng.randrange(cols), rng.randrange(n), rng.randrange(P))
