@@ -245,7 +245,8 @@ int sp_prewarm(sp_ctx* ctx, uint64_t n, uint32_t main_cols, uint32_t aux_cols, i
 /* Callable from ANY thread: asks the sp_prewarm that runs on this context - or the next one, if none does yet - to return as soon as it
  * can.  Everything a first proof needs (arena, plumbing, first launches) is still done; the clock ramp (SP_PREWARM_CLOCKS: round 1 at the
  * real shape, column slice by column slice) stops behind the slice in flight.  The intended use: start sp_prewarm on a thread, run the VM,
- * call sp_prewarm_cancel when the trace exists, join the thread, prove - the ramp then lasts exactly as long as the VM did. */
+ * call sp_prewarm_cancel when the trace exists, join the thread, prove - the ramp then lasts exactly as long as the VM did.  A request
+ * that finds no prewarm to stop is dropped by the next proof on the context. */
 int sp_prewarm_cancel(sp_ctx* ctx);
 
 /* interpolate_and_commit (prover.rs:126-159): rows = row-major n x cols trace segment (0 main, 1 auxiliary).

@@ -330,6 +330,7 @@ static int cairo_prove_impl(sp_ctx* c, const uint8_t* main_trace, uint64_t n, ui
                             const sp_proof_options* opt, uint8_t** proof_out, uint64_t* proof_len, StarkProver::TraceSource src,
                             int col_enc, uint64_t col_stride) {
     if (!c || !main_trace || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
+    c->prewarm_cancel.store(0, std::memory_order_release);   // (a sp_prewarm_cancel that found no prewarm to stop ends here, not in some later prewarm)
     try {
         ProofOptionsHost o{opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor};
         std::vector<uint8_t> bytes;
