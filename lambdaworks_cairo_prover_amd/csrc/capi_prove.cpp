@@ -369,6 +369,7 @@ int sp_last_round_ms(sp_ctx* c, float out[5]) {
 int sp_air_prove(sp_ctx* c, const sp_air_desc* d, const uint8_t* main_trace, uint64_t n, const sp_proof_options* opt,
                  uint8_t** proof_out, uint64_t* proof_len) {
     if (!c || !d || !main_trace || !opt || !proof_out || !proof_len) return SP_E_INVALID_ARG;
+    c->prewarm_cancel.store(0, std::memory_order_release);
     if (d->n_offsets == 0 || d->n_offsets > 8 || d->n_transitions == 0 || d->n_transitions > 64 || (d->n_ops && !d->ops) ||
         (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) { sp_set_error("sp_air_prove: malformed descriptor"); return SP_E_INVALID_ARG; }
     sp::AirDescHost a;
