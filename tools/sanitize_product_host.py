@@ -36,4 +36,38 @@ for backend in (0, 1):
         api.cairo_verify(junk, run.public_inputs_c, OPT, backend)
 blob = api.proof_file_bytes(p, run)
 n = ctypes.c_int(); lib.sp_host_cpus(ctypes.byref(n)); api.host_bind_to_device(0)
+# round 4: the inputs of the random tests - bit-flipped programs through the VM, damaged dumps and arrays through the readers, every
+# length prefix of a proof through the verifier
+import numpy as np
+import cairo_asm as A
+G = os.path.join(ROOT, 'tests', 'golden')
+t0, m0 = open(G + '/program.trace', 'rb').read(), open(G + '/program.memory', 'rb').read()
+for seed in range(400):
+    r = random.Random(seed)
+    words, entry = A.random_program(seed, 20)
+    words = list(words)
+    for _ in range(r.randrange(0, 4)):
+        j = r.randrange(len(words)); words[j] = (words[j] ^ (1 << r.randrange(63))) % A.P
+    try:
+        rn = api.CairoRun.from_program(words, entry_pc=entry, max_steps=r.choice([16, 256, 4096])); rn.main_trace(); regs, addrs, vals = rn.export()
+    except api.SpError:
+        continue
+    if r.random() < 0.5:
+        addrs = addrs.copy(); addrs[r.randrange(len(addrs))] ^= np.uint64(1 << r.randrange(12))
+    try: api.CairoRun.from_arrays(regs, addrs, vals, len(words)).main_trace()
+    except api.SpError: pass
+for seed in range(300):
+    r = random.Random(seed); t, m = bytearray(t0), bytearray(m0)
+    k = r.choice(['t', 'm', 'tt', 'mt'])
+    if k == 't': t[r.randrange(len(t))] ^= 1 << r.randrange(8)
+    elif k == 'm': m[r.randrange(len(m))] ^= 1 << r.randrange(8)
+    elif k == 'tt': t = t[:r.randrange(len(t))]
+    else: m = m[:r.randrange(len(m))]
+    try: api.CairoRun.from_dumps(bytes(t), bytes(m), program_size=r.choice([1, 5, len(m0) // 40])).main_trace()
+    except api.SpError: pass
+O.set_merkle_backend(0)
+p = O.cairo_prove(run.main_trace(), run.public_inputs_c, opts)
+for pos in range(0, len(p), 3):
+    bad = bytearray(p); bad[pos] ^= 1 << (pos % 8)
+    assert not api.cairo_verify(bytes(bad), run.public_inputs_c, OPT, 0)
 print("product host code under ASan: ok")
