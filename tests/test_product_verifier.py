@@ -126,3 +126,46 @@ def test_padding_the_reference_deserializer_tolerates_is_refused(hip_lib, oracle
     assert oracle.cairo_verify(padded, run.public_inputs_c, options)           # the reference's parse: padding inside a slice is ignored
     assert not api.cairo_verify(padded, run.public_inputs_c, OPT)              # the product: a prefix must equal its part
     assert not oracle.cairo_verify(body + pad + nonce[:-1] + bytes([nonce[-1] ^ 1]), run.public_inputs_c, options)   # (bytes behind the openings move nothing either - but a changed nonce never passes)
+
+
+def test_verdicts_agree_on_mixed_mutations(hip_lib, oracle):
+    """Flips, truncations, appended bytes, zeroed and swapped 32-byte words on proofs of three programs and option sets: the product's
+    verdict is the oracle's on every one of them (the oracle parses like the reference - part by part inside the announced slices,
+    the nonce from the last eight bytes - so appended bytes change the nonce it reads and the proof falls with it)."""
+    import cairo_asm as A
+    cases = []
+    for seed in range(3):
+        rng = random.Random(seed)
+        if seed == 0:
+            run = api.CairoRun.fibonacci(10)
+        else:
+            words, entry = A.random_program(seed, 30)
+            run = api.CairoRun.from_program(words, entry_pc=entry)
+        options = [(4, 3, 3, 1), (2, 5, 3, 2), (8, 4, 3, 0)][seed]
+        proof = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+        assert oracle.cairo_verify(proof, run.public_inputs_c, options) and api.cairo_verify(proof, run.public_inputs_c, api.ProofOptions(*options))
+        cases.append((run, options, proof))
+    rejected = 0
+    for i in range(450):
+        rng = random.Random(1000 + i)
+        run, options, proof = cases[i % 3]
+        b = bytearray(proof)
+        kind = rng.choice(["flip", "flip", "flip", "trunc", "extend", "zero", "swap"])
+        if kind == "flip":
+            for _ in range(rng.choice([1, 1, 2, 5])):
+                b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        elif kind == "trunc":
+            b = b[:rng.randrange(len(b))]
+        elif kind == "extend":
+            b += bytes(rng.randrange(256) for _ in range(rng.randrange(1, 64)))
+        elif kind == "zero":
+            j = rng.randrange(len(b))
+            b[j:j + 32] = bytes(min(32, len(b) - j))
+        else:
+            j, k = rng.randrange(len(b) - 32), rng.randrange(len(b) - 32)
+            b[j:j + 32], b[k:k + 32] = b[k:k + 32], b[j:j + 32]
+        want = oracle.cairo_verify(bytes(b), run.public_inputs_c, options)
+        got = api.cairo_verify(bytes(b), run.public_inputs_c, api.ProofOptions(*options))
+        assert got == want, (i, kind)
+        rejected += not got
+    assert rejected >= 440          # (a swap of two equal words or a zeroed all-zero word leaves the proof as it was)
