@@ -437,7 +437,13 @@ int sp_cairo_run_main_trace_dev(sp_ctx* ctx, const sp_cairo_run* run, int fe_enc
 
 /* verify_cairo_proof (reference src/cairo/air.rs:1176-1182, src/starks/verifier.rs:559-657) on the host CPU: returns 1 when the
  * proof is accepted, 0 when it is rejected or malformed. Ships with the library so that proofs of shapes without a golden
- * file can be checked where they are produced. */
+ * file can be checked where they are produced.
+ * STRICTER THAN THE REFERENCE'S PARSER, on purpose: StarkProof::deserialize (src/starks/proof/stark.rs:225-440) reads each part inside
+ * the slice its length prefix announces and the nonce from the last eight bytes, so it tolerates padding inside and behind the parts;
+ * this verifier accepts only the bytes StarkProof::serialize writes (every prefix equals its part, element length 32, nothing behind the
+ * nonce, Poseidon path digests below p) - a proof the reference accepts can be refused here if someone re-framed it.  After a 0,
+ * sp_last_error() says which it was by its first word: "rejected:" a well-formed proof failed a verification step; "malformed:" neither
+ * parser could read it; "non-canonical framing:" only this strict parser refuses it (re-serialize the proof and try again). */
 int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_public_inputs* pub, const sp_proof_options* opt);
 /* The same two verifiers for proofs whose commitments use another hash (SP_OPT_MERKLE_BACKEND): merkle_backend = SP_MERKLE_*.
  * With SP_MERKLE_KECCAK256 they are sp_cairo_verify / sp_air_verify. */

@@ -396,6 +396,12 @@ def cairo_verify(proof, public_inputs_c, options, merkle_backend=0):
     return lib.sp_cairo_verify_backend(proof, ctypes.c_uint64(len(proof)), ctypes.byref(public_inputs_c), ctypes.byref(opt), int(merkle_backend)) == 1
 
 
+def last_error():
+    """sp_last_error(): the message behind the last non-OK return of this thread's calls; after a 0 from the verifiers its first word
+    tells "rejected:" / "malformed:" / "non-canonical framing:" apart (include/stark252_hip.h, sp_cairo_verify)."""
+    return _lib.load().sp_last_error().decode(errors="replace")
+
+
 def air_verify(proof, desc, options, merkle_backend=0):
     """sp_air_verify(_backend): the library's CPU verifier for an AIR given as a constraint program."""
     lib = _lib.load()

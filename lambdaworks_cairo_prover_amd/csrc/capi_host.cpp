@@ -211,11 +211,25 @@ int sp_cairo_run_from_arrays(const uint64_t* regs, uint64_t steps, const uint64_
         if (hi < 8 * n_cells + 1024 && hi + 1 < (1ULL << 32)) {
             r->mem.dense.assign(hi + 1, fe_zero());
             r->mem.present.assign(hi + 1, 0);
+            // Cairo memory is write-once: the first thread to claim an address writes it, a second entry for the same address is
+            // set aside and must carry the same value (checked once every first write has landed) - otherwise the winner would
+            // depend on the thread schedule
+            std::mutex dup_m;
+            std::vector<uint64_t> dups;
             sp::host_parallel_for(n_cells, 1 << 14, [&](size_t b, size_t e) {
-                for (size_t k = b; k < e; ++k) { r->mem.dense[addrs[k]] = cell(k); r->mem.present[addrs[k]] = 1; }   // (a duplicate address: last writer wins, as with set)
+                for (size_t k = b; k < e; ++k) {
+                    if (__atomic_exchange_n(&r->mem.present[addrs[k]], (uint8_t)1, __ATOMIC_ACQ_REL)) { std::lock_guard<std::mutex> lk(dup_m); dups.push_back(k); }
+                    else r->mem.dense[addrs[k]] = cell(k);
+                }
             });
+            for (uint64_t k : dups)
+                if (!fe_eq(r->mem.dense[addrs[k]], cell(k))) throw std::runtime_error("InconsistentMemory: two values for one address");
         } else {
-            for (uint64_t k = 0; k < n_cells; ++k) r->mem.set(addrs[k], cell(k));
+            for (uint64_t k = 0; k < n_cells; ++k) {
+                const fe v = cell(k);
+                if (const fe* seen = r->mem.get(addrs[k])) { if (!fe_eq(*seen, v)) throw std::runtime_error("InconsistentMemory: two values for one address"); }
+                else r->mem.set(addrs[k], v);
+            }
         }
         std::vector<sp::MemorySegment> segs;
         for (uint32_t i = 0; i < n_segments; ++i) {
@@ -340,7 +354,9 @@ int sp_cairo_verify(const uint8_t* proof, uint64_t proof_len, const sp_cairo_pub
     if (!proof || !p || !opt) return SP_E_INVALID_ARG;
     try {
         sp::PublicInputs r = sp::public_inputs_from_c(p);
-        return sp::cairo_verify_host(proof, proof_len, r, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+        const int ok = sp::cairo_verify_host(proof, proof_len, r, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+        sp_set_error(ok == 1 ? "" : "rejected: a verification step failed");
+        return ok;
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }
 
@@ -362,7 +378,7 @@ int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d
     if (!proof || !d || !opt) return SP_E_INVALID_ARG;
     try {
         if (d->n_offsets == 0 || d->n_offsets > 8 || d->n_transitions == 0 || d->n_transitions > 64 || (d->n_ops && !d->ops) ||
-            (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) return 0;
+            (d->n_consts && !d->consts) || (d->n_boundary && !d->boundary)) { sp_set_error("malformed: AIR descriptor"); return 0; }
         std::vector<uint32_t> offsets(d->offsets, d->offsets + d->n_offsets), degrees(d->degrees, d->degrees + d->n_transitions),
             exemptions(d->exemptions, d->exemptions + d->n_transitions);
         std::vector<std::array<uint16_t, 3>> ops;
@@ -371,8 +387,10 @@ int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d
         for (uint32_t i = 0; i < d->n_consts; ++i) consts.push_back(fe_from_bytes_be(d->consts + 32 * (size_t)i));
         std::vector<sp::BoundaryConstraint> bcs;
         for (uint32_t i = 0; i < d->n_boundary; ++i) bcs.push_back(sp::BoundaryConstraint{d->boundary[i].col, d->boundary[i].step, fe_from_bytes_be(d->boundary[i].value)});
-        return sp::air_verify_host(proof, proof_len, d->main_cols, d->aux_cols, offsets, degrees, exemptions, d->degree_bound_factor, ops, consts,
-                                   d->n_rap, bcs, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+        const int ok = sp::air_verify_host(proof, proof_len, d->main_cols, d->aux_cols, offsets, degrees, exemptions, d->degree_bound_factor, ops, consts,
+                                           d->n_rap, bcs, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+        sp_set_error(ok == 1 ? "" : "rejected: a verification step failed");
+        return ok;
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }
 

@@ -66,6 +66,7 @@ void StarkProver::free_all() {
     if (comm_stream_) (void)hipStreamSynchronize(comm_stream_);
     d_bpre_ = nullptr; bpre_cap_ = 0; bpre_valid_ = false; deep_pref_ = false; d_flag_side_ = nullptr;
     d_fri_chain_ = nullptr; fri_chain_layers_ = 0; d_comp_consts_chk_ = nullptr; check_pending_ = false; presorted_ = false; presort_pub_ = nullptr;
+    d_flagbits_ = nullptr; flagbits_words_ = 0;     // carved from the arena / allocs_ like the rest: gone with the shape
     // (the page-locked upload ring does not depend on the shape: it stays until the prover goes)
     for (void* p : allocs_) (void)hipFree(p);
     allocs_.clear();
@@ -506,6 +507,8 @@ int StarkProver::commit_local(const fe* cols_dev, uint64_t stride, uint32_t ncol
 }
 
 int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t cols, uint8_t root_out[32], TraceSource src, int col_enc, uint64_t col_stride) {
+    const uint32_t binary_hint = binary_cols_hint_;   // (this call only, whatever becomes of it: a later table on this prover need not be a Cairo trace)
+    binary_cols_hint_ = 0;
     if (!rows_host || !root_out) return SP_E_INVALID_ARG;
     if (!((segment == 0 && stage_ == 1 && cols == Cm_) || (segment == 1 && stage_ == 2 && cols == Ca_))) {
         sp_set_error("commit_trace: wrong segment order or column count");
@@ -514,8 +517,6 @@ int StarkProver::commit_trace(int segment, const uint8_t* rows_host, uint32_t co
     SP_HIP_CHECK(hipSetDevice(c_->device));
     for (double& x : c_->upload_stats) x = 0.0;
     leaf_head_done_ = false;
-    const uint32_t binary_hint = binary_cols_hint_;   // (one call only: a later table on this prover need not be a Cairo trace)
-    binary_cols_hint_ = 0;
     // An upload that fails half-way must not return while copies from the caller's buffer are still in flight (the caller is free
     // to release it): every non-OK exit of the host paths waits for the copy and the compute stream first.
     auto drained = [this](int rc) {

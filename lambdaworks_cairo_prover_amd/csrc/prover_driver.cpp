@@ -150,6 +150,7 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
         double _tp = wall_ms();
         static const bool tail_timing = std::getenv("SP_TAIL_TIMING") != nullptr;
         const double t_entry = wall_ms();
+        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         SP_TRY(P->setup(n, air.main_columns, air.aux_columns, air.has_rc_builtin, opt));
         SP_TIMEPOINT("setup (alloc + tables)");
         HostTranscript tr;
@@ -238,7 +239,6 @@ int cairo_prove(sp_ctx* ctx, const uint8_t* main_trace, uint64_t n, uint32_t col
             tr.append(nb, 8);
         }
         SP_TIMEPOINT("r4 grinding");
-        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)
@@ -272,6 +272,7 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
     try {
         if (air.main_cols == 0 || air.main_cols + air.aux_cols > 64) { sp_set_error("air_prove: column count out of range"); return SP_E_INVALID_ARG; }
         StarkProver* P = &prover_holder(ctx, true)->prover;   // kept (with its device buffers) across proofs of the same shape on this context
+        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         SP_TRY(P->setup(n, air.main_cols, air.aux_cols, false, opt));
         HostTranscript tr;
         uint8_t root[32];
@@ -377,7 +378,6 @@ int air_prove(sp_ctx* ctx, const AirDescHost& air, const uint8_t* main_trace, ui
             for (int i = 0; i < 8; ++i) nb[i] = (uint8_t)(nonce >> (56 - 8 * i));
             tr.append(nb, 8);
         }
-        if (opt.fri_number_of_queries == 0) { sp_set_error("prove: fri_number_of_queries must be at least 1 (the reference emits a proof without openings for 0; this prover does not)"); return SP_E_INVALID_ARG; }
         std::vector<uint64_t> iotas(opt.fri_number_of_queries);
         for (auto& x : iotas) x = tr.to_usize() % P->N();
         Openings& o = prover_holder(ctx, true)->open;     // (kept with the prover: its arrays are reused by the next proof)

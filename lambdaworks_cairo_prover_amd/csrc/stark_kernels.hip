@@ -102,7 +102,19 @@ __device__ __forceinline__ uint32_t phase_gate(const fe& a, const fe& b) {
 #ifndef SP_COMP_WAVES
 #define SP_COMP_WAVES 3
 #endif
-constexpr size_t COMP_LDS_LIMIT = 128u << 10;   // bytes of LDS the composition kernel may take for its per-coset coefficient table (160 KB a CU on gfx950)
+// bytes of LDS the composition kernel may take for its per-coset coefficient table: 128 KB of gfx950's 160 KB a CU, and never more than
+// the device grants one work-group (asked once per device: a part with 64 KB per group then takes the table from global memory)
+static size_t comp_lds_limit() {
+    static size_t cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+    if (!cached[dev]) {
+        int per_block = 0;
+        if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || per_block <= 0) per_block = 64 << 10;
+        cached[dev] = std::min<size_t>(128u << 10, (size_t)per_block);
+    }
+    return cached[dev];
+}
 // STAGED: the per-coset coefficient table is copied into LDS first (every blowup factor up to 64); not STAGED (blowup 128: the table
 // would take 237 KB): read from the constant block in global memory.  A template parameter, not a run-time choice: a pointer that may
 // point into either address space becomes a flat pointer, and the flat accesses to LDS raised memory-aperture violations.
@@ -291,7 +303,7 @@ int cairo_composition(hipStream_t st, const fe* lde, uint64_t count, uint64_t co
                       const fe* roots_N, const CompositionConsts* consts_dev, const fe* binv, fe* out, uint32_t shard_log, uint32_t shard_rank) {
     if ((1u << logb) > CAIRO_MAX_BLOWUP) { sp_set_error("composition: blowup factor > 128 unsupported"); return SP_E_UNSUPPORTED; }
     size_t lds = (size_t)(1u << logb) * (CAIRO_MAX_TRANSITIONS + CAIRO_MAX_BOUNDARY) * sizeof(fe);
-    if (lds > COMP_LDS_LIMIT)
+    if (lds > comp_lds_limit())
         hipLaunchKernelGGL((cairo_composition_kernel<false, false>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, lde, count, col_len, stride_log,
                            logN, logb, roots_N, consts_dev, binv, out, (int*)nullptr, shard_log, shard_rank, (uint64_t)0, count);
     else

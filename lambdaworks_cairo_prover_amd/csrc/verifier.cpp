@@ -83,14 +83,14 @@ typedef std::array<uint8_t, 32> Dig;
 struct Reader {
     const uint8_t* p; size_t n, pos = 0;
     Reader(const uint8_t* d, size_t len) : p(d), n(len) {}
-    void need(size_t k) { if (k > n - pos) throw std::runtime_error("InvalidAmountOfBytes"); }
+    void need(size_t k) { if (k > n - pos) throw std::runtime_error("malformed: InvalidAmountOfBytes"); }
     uint64_t u64() { need(8); uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | p[pos + i]; pos += 8; return v; }
-    uint64_t count(size_t unit) { uint64_t k = u64(); if (k > (n - pos) / (unit ? unit : 1)) throw std::runtime_error("length field exceeds the proof"); return k; }
+    uint64_t count(size_t unit) { uint64_t k = u64(); if (k > (n - pos) / (unit ? unit : 1)) throw std::runtime_error("malformed: a length field exceeds the proof"); return k; }
     fe felt() {
         need(32);
         // reject non-canonical encodings (>= p)
         static const uint8_t PBE[32] = {0x08, 0, 0, 0, 0, 0, 0, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1};
-        if (std::memcmp(p + pos, PBE, 32) >= 0) throw std::runtime_error("field element out of range");
+        if (std::memcmp(p + pos, PBE, 32) >= 0) throw std::runtime_error("malformed: field element out of range");
         fe x = fe_from_bytes_be(p + pos); pos += 32; return x;
     }
     Dig dig() { need(32); Dig d; std::memcpy(d.data(), p + pos, 32); pos += 32; return d; }
@@ -111,8 +111,13 @@ Proof parse(const uint8_t* data, size_t len) {
     Reader r(data, len);
     Proof p;
     auto slice = [&](void) { const uint64_t l = r.u64(); r.need(l); return r.pos + (size_t)l; };          // end position of a length-prefixed part
-    auto close = [&](size_t end) { if (r.pos != end) throw std::runtime_error("a length prefix disagrees with its part"); };
-    auto felt_len = [&](void) { if (r.u64() != 32) throw std::runtime_error("element length is not 32"); };
+    // (messages that start with "non-canonical framing:" mark what ONLY this strict parser refuses - sp_last_error() after a 0 from
+    // sp_cairo_verify / sp_air_verify lets a caller that re-frames proofs tell that from an invalid proof, include/stark252_hip.h)
+    auto close = [&](size_t end) {
+        if (r.pos < end) throw std::runtime_error("non-canonical framing: padding inside a length-prefixed part");
+        if (r.pos > end) throw std::runtime_error("malformed: a part overruns its length prefix");
+    };
+    auto felt_len = [&](void) { if (r.u64() != 32) throw std::runtime_error("non-canonical framing: element length is not 32"); };
     p.trace_length = r.u64();
     uint64_t nr = r.count(32);
     for (uint64_t i = 0; i < nr; ++i) p.trace_roots.push_back(r.dig());
@@ -152,7 +157,7 @@ Proof parse(const uint8_t* data, size_t len) {
         p.openings.push_back(std::move(o));
     }
     p.nonce = r.u64();
-    if (r.pos != len) throw std::runtime_error("trailing bytes");
+    if (r.pos != len) throw std::runtime_error("non-canonical framing: trailing bytes behind the nonce");
     return p;
 }
 struct Tr {
@@ -193,7 +198,7 @@ bool merkle_ok(const std::vector<Dig>& path, const Dig& root, uint64_t index, co
     Dig h = hash_felts(v, k, single_element_tree);
     for (const Dig& s : path) {
         if (t_merkle_backend == SP_MERKLE_POSEIDON) {
-            if (!poseidon_digest_canonical(s)) return false;
+            if (!poseidon_digest_canonical(s)) throw std::runtime_error("non-canonical framing: a Poseidon path digest is not below p");
             h = poseidon_dig((index & 1) ? poseidon_hash2(poseidon_fe(s), poseidon_fe(h)) : poseidon_hash2(poseidon_fe(h), poseidon_fe(s)));
             index >>= 1;
             continue;
@@ -390,7 +395,7 @@ int cairo_verify_host(const uint8_t* proof_bytes, size_t len, const PublicInputs
     spec.degrees = info.transition_degrees; spec.exemptions = info.transition_exemptions;
     spec.bound_factor = 2; spec.n_rap = 3;
     // the trace length is only known from the proof: read it first (boundary steps depend on it)
-    if (len < 8) throw std::runtime_error("InvalidAmountOfBytes");
+    if (len < 8) throw std::runtime_error("malformed: InvalidAmountOfBytes");
     uint64_t n = 0;
     for (int i = 0; i < 8; ++i) n = (n << 8) | proof_bytes[i];
     const bool has_rc = info.has_rc_builtin;
@@ -417,7 +422,7 @@ int air_verify_host(const uint8_t* proof_bytes, size_t len, uint32_t main_cols, 
             case 5: ok = a < T && b < t && ops[b][0] != 5; break;
             default: ok = false;
         }
-        if (!ok) throw std::runtime_error("malformed constraint program");
+        if (!ok) throw std::runtime_error("malformed: constraint program");
     }
     VerifySpec spec;
     spec.main_cols = main_cols; spec.aux_cols = aux_cols; spec.offsets = offsets; spec.degrees = degrees; spec.exemptions = exemptions;

@@ -105,3 +105,28 @@ def test_damaged_arrays_give_an_error_or_a_well_formed_run():
             assert np.array_equal(trace, run0.main_trace()), (i, kind)
             same += 1
     assert same > 100 and refused > 100
+
+
+def test_conflicting_duplicate_address_is_an_error():
+    """Cairo memory is write-once: the same address twice with the same value is one cell, with two values it is
+    InconsistentMemory - in the flat-array path (filled by several threads: no schedule-dependent winner) and in the sparse one."""
+    import numpy as np
+
+    import cairo_asm as A
+    words, entry = A.random_program(1, 25)
+    run0 = api.CairoRun.from_program(words, entry_pc=entry)
+    regs, addrs, vals = run0.export()
+    for far in (False, True):
+        a, v = addrs.copy(), vals.copy()
+        if far:     # one cell far away sends the whole list cell by cell through CairoMemory::set
+            a, v = np.append(a, np.uint64(2**40)), np.append(v, v[:1], axis=0)
+        for j in (0, len(addrs) // 2, len(addrs) - 1):
+            same = api.CairoRun.from_arrays(regs, np.append(a, a[j]), np.append(v, v[j:j + 1], axis=0), len(words))
+            assert np.array_equal(same.main_trace(), run0.main_trace())
+            other = v[j:j + 1].copy()
+            other[0, 31] ^= 1
+            for order in (0, 1):    # the conflicting entry behind or in front of the original
+                aa = np.append(a, a[j]) if order == 0 else np.insert(a, 0, a[j])
+                vv = np.append(v, other, axis=0) if order == 0 else np.insert(v, 0, other, axis=0)
+                with pytest.raises(api.SpError, match="InconsistentMemory"):
+                    api.CairoRun.from_arrays(regs, aa, vv, len(words))

@@ -75,3 +75,33 @@ def test_small_tables_through_the_upload_pipeline(env):
     assert len(res) >= 11
     bad = [c for c in res if not (c["same_bytes"] and c["kind_ok"])]
     assert not bad, bad
+
+
+RESHAPE_CHILD = r'''
+import json, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_lib as oracle
+from lambdaworks_cairo_prover_amd import api
+out = []
+with api.Context(device=0) as ctx:
+    # one context, shapes that change with equal or fewer rows: the flag-bitmap staging buffer must be re-carved with the shape
+    # (ADVICE r4: it used to survive free_all() and point into freed / re-used arena memory)
+    for fib, options in ((4000, (2, 3, 3, 1)), (4000, (8, 3, 3, 1)), (2000, (4, 3, 3, 1)), (4000, (4, 3, 3, 1)), (300, (2, 3, 3, 1)), (4000, (2, 3, 3, 1))):
+        run = api.CairoRun.fibonacci(fib)
+        want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+        got = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+        st = ctx.last_upload_stats()
+        out.append({"case": f"fib({fib}) blowup {options[0]}", "same_bytes": got == want, "kind": st["kind"]})
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_shape_changes_on_one_context_with_flag_bitmaps():
+    e = dict(os.environ, SP_UPLOAD_MIN_MB="0")
+    r = subprocess.run([sys.executable, "-c", RESHAPE_CHILD, ROOT], env=e, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    res = json.loads(lines[-1][7:])
+    assert len(res) == 6
+    bad = [c for c in res if not (c["same_bytes"] and c["kind"].startswith("row-major host buffer, gathered"))]
+    assert not bad, bad

@@ -125,6 +125,12 @@ def test_padding_the_reference_deserializer_tolerates_is_refused(hip_lib, oracle
     padded = body[:-s - 8] + struct.pack(">Q", s + len(pad)) + body[-s:] + pad + nonce
     assert oracle.cairo_verify(padded, run.public_inputs_c, options)           # the reference's parse: padding inside a slice is ignored
     assert not api.cairo_verify(padded, run.public_inputs_c, OPT)              # the product: a prefix must equal its part
+    assert api.last_error().startswith("non-canonical framing:")               # ... and says that this is why: not "rejected:"
+    assert not api.cairo_verify(proof + b"\0", run.public_inputs_c, OPT) and api.last_error().startswith("non-canonical framing:")
+    tampered = bytearray(proof); tampered[40] ^= 1                             # a bit of the first trace root: well-formed, invalid
+    assert not api.cairo_verify(bytes(tampered), run.public_inputs_c, OPT) and api.last_error().startswith("rejected:")
+    assert not api.cairo_verify(proof[:100], run.public_inputs_c, OPT) and api.last_error().startswith("malformed:")
+    assert api.cairo_verify(proof, run.public_inputs_c, OPT) and api.last_error() == ""
     assert not oracle.cairo_verify(body + pad + nonce[:-1] + bytes([nonce[-1] ^ 1]), run.public_inputs_c, options)   # (bytes behind the openings move nothing either - but a changed nonce never passes)
 
 
