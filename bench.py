@@ -366,7 +366,7 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
         proof = ctx.cairo_prove_dev(dev_trace.data_ptr(), n, cols, run.public_inputs_c, opt)
         dt = (time.perf_counter() - t0) * 1e3
         if dist is not None and world > 1:   # max over ranks
-            t = torch.tensor([dt], dtype=torch.float64, device=dev_trace.device if dist.get_backend() == "nccl" else "cpu")
+            t = torch.tensor([dt], dtype=torch.float64)       # (the control plane is a gloo group: CPU tensors)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         times.append(dt)
@@ -678,15 +678,33 @@ def _free_port():
 
 
 def _placement(local_rank, world):
-    """(device index, backend): one GPU per rank over RCCL when the box has them; otherwise (development box) the ranks share
-    the devices there are and exchange through host-staged gloo hooks - reported as devices_shared in the JSON line."""
+    """(device index, transport, devices shared): one GPU per rank and the library's own RCCL communicator ("rccl") when the box has
+    the GPUs; otherwise (development box) the ranks share the devices there are and exchange through host-staged gloo hooks
+    ("gloo-staged") - reported as devices_shared in the JSON line.  The CONTROL plane (rendezvous, barriers, the max over ranks, the
+    128-byte RCCL id) is always a gloo group: it has monitored barriers with a timeout, needs no GPU, and keeps the headline line alive
+    whatever the fabric does - every byte of the data path goes through sp_comm_init_rccl's communicator inside the library."""
     import torch
     count = torch.cuda.device_count()          # does not initialise the GPU
     if "SP_BENCH_FORCE_DEVICE" in os.environ:
-        return int(os.environ["SP_BENCH_FORCE_DEVICE"]), os.environ.get("SP_BENCH_BACKEND", "gloo"), True
+        return int(os.environ["SP_BENCH_FORCE_DEVICE"]), os.environ.get("SP_BENCH_TRANSPORT", "gloo-staged"), True
     if count >= world:
-        return local_rank, os.environ.get("SP_BENCH_BACKEND", "nccl"), False
-    return local_rank % max(count, 1), "gloo", True
+        return local_rank, os.environ.get("SP_BENCH_TRANSPORT", "rccl"), False
+    return local_rank % max(count, 1), "gloo-staged", True
+
+
+def _init_control_plane(timeout_s):
+    """torch.distributed over gloo on the loopback interface (one node by contract; the container's hostname may not resolve)."""
+    import datetime
+    import socket
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if "GLOO_SOCKET_IFNAME" not in os.environ:
+        try:
+            socket.gethostbyname(socket.gethostname())
+        except OSError:
+            os.environ["GLOO_SOCKET_IFNAME"] = "lo"
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=timeout_s))
+    return dist
 
 
 def proof_child(args):
@@ -695,17 +713,13 @@ def proof_child(args):
     import torch
     from lambdaworks_cairo_prover_amd import api
     rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
-    import torch.distributed as dist
-    dev_index, backend, shared = _placement(local_rank, world)
+    dev_index, transport, shared = _placement(local_rank, world)
     torch.cuda.set_device(dev_index)
-    if backend == "nccl":
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
-    else:
-        dist.init_process_group(backend)
+    dist = _init_control_plane(INIT_TIMEOUT_S)
     result = {}
     try:
         ctx = api.Context(device=dev_index)
-        if backend == "nccl":
+        if transport == "rccl":
             ctx.init_rccl()                                   # the library's own RCCL communicator (xGMI)
         else:                                                 # development aid: ranks sharing one GPU, host-staged exchange
             ctx.set_collective(world, rank, api.StagedAllGather())
@@ -724,7 +738,7 @@ def proof_child(args):
             except Exception as e:
                 result[key] = {"error": repr(e)}
         stats = ctx.comm_stats()
-        result["rccl"] = {"world": stats["world"], "backend": "rccl" if backend == "nccl" else "gloo-staged hook", "devices_shared": shared,
+        result["rccl"] = {"world": stats["world"], "backend": "rccl" if transport == "rccl" else "gloo-staged hook", "devices_shared": shared,
                           "allgather_calls": stats["allgather_calls"], "allgather_bytes": stats["allgather_bytes"],
                           "alltoall_calls": stats["alltoall_calls"], "alltoall_bytes": stats["alltoall_bytes"]}
         ctx.close()
@@ -779,23 +793,128 @@ def proof_isolated(args, rank, local_rank, world, dist):
         return {"error": f"sharded proof child: {status}", "stderr_tail": tail}
 
 
+BENCH_DEADLINE_S = float(os.environ.get("SP_BENCH_DEADLINE_S", "1500"))          # the whole N > 1 job (the driver's own limit is 1800 s)
+INIT_TIMEOUT_S = float(os.environ.get("SP_BENCH_INIT_TIMEOUT_S", "300"))          # rendezvous of the control plane (a fresh box pages torch in for 1-2 min)
+BARRIER_TIMEOUT_S = float(os.environ.get("SP_BENCH_BARRIER_TIMEOUT_S", "300"))    # one barrier of the timed region
+
+
+def error_line(args, world, message, **extra):
+    """The ONE JSON line of a run that did not get to its measurement: the contract keys with value null and the reason."""
+    line = {"metric": "stark252_ntt_field_ops_per_s", "value": None, "unit": "butterflies/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
+            "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])"},
+            "error": message}
+    line.update(extra)
+    return line
+
+
+_final_line_printed = False
+
+
+def print_final(line):
+    """Exactly one JSON line per job on stdout (whoever gets there first: the measurement, the watchdog or the SIGTERM handler)."""
+    global _final_line_printed
+    if _final_line_printed:
+        return
+    _final_line_printed = True
+    sys.stdout.write(json.dumps(line) + "\n")
+    sys.stdout.flush()
+
+
+class RankGuard:
+    """What keeps an N > 1 rank from waiting for ever: a deadline on a timer thread (a collective or a kernel that never returns cannot
+    be interrupted from Python) and a SIGTERM handler (torch.distributed.run terminates the other workers when one dies).  Either way
+    rank 0 still prints the one JSON line - with the reason - and the process ends with a non-zero code."""
+
+    def __init__(self, args, rank, world):
+        import signal
+        import threading
+        self.args, self.rank, self.world, self.stage = args, rank, world, "start"
+        self._timer = threading.Timer(BENCH_DEADLINE_S, self._expired)
+        self._timer.daemon = True
+        self._timer.start()
+        try:
+            signal.signal(signal.SIGTERM, self._terminated)
+        except ValueError:      # (not the main thread)
+            pass
+
+    def _say(self, message):
+        if self.rank == 0:
+            print_final(error_line(self.args, self.world, message, stage=self.stage))
+
+    def _expired(self):
+        self._say(f"deadline of {BENCH_DEADLINE_S:.0f} s passed in stage '{self.stage}'")
+        os._exit(4)
+
+    def _terminated(self, signum, frame):
+        self._say(f"terminated (SIGTERM) in stage '{self.stage}': another rank failed or the launcher gave up")
+        os._exit(143)
+
+    def fail(self, message):
+        self._say(message)
+        os._exit(5)
+
+    def done(self):
+        self._timer.cancel()
+
+
 def launch_ranks(args):
-    """`python bench.py --gpus N` as a plain command: start the N ranks as fresh child processes (this parent never touches
-    the GPU), wait for them, pass rank 0's JSON line through."""
+    """`python bench.py --gpus N` as a plain command: start the N ranks as fresh child processes (this parent never touches the GPU),
+    watch ALL of them, pass rank 0's JSON line through.  One rank that exits with an error - or an overall deadline - ends the job:
+    the remaining children (each its own process group, so their proof children go with them) are terminated, ONE JSON line is printed
+    whatever happened (rank 0's if it got that far, else an error line) and the return code is non-zero."""
+    import signal
     port = _free_port()
-    procs = []
+    procs, out0 = [], tempfile.TemporaryFile()
     for r in range(args.gpus):
         env = dict(os.environ)
-        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = p.wait() or rc
-    lines = [l for l in out.decode().splitlines() if l.startswith("{")]   # (gloo prints its connection banner on stdout)
-    sys.stdout.write((lines[-1] if lines else out.decode()) + "\n")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    t_end = time.monotonic() + BENCH_DEADLINE_S + 30.0       # (the ranks' own deadline comes first and leaves an error line)
+    reason = None
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+        if bad:
+            reason = f"rank {bad[0][0]} exited with code {bad[0][1]}"
+        elif time.monotonic() > t_end:
+            reason = f"launcher deadline of {BENCH_DEADLINE_S + 30:.0f} s passed"
+        if reason:
+            for sig, grace in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+                for p in procs:
+                    if p.poll() is None:
+                        try:
+                            os.killpg(p.pid, sig)        # exactly the process groups started above
+                        except ProcessLookupError:
+                            pass
+                t_grace = time.monotonic() + grace
+                while time.monotonic() < t_grace and any(p.poll() is None for p in procs):
+                    time.sleep(0.05)
+            break
+        time.sleep(0.2)
+    codes = [p.wait() for p in procs]
+    rc = next((c for c in codes if c != 0), 0)
+    out0.seek(0)
+    text = out0.read().decode(errors="replace")
+    line = None
+    for l in reversed(text.splitlines()):                  # (gloo prints its connection banner on stdout)
+        if l.startswith("{"):
+            try:
+                line = json.loads(l)
+                break
+            except ValueError:
+                continue
+    if line is None:
+        line = error_line(args, args.gpus, reason or f"rank 0 printed no JSON line (exit codes {codes})", exit_codes=codes)
+        rc = rc or 1
+    elif reason and "error" not in line:
+        line["launcher_note"] = reason
+    sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
     return rc
 
@@ -833,21 +952,28 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)
 
-    import torch
-    from lambdaworks_cairo_prover_amd import api
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    guard = RankGuard(args, rank, world) if world > 1 else None
+    if world > 1 and os.environ.get("SP_BENCH_FAULT_RANK") == str(rank):     # fault injection (tests/test_bench_launcher.py): this rank never joins
+        if os.environ.get("SP_BENCH_FAULT", "exit") == "hang":
+            time.sleep(1e6)
+        sys.exit(3)
+
+    import torch
+    from lambdaworks_cairo_prover_amd import api
+
     dist = None
-    dev_index, backend, shared = _placement(local_rank, world)
+    dev_index, transport, shared = _placement(local_rank, world)
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
-        else:
-            dist.init_process_group(backend)
+        guard.stage = "rendezvous"
+        try:
+            dist = _init_control_plane(INIT_TIMEOUT_S)
+        except Exception as e:
+            guard.fail(f"rendezvous of the {world} ranks failed: {e!r}")
+        os.environ.setdefault("SP_HOST_RANKS", os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # the library's host-thread budget (sp_set_option SP_OPT_HOST_RANKS)
+        guard.stage = "setup"
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
 
@@ -870,27 +996,34 @@ def main():
     data = host.to(dev).contiguous()
     ctx = api.Context(device=dev_index)
 
-    def barrier():
+    def barrier(stage="barrier"):
         torch.cuda.synchronize()
         if dist is not None:
-            dist.barrier()
+            import datetime
+            guard.stage = stage
+            try:        # bounded: names the rank that did not arrive instead of waiting for it for ever
+                dist.monitored_barrier(timeout=datetime.timedelta(seconds=BARRIER_TIMEOUT_S))
+            except Exception as e:
+                guard.fail(f"{stage}: {e!r}"[:600])
         ctx.sync()
 
     self_warm = warm_until(ctx, lambda: ctx.ntt_dev(data.data_ptr(), n))   # clock ramp, independent of --warmup
     for _ in range(args.warmup):
         ctx.ntt_dev(data.data_ptr(), n)
-    barrier()
+    barrier("barrier before the timed region")
     t0 = time.perf_counter()
     ctx.timer_start()                    # HIP events on the context stream bracket the timed region
     for _ in range(args.steps):
         ctx.ntt_dev(data.data_ptr(), n)  # asynchronous launches, back to back on the context stream
     kernel_ms = [ctx.timer_stop() / args.steps]
-    barrier()
+    barrier("barrier behind the timed region")
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        guard.stage = "max over ranks"
+        t = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        guard.stage = "proofs"
 
     # HBM bytes per NTT from the committed PMC passes of this very kernel source (tools/profile_round.sh); a profile taken
     # from other sources is reported as stale instead of being passed off as a measurement of this build
@@ -1009,10 +1142,18 @@ def main():
                     "from": "cpu_baseline.proof_cfg4 (a full run of the CPU oracle in this process' host, identical bytes) x "
                             "(N3 log2 N3) / (N4 log2 N4), N = LDE points; a one-off full run took 460 s on 8 cores"}
     if rank == 0:
-        print(json.dumps(compact_line(out)))
+        print_final(compact_line(out))
+    if guard is not None:
+        guard.stage = "shutdown"
     ctx.close()
     if dist is not None:
-        dist.destroy_process_group()
+        try:
+            dist.monitored_barrier(timeout=__import__("datetime").timedelta(seconds=BARRIER_TIMEOUT_S))   # nobody leaves while a peer may still need the store
+            dist.destroy_process_group()
+        except Exception:
+            pass
+    if guard is not None:
+        guard.done()
     return 0
 
 

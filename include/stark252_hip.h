@@ -70,6 +70,9 @@ int sp_device_count(int* count_out);      /* number of visible HIP devices (0 wi
 /* CPUs the host side of the library may really use: hardware threads cut down by the affinity mask and the cgroup CPU quota
  * (what sizes the gather threads of sp_cairo_prove and the front-end's trace builder). */
 int sp_host_cpus(int* count_out);
+/* This process' share of them: sp_host_cpus / the ranks sharing the host (SP_OPT_HOST_RANKS, see sp_set_option), at least 1 - the
+ * figure every host-side thread count is derived from.  ranks_out (optional): the rank count in force. */
+int sp_host_cpu_budget(int* budget_out, int* ranks_out);
 /* NUMA placement on multi-socket hosts: restricts the CALLING THREAD - and every thread it creates afterwards - to the CPUs of the
  * NUMA node the device hangs off (within the affinity mask it already has), so that the tables a prover process builds are
  * first-touched on that node: the page-locked staging of the host-buffer entry points lives there, and a table on the other node
@@ -133,6 +136,11 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *   SP_OPT_LINK_GBS (46)           GB/s one xGMI link delivers per direction, for that decision (76.8 GB/s x an assumed 0.6).
  *   SP_OPT_UPLOAD_THREADS (24)     host threads that gather the column groups of a row-major host trace into pinned memory
  *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB).
+ *   SP_OPT_HOST_RANKS (env)        how many ranks (processes, one context and GPU each) share this HOST.  Process-wide.  Every host thread
+ *                                  count of the library is a share of the CPUs the process may use (affinity mask, cgroup quota) divided by
+ *                                  this: the gather pool is min(SP_OPT_UPLOAD_THREADS, 2 x CPUs / ranks), the front-end's loops CPUs / ranks;
+ *                                  with more ranks than CPUs the Fiat-Shamir waits block instead of polling.  Default: the environment -
+ *                                  SP_HOST_RANKS, else LOCAL_WORLD_SIZE (what torch.distributed.run exports), else 1.  0 = back to that.
  *   SP_OPT_MERKLE_BACKEND (SP_MERKLE_KECCAK256)  the hash of every commitment of the context (trace, composition and FRI trees,
  *                                  sp_merkle_build*).  SP_MERKLE_KECCAK256 is the reference's configuration (src/starks/config.rs:10-20)
  *                                  and the only one whose proofs the reference verifies.  SP_MERKLE_POSEIDON (BASELINE.json configs[4]; NO
@@ -149,7 +157,7 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  rows of ONE column (leaf = hash_many over one element) - what the prover commits a one-column trace
  *                                  segment with (prover.rs:96-104 batch_commit).  Keccak256 trees have one leaf form; no effect there. */
 enum { SP_OPT_FRI_SHARD_MIN_LOG = 1, SP_OPT_SHARD_INTERPOLATION = 2, SP_OPT_UPLOAD_THREADS = 3, SP_OPT_MERKLE_BACKEND = 4, SP_OPT_MERKLE_ONE_COLUMN_ROWS = 5,
-       SP_OPT_DEVICE_TRACE = 6, SP_OPT_LINK_GBS = 7 };
+       SP_OPT_DEVICE_TRACE = 6, SP_OPT_LINK_GBS = 7, SP_OPT_HOST_RANKS = 8 };
 enum { SP_MERKLE_KECCAK256 = 0, SP_MERKLE_POSEIDON = 1 };
 int sp_set_option(sp_ctx* ctx, int key, int64_t value);
 

@@ -245,6 +245,13 @@ def host_cpus():
     return n.value
 
 
+def host_cpu_budget():
+    """sp_host_cpu_budget: (CPUs of this process' share, ranks sharing the host) - SP_OPT_HOST_RANKS / SP_HOST_RANKS / LOCAL_WORLD_SIZE."""
+    b, r = ctypes.c_int(), ctypes.c_int()
+    check(_lib.load().sp_host_cpu_budget(ctypes.byref(b), ctypes.byref(r)))
+    return b.value, r.value
+
+
 def host_bind_to_device(device=0):
     """sp_host_bind_to_device: keep this thread (and the threads it creates from now on) on the CPUs of the GPU's NUMA node; returns
     the node or -1 when unknown (nothing changed)."""
@@ -646,7 +653,7 @@ def _ctx_comm_stats(self):
             "alltoall_bytes": out[4], "received_bytes": out[5]}
 
 
-SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS, SP_OPT_DEVICE_TRACE, SP_OPT_LINK_GBS = 1, 2, 3, 4, 5, 6, 7
+SP_OPT_FRI_SHARD_MIN_LOG, SP_OPT_SHARD_INTERPOLATION, SP_OPT_UPLOAD_THREADS, SP_OPT_MERKLE_BACKEND, SP_OPT_MERKLE_ONE_COLUMN_ROWS, SP_OPT_DEVICE_TRACE, SP_OPT_LINK_GBS, SP_OPT_HOST_RANKS = 1, 2, 3, 4, 5, 6, 7, 8
 SP_MERKLE_KECCAK256, SP_MERKLE_POSEIDON = 0, 1
 SP_PREWARM_KERNELS, SP_PREWARM_CLOCKS, SP_PREWARM_HOST_ROWS, SP_PREWARM_ALL = 1, 2, 4, 7
 
@@ -676,6 +683,6 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS", "SP_OPT_HOST_RANKS", "host_cpu_budget", "last_error",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
             "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

@@ -184,12 +184,24 @@ unsigned host_effective_cpus() {
     return cached;
 }
 
-void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
-    static const unsigned max_threads = [] {
-        unsigned t = std::min(64u, host_effective_cpus());
-        if (const char* e = std::getenv("SP_HOST_THREADS")) { int v = std::atoi(e); if (v >= 1) t = (unsigned)std::min(v, 256); }
-        return t;
+static std::atomic<unsigned> g_host_ranks{0};    // 0: not set by the caller - the environment decides
+unsigned host_ranks() {
+    const unsigned set = g_host_ranks.load(std::memory_order_relaxed);
+    if (set) return set;
+    static const unsigned from_env = [] {
+        for (const char* name : {"SP_HOST_RANKS", "LOCAL_WORLD_SIZE"})
+            if (const char* e = std::getenv(name)) { const int v = std::atoi(e); if (v >= 1) return (unsigned)std::min(v, 1024); }
+        return 1u;
     }();
+    return from_env;
+}
+void set_host_ranks(unsigned ranks) { g_host_ranks.store(std::min(ranks, 1024u), std::memory_order_relaxed); }
+unsigned host_cpu_budget() { return std::max(1u, host_effective_cpus() / host_ranks()); }
+bool host_oversubscribed() { return host_ranks() > host_effective_cpus(); }
+
+void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn) {
+    static const int env_threads = [] { const char* e = std::getenv("SP_HOST_THREADS"); return e ? std::atoi(e) : 0; }();
+    const unsigned max_threads = env_threads >= 1 ? (unsigned)std::min(env_threads, 256) : std::min(64u, host_cpu_budget());
     const size_t parts = std::max<size_t>(1, std::min<size_t>(max_threads, n / std::max<size_t>(min_chunk, 1)));
     if (parts <= 1) { fn(0, n); return; }
     const size_t per = (n + parts - 1) / parts;

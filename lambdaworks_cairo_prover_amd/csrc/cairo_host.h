@@ -80,7 +80,15 @@ bool hip_runtime_in_use();
 
 // hardware threads, affinity mask and cgroup CPU quota taken together
 unsigned host_effective_cpus();
-// fn(begin, end) over [0, n) on up to SP_HOST_THREADS (default: host_effective_cpus(), at most 64) host threads
+// Ranks (processes with a context each, one per GPU) that share this host and its CPUs: sp_set_option(SP_OPT_HOST_RANKS), else the
+// environment (SP_HOST_RANKS, then torch.distributed.run's LOCAL_WORLD_SIZE), else 1.  Every host-side thread count of the library
+// (gather pool of the row-major upload, host_parallel_for) is sized from host_cpu_budget() = host_effective_cpus() / host_ranks(),
+// at least 1; with more ranks than CPUs (host_oversubscribed) waits block instead of polling.
+unsigned host_ranks();
+void set_host_ranks(unsigned ranks);
+unsigned host_cpu_budget();
+bool host_oversubscribed();
+// fn(begin, end) over [0, n) on up to SP_HOST_THREADS (default: host_cpu_budget(), at most 64) host threads
 void host_parallel_for(size_t n, size_t min_chunk, const std::function<void(size_t, size_t)>& fn);
 
 struct MemorySegment { uint8_t type; uint64_t start, end; };  // type 0 RangeCheck, 1 Output (air.rs:156-160)

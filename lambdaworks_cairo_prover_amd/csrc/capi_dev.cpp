@@ -123,6 +123,10 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
             if (value != SP_MERKLE_KECCAK256 && value != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
             c->opt_merkle_backend = (int)value;
             break;
+        case SP_OPT_HOST_RANKS:
+            if (value < 0 || value > 1024) return SP_E_INVALID_ARG;
+            sp::set_host_ranks((unsigned)value);      // (process-wide: one context per process and GPU; 0 = back to the environment)
+            return SP_OK;                     // (shapes no prover buffer; the gather pool follows at the next upload)
         case SP_OPT_DEVICE_TRACE:
             c->opt_device_trace = value != 0;
             return SP_OK;                     // (shapes no prover buffer)

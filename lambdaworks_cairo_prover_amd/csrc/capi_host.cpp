@@ -100,6 +100,13 @@ int sp_host_cpus(int* count_out) {
     return SP_OK;
 }
 
+int sp_host_cpu_budget(int* budget_out, int* ranks_out) {
+    if (!budget_out) return SP_E_INVALID_ARG;
+    *budget_out = (int)sp::host_cpu_budget();
+    if (ranks_out) *ranks_out = (int)sp::host_ranks();
+    return SP_OK;
+}
+
 int sp_fe_to_device(int enc, const uint8_t* in, uint64_t n, uint8_t* out) {
     if (!in || !out) return SP_E_INVALID_ARG;
     fe* o = reinterpret_cast<fe*>(out);

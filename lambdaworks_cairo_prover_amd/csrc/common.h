@@ -26,8 +26,12 @@ void sp_set_error(const std::string& s);
 // hipStreamSynchronize costs ~20 us of wake-up each, so the first 100 us are spent polling; a wait that lasts longer (the LDE and
 // hashing of a trace segment, a collective of another rank) is not latency-critical any more and goes to sleep in the runtime
 // instead of burning a core - eight ranks polling through every collective took 2m21 of system time in a 37 s test.
+// With more ranks on the host than CPUs for them (sp::host_oversubscribed(): SP_OPT_HOST_RANKS against the cgroup's CPUs) nothing
+// polls: a spinning rank would only take the core another rank's launch thread needs.
 #include <chrono>
+namespace sp { bool host_oversubscribed(); }
 static inline hipError_t sp_stream_wait_polling(hipStream_t st) {
+    if (sp::host_oversubscribed()) return hipStreamSynchronize(st);
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0;; ++spins) {
         const hipError_t e = hipStreamQuery(st);

@@ -360,7 +360,11 @@ int StarkProver::ensure_ring_and_pool() {
     // 100 ms period and the upload is a burst of a quarter of a proof, so twice the quota's CPUs for that long stays inside it
     // (24 threads move 55-80 GB/s where the quota's own 14 move 40); far beyond it the whole process gets throttled - the 130 ms
     // proofs of a 64-thread gather in a 16-CPU container.
-    if (!pool_) pool_ = new HostPool(std::max(2u, std::min(c_->opt_upload_threads, 2 * host_effective_cpus())) - 1u);
+    // Per HOST, not per context: with R ranks on the host (SP_OPT_HOST_RANKS / LOCAL_WORLD_SIZE) each pool gets the R-th part of that -
+    // eight ranks of a 16-CPU container used to start 8 x 23 gather threads.
+    const unsigned want = std::max(2u, std::min(c_->opt_upload_threads, 2 * host_cpu_budget()));
+    if (pool_ && pool_->size() != want) { delete pool_; pool_ = nullptr; }      // (the option changed between two proofs)
+    if (!pool_) pool_ = new HostPool(want - 1u);
     const size_t chunk = upload_chunk_bytes();
     if (stage_bytes_ < chunk) {
         for (auto& p : h_stage_) { if (p) (void)hipHostFree(p); p = nullptr; }
@@ -521,6 +525,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
     // boxes a barrier every 0.7 ms met a descheduled thread most of the time.  The calling thread does not gather: it enqueues
     // the DMAs of a chunk when its last block is in, the group's transforms behind the last chunk of a group, and hands slots
     // back when their DMA has completed.
+    const bool yield_idle = host_cpu_budget() < 2;   // this thread shares its core with a gather worker (or another rank): give it up when idle
     auto orchestrate = [&]() -> int {
         size_t k = 0, d = 0;   // next chunk to send, next chunk whose DMA completion is awaited
         uint64_t idle_spins = 0;
@@ -576,7 +581,7 @@ int StarkProver::commit_trace_pipelined(int segment, const uint8_t* rows_host, u
                 progress = true;
             }
             if (progress) { idle_since = 0.0; continue; }
-            __builtin_ia32_pause();
+            if (yield_idle) std::this_thread::yield(); else __builtin_ia32_pause();
             if ((++idle_spins & 0xfffffu) == 0) {   // (~every few ms) a watchdog: neither a block gathered nor a DMA completed for 60 s
                 const double now = wall_ms();
                 if (idle_since == 0.0) idle_since = now;

@@ -1,0 +1,79 @@
+"""`python bench.py --gpus N` must not be able to hang or to end without its ONE JSON line: the launcher watches
+every rank, a rank that dies or never joins ends the job within the stated timeouts, the line carries the reason, the code is non-zero.
+No GPU needed: the injected fault strikes before the rendezvous, and nothing touches a device until the rendezvous has succeeded."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "config", "error"}
+
+
+def run_bench(extra_env, *argv, timeout=170):
+    env = dict(os.environ, **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=env, capture_output=True, text=True, timeout=timeout)
+    return r, time.monotonic() - t0
+
+
+def the_one_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-1500:]
+    return json.loads(lines[0])
+
+
+def test_a_rank_that_exits_before_the_rendezvous_ends_the_job_quickly():
+    r, took = run_bench({"SP_BENCH_FAULT_RANK": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline")
+    line = the_one_line(r.stdout)
+    assert r.returncode != 0 and took < 60, (r.returncode, took)
+    assert KEYS <= set(line) and line["value"] is None and line["n_gpus"] == 2
+    assert "rank 1 exited with code 3" in line["error"] or "terminated" in line["error"], line["error"]
+
+
+def test_four_ranks_one_missing():
+    r, took = run_bench({"SP_BENCH_FAULT_RANK": "3"}, "--gpus", "4", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline")
+    line = the_one_line(r.stdout)
+    assert r.returncode != 0 and took < 90 and line["value"] is None and line["n_gpus"] == 4
+
+
+def test_a_rank_that_hangs_before_the_rendezvous_is_timed_out():
+    """Rank 1 sleeps for ever: the others' rendezvous gives up after SP_BENCH_INIT_TIMEOUT_S, rank 0 prints the reason, the launcher
+    terminates the sleeper."""
+    r, took = run_bench({"SP_BENCH_FAULT_RANK": "1", "SP_BENCH_FAULT": "hang", "SP_BENCH_INIT_TIMEOUT_S": "15"},
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline")
+    line = the_one_line(r.stdout)
+    assert r.returncode != 0 and took < 120, (r.returncode, took)
+    assert line["value"] is None and "rendezvous" in line["error"], line
+
+
+def test_the_overall_deadline_ends_a_job_that_never_finishes():
+    """Same sleeper, but the rendezvous timeout is long: the ranks' own deadline (SP_BENCH_DEADLINE_S) fires on a timer thread."""
+    r, took = run_bench({"SP_BENCH_FAULT_RANK": "1", "SP_BENCH_FAULT": "hang", "SP_BENCH_INIT_TIMEOUT_S": "600", "SP_BENCH_DEADLINE_S": "12"},
+                        "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline")
+    line = the_one_line(r.stdout)
+    assert r.returncode != 0 and took < 120, (r.returncode, took)
+    assert line["value"] is None and "deadline" in line["error"], line
+
+
+def test_under_torchrun_rank_0_still_prints_its_line_when_a_peer_dies():
+    """The driver's own command line: torch.distributed.run terminates the other workers when one fails; rank 0's SIGTERM handler (or its
+    rendezvous timeout) leaves the JSON line on stdout."""
+    env = dict(os.environ, SP_BENCH_FAULT_RANK="1", SP_BENCH_INIT_TIMEOUT_S="20")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=170)
+    took = time.monotonic() - t0
+    assert r.returncode != 0 and took < 150
+    line = the_one_line(r.stdout)
+    assert line["value"] is None and line["n_gpus"] == 2 and line["error"]

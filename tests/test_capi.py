@@ -117,3 +117,39 @@ def test_host_side_helpers_of_round_3(hip_lib):
         assert api.host_bind_to_device(0) == -1 and os.sched_getaffinity(0) == before
     assert hip_lib.sp_host_bind_to_device(-1, None) == _lib.SP_E_INVALID_ARG
     assert api.poseidon_host(2, [0]) == api.poseidon_host(3, [0, 0, 1])[0]     # hash_single(x) = permute(x, 0, 1)[0]
+
+
+def test_integration_rust_block_declares_every_header_symbol():
+    """INTEGRATION.md section 2 is the binding a maintainer of the reference would paste: it must name every entry point of the header
+    (VERDICT r4 item 12 - 16 of 75 were missing and nothing kept the two in step), and nothing the header does not have."""
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    start = integ.index("```rust")
+    rust = integ[start:integ.index("```\n", start + 10)]
+    have = set(re.findall(r"pub fn (sp_[a-z0-9_]+)\s*\(", rust))
+    want = set(declared_symbols())
+    assert want - have == set(), f"declared in include/stark252_hip.h, absent from INTEGRATION.md's extern block: {sorted(want - have)}"
+    assert have - want == set(), f"in INTEGRATION.md's extern block, not in the header: {sorted(have - want)}"
+    # the option keys the block mentions by number agree with the header's enum
+    header = open(os.path.join(ROOT, "include", "stark252_hip.h")).read()
+    enum = dict((k, int(v)) for k, v in re.findall(r"\b(SP_OPT_[A-Z_]+)\s*=\s*(\d+)", header))
+    for k, v in re.findall(r"\b(SP_OPT_[A-Z_]+)\s*=\s*(\d+)", rust):
+        assert enum.get(k) == int(v), (k, v, enum.get(k))
+
+
+def test_host_thread_budget_is_per_host_not_per_context():
+    """sp_host_cpu_budget: the CPUs of the process divided by the ranks sharing the host - from SP_HOST_RANKS, else
+    from LOCAL_WORLD_SIZE as torch.distributed.run exports it; never below 1."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lambdaworks_cairo_prover_amd import api\n"
+            "print(api.host_cpus(), *api.host_cpu_budget())" % ROOT)
+    def probe(**env):
+        e = {k: v for k, v in os.environ.items() if k not in ("SP_HOST_RANKS", "LOCAL_WORLD_SIZE")}
+        e.update(env)
+        return tuple(int(x) for x in subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, check=True).stdout.split())
+    cpus, budget, ranks = probe()
+    assert (budget, ranks) == (cpus, 1)
+    assert probe(LOCAL_WORLD_SIZE="4") == (cpus, max(1, cpus // 4), 4)
+    assert probe(LOCAL_WORLD_SIZE="4", SP_HOST_RANKS="2") == (cpus, max(1, cpus // 2), 2)
+    assert probe(SP_HOST_RANKS="1000") == (cpus, 1, 1000)
