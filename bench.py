@@ -997,7 +997,10 @@ def main():
     ctx = api.Context(device=dev_index)
 
     def barrier(stage="barrier"):
+        """cuda synchronize + barrier; returns the moment THIS rank's device work was done (before it waited for the others)."""
         torch.cuda.synchronize()
+        ctx.sync()
+        t_synced = time.perf_counter()
         if dist is not None:
             import datetime
             guard.stage = stage
@@ -1005,7 +1008,7 @@ def main():
                 dist.monitored_barrier(timeout=datetime.timedelta(seconds=BARRIER_TIMEOUT_S))
             except Exception as e:
                 guard.fail(f"{stage}: {e!r}"[:600])
-        ctx.sync()
+        return t_synced
 
     self_warm = warm_until(ctx, lambda: ctx.ntt_dev(data.data_ptr(), n))   # clock ramp, independent of --warmup
     for _ in range(args.warmup):
@@ -1016,8 +1019,9 @@ def main():
     for _ in range(args.steps):
         ctx.ntt_dev(data.data_ptr(), n)  # asynchronous launches, back to back on the context stream
     kernel_ms = [ctx.timer_stop() / args.steps]
-    barrier("barrier behind the timed region")
-    dt = time.perf_counter() - t0
+    # each rank's K steps end when ITS device is idle; the closing barrier's own latency (a gloo round over N ranks, ~1 ms beside a
+    # 7 ms region at --steps 20) is not NTT time.  The figure reported is the MAX of these over the ranks.
+    dt = barrier("barrier behind the timed region") - t0
     if dist is not None:
         guard.stage = "max over ranks"
         t = torch.tensor([dt], dtype=torch.float64)
