@@ -371,6 +371,7 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
             dt = float(t.item())
         times.append(dt)
     rounds_dev = ctx.last_round_ms()
+    info = ctx.last_proof_info()
     host_ms, run_ms, runcols_ms, up_rows, up_run = [], [], [], None, None
     ctx.cairo_prove(trace, run.public_inputs_c, opt)        # (first call: pinned staging ring, gather threads)
     ctx.cairo_prove_run(run, opt)
@@ -406,6 +407,7 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
     return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": rounds_dev, "trace_rows": run.n_rows,
             "trace_cols": 52, "blowup": blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
+            "interpolation_sharded": info.get("interpolation_sharded"), "groups": info.get("groups"),
             "proof_gen_ms_from_host_buffer": min(host_ms), "proof_gen_ms_from_host_buffer_all": host_ms, "upload": up_rows,
             "proof_gen_ms_from_run": min(run_ms), "proof_gen_ms_from_run_all": run_ms, "upload_run": up_run,
             "proof_gen_ms_from_run_host_table_all": runcols_ms, "proofs_run": calls[0] + 8,
@@ -538,7 +540,9 @@ def compact_line(full):
     if isinstance(ap, dict) and "ms" in ap:
         summ["air_prove"] = {k: _r(ap.get(k)) for k in ("air", "rows", "blowup", "ms")}
     if isinstance(full.get("rccl"), dict):
-        summ["rccl"] = dict({k: full["rccl"].get(k) for k in ("world", "backend", "devices_shared")}, selftest=full.get("transport_selftest"))
+        lk = full["rccl"].get("link") or {}
+        summ["rccl"] = dict({k: full["rccl"].get(k) for k in ("world", "backend", "devices_shared", "interpolation_sharded")}, selftest=full.get("transport_selftest"),
+                            link_gbs=[_r(lk.get("allgather_gbs_per_link"), 1), _r(lk.get("alltoall_gbs_per_link"), 1)], link_ms=[_r(lk.get("allgather_ms"), 3), _r(lk.get("alltoall_ms"), 3)])
     line["summary"] = summ
     return line
 
@@ -740,7 +744,11 @@ def proof_child(args):
         stats = ctx.comm_stats()
         result["rccl"] = {"world": stats["world"], "backend": "rccl" if transport == "rccl" else "gloo-staged hook", "devices_shared": shared,
                           "allgather_calls": stats["allgather_calls"], "allgather_bytes": stats["allgather_bytes"],
-                          "alltoall_calls": stats["alltoall_calls"], "alltoall_bytes": stats["alltoall_bytes"]}
+                          "alltoall_calls": stats["alltoall_calls"], "alltoall_bytes": stats["alltoall_bytes"],
+                          # sp_comm_measure (sp_comm_init_rccl runs it once, 64 MB per rank): GB/s per link and direction, minimum over the
+                          # ranks - what SP_OPT_SHARD_INTERPOLATION = 2 decided from; zeros under the staged hooks (nothing measured)
+                          "link": ctx.comm_measure(0),
+                          "interpolation_sharded": {k: result[k].get("interpolation_sharded") for k in ("proof", "proof_cfg4") if isinstance(result.get(k), dict)}}
         ctx.close()
     except Exception as e:
         result["error"] = repr(e)

@@ -126,6 +126,17 @@ int sp_comm_stats(sp_ctx* ctx, uint64_t out[6]);
 /* Checks the installed transport (RCCL or hooks): one all-gather and, if installed, one all-to-all of rank-stamped blocks of
  * bytes_per_block bytes (a multiple of 8); every rank must call it.  0 = both deliver the layout documented above. */
 int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
+/* Times the installed transport - every rank must call it: one all-gather and (if installed) one all-to-all of bytes_per_rank bytes
+ * per rank, after an untimed one of each.  out = {all-gather ms, its GB/s per link and direction, all-to-all ms, its GB/s per link
+ * and direction, bytes per rank, world}: what a rank received from the others / time / (world - 1) links - the unit of
+ * SP_OPT_LINK_GBS - as the MINIMUM over the ranks, so every rank holds the same figures.  SP_OPT_SHARD_INTERPOLATION = 2 decides
+ * from the all-gather's rate unless the caller stated SP_OPT_LINK_GBS.  sp_comm_init_rccl runs it once (64 MB per rank; environment
+ * SP_COMM_MEASURE_MB, 0 = not at all).  bytes_per_rank = 0: only read the stored figures back (zeros when nothing was measured). */
+int sp_comm_measure(sp_ctx* ctx, uint64_t bytes_per_rank, double out[6]);
+/* The decision rule of SP_OPT_SHARD_INTERPOLATION = 2 as a pure function: 1 when interpolating a trace segment by column (+ an
+ * all-gather of the coefficients) beats interpolating every column on every rank - 64 x 1.35e11 < (groups - 1) x link x log2(rows):
+ * the butterfly rate of one MI355X against what groups - 1 links deliver. */
+int sp_model_shard_interpolation(double link_gbs_per_direction, uint32_t groups, uint32_t log2_rows);
 /* Tuning knobs of the sharded prover (defaults in parentheses):
  *   SP_OPT_FRI_SHARD_MIN_LOG (16)  FRI layers with at least 2^value leaves keep their evaluations and trees sharded; smaller
  *                                  layers are all-gathered once and continue replicated (fri/mod.rs:20-72 is sequential in the layers);
@@ -133,7 +144,8 @@ int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
  *                                  coefficients all-gathered (prover.rs:161-185, trace.rs:104-110); 0: every rank interpolates all columns;
  *                                  2: whichever is faster for the shape on the link model - a rank saves (1 - 1/G) of the inverse transforms
  *                                  and receives (1 - 1/G) of the coefficients, which pays when (G - 1) x link rate x log2 n > 64 x 1.35e11.
- *   SP_OPT_LINK_GBS (46)           GB/s one xGMI link delivers per direction, for that decision (76.8 GB/s x an assumed 0.6).
+ *   SP_OPT_LINK_GBS (46)           GB/s one xGMI link delivers per direction, for that decision.  Unset: the rate sp_comm_measure found
+ *                                  (sp_comm_init_rccl measures once per communicator), else 46 (76.8 GB/s x an assumed 0.6).
  *   SP_OPT_UPLOAD_THREADS (24)     host threads that gather the column groups of a row-major host trace into pinned memory
  *                                  (sp_cairo_prove / sp_commit_trace from host buffers above 64 MB).
  *   SP_OPT_HOST_RANKS (env)        how many ranks (processes, one context and GPU each) share this HOST.  Process-wide.  Every host thread

@@ -646,6 +646,21 @@ def _ctx_comm_selftest(self, bytes_per_block=1 << 20):
     check(self._lib.sp_comm_selftest(self._h, ctypes.c_uint64(bytes_per_block)))
 
 
+def _ctx_comm_measure(self, bytes_per_rank=64 << 20):
+    """sp_comm_measure (every rank calls it): the transport's all-gather and all-to-all timed at bytes_per_rank; 0 = read back."""
+    out = (ctypes.c_double * 6)()
+    check(self._lib.sp_comm_measure(self._h, ctypes.c_uint64(int(bytes_per_rank)), out))
+    return {"allgather_ms": out[0], "allgather_gbs_per_link": out[1], "alltoall_ms": out[2], "alltoall_gbs_per_link": out[3],
+            "bytes_per_rank": int(out[4]), "world": int(out[5])}
+
+
+def model_shard_interpolation(link_gbs, groups, log2_rows):
+    """sp_model_shard_interpolation: the decision rule of SP_OPT_SHARD_INTERPOLATION = 2 (no GPU needed)."""
+    lib = _lib.load()
+    lib.sp_model_shard_interpolation.argtypes = [ctypes.c_double, ctypes.c_uint32, ctypes.c_uint32]
+    return int(lib.sp_model_shard_interpolation(float(link_gbs), int(groups), int(log2_rows)))
+
+
 def _ctx_comm_stats(self):
     out = (ctypes.c_uint64 * 6)()
     check(self._lib.sp_comm_stats(self._h, out))
@@ -681,8 +696,9 @@ Context.init_null = _ctx_init_null
 Context.set_collective_async = _ctx_set_collective_async
 Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
+Context.comm_measure = _ctx_comm_measure
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
-            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS", "SP_OPT_HOST_RANKS", "host_cpu_budget", "last_error",
+            "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS", "SP_OPT_HOST_RANKS", "host_cpu_budget", "last_error", "model_shard_interpolation",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
             "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

@@ -3,6 +3,9 @@
 #include "ctx.h"
 #include "cairo_host.h"
 #include <rccl/rccl.h>
+#include <chrono>
+#include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -114,6 +117,7 @@ int sp_set_option(sp_ctx* c, int key, int64_t value) {
         case SP_OPT_LINK_GBS:
             if (value < 1 || value > 10000) return SP_E_INVALID_ARG;
             c->opt_link_gbs = (double)value;
+            c->opt_link_gbs_explicit = true;      // the caller's word beats a measurement (sp_comm_measure)
             break;
         case SP_OPT_UPLOAD_THREADS:
             if (value < 1 || value > 128) return SP_E_INVALID_ARG;
@@ -254,7 +258,88 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     SP_TRY(sp_set_collective(c, world, rank, rccl_allgather, rc));
     SP_TRY(sp_set_collective_async(c, rccl_allgather_async));
     SP_TRY(sp_set_alltoall_async(c, rccl_alltoall_async));
-    return sp_set_alltoall(c, rccl_alltoall);
+    SP_TRY(sp_set_alltoall(c, rccl_alltoall));
+    // One timed all-gather and all-to-all per communicator (64 MB per rank; SP_COMM_MEASURE_MB, 0 = none): opens RCCL's channels
+    // before the first proof needs them, and gives SP_OPT_SHARD_INTERPOLATION = 2 a measured link rate instead of an assumed one.
+    uint64_t mb = 64;
+    if (const char* e = std::getenv("SP_COMM_MEASURE_MB")) mb = (uint64_t)std::min(1024, std::max(0, std::atoi(e)));
+    if (world > 1 && mb) SP_TRY(sp_comm_measure(c, mb << 20, nullptr));
+    return SP_OK;
+}
+
+// The link model behind SP_OPT_SHARD_INTERPOLATION = 2 as a pure function (unit-tested with injected rates): interpolation by column
+// saves a rank (1 - 1/G) of the size-n inverse transforms - n log2(n) / 2 butterflies per column at ~1.35e11 / s - and makes it receive
+// (1 - 1/G) of the coefficients, 32 n bytes per column, over G - 1 links: it pays when 64 x 1.35e11 < (G - 1) x link bytes/s x log2 n.
+int sp_model_shard_interpolation(double link_gbs_per_direction, uint32_t groups, uint32_t log2_rows) {
+    if (groups < 2 || !(link_gbs_per_direction > 0)) return 0;
+    return 64.0 * 1.35e11 < (double)(groups - 1) * link_gbs_per_direction * 1e9 * (double)log2_rows ? 1 : 0;
+}
+
+// Times the installed transport: one all-gather and one all-to-all of bytes_per_rank bytes per rank (after an untimed one of each that
+// opens RCCL's channels), HIP events on the context stream around the stream-ordered forms, wall time around the blocking ones.  The
+// rate of a collective is what a rank RECEIVED from the others divided by the time and by the world - 1 links it arrived over (xGMI
+// is point-to-point: GB/s per link and direction, the unit of SP_OPT_LINK_GBS); the minimum over the ranks (one more tiny all-gather)
+// is stored, so that every rank draws the same conclusion from it.  bytes_per_rank = 0 only reads the stored figures back.
+int sp_comm_measure(sp_ctx* c, uint64_t bytes_per_rank, double out[6]) {
+    if (!c || bytes_per_rank % 8) return SP_E_INVALID_ARG;
+    if (bytes_per_rank == 0 || c->world < 2) {
+        if (out) for (int i = 0; i < 6; ++i) out[i] = c->measured_link[i];
+        return SP_OK;
+    }
+    if (!c->allgather) { sp_set_error("sp_comm_measure: no collective installed"); return SP_E_STATE; }
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    const uint64_t W = (uint64_t)c->world, per_pair = std::max<uint64_t>(8, (bytes_per_rank / W) & ~(uint64_t)7);
+    DevBuf send, recv, small;
+    SP_TRY(send.alloc(std::max(bytes_per_rank, W * per_pair)));
+    SP_TRY(recv.alloc(std::max(W * bytes_per_rank, W * per_pair)));
+    SP_TRY(small.alloc(W * 16 + 16));
+    SP_HIP_CHECK(hipMemsetAsync(send.p, 0x5a, std::max(bytes_per_rank, W * per_pair), c->stream));
+    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    SP_HIP_CHECK(hipEventCreate(&e0));
+    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return SP_E_HIP; }
+    auto timed = [&](bool a2a, double* ms) -> int {
+        for (int rep = 0; rep < 2; ++rep) {      // the first call of each opens the channels
+            const auto t0 = std::chrono::steady_clock::now();
+            int rc = 0;
+            if (a2a ? (c->alltoall_async != nullptr) : (c->allgather_async != nullptr)) {
+                SP_HIP_CHECK(hipEventRecord(e0, c->stream));
+                rc = a2a ? c->alltoall_async(c->allgather_user, send.p, recv.p, per_pair, c->stream) : c->allgather_async(c->allgather_user, send.p, recv.p, bytes_per_rank, c->stream);
+                SP_HIP_CHECK(hipEventRecord(e1, c->stream));
+                SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+                float f = 0.f;
+                SP_HIP_CHECK(hipEventElapsedTime(&f, e0, e1));
+                *ms = (double)f;
+            } else {
+                rc = a2a ? c->alltoall(c->allgather_user, send.p, recv.p, per_pair) : c->allgather(c->allgather_user, send.p, recv.p, bytes_per_rank);
+                *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (rc != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
+        }
+        return SP_OK;
+    };
+    double ag_ms = 0.0, a2a_ms = 0.0;
+    int rc = timed(false, &ag_ms);
+    if (rc == SP_OK && (c->alltoall || c->alltoall_async)) rc = timed(true, &a2a_ms);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    SP_TRY(rc);
+    double mine[2] = {ag_ms > 0 ? (double)bytes_per_rank / (ag_ms * 1e-3) / 1e9 : 0.0,        // (W - 1) B received over W - 1 links
+                      a2a_ms > 0 ? (double)per_pair / (a2a_ms * 1e-3) / 1e9 : 0.0};
+    // the minimum over the ranks, through the transport itself
+    std::vector<double> all(2 * W, 0.0);
+    SP_HIP_CHECK(hipMemcpy(small.p, mine, 16, hipMemcpyHostToDevice));
+    uint8_t* gathered = small.as<uint8_t>() + 16;
+    if (c->allgather(c->allgather_user, small.p, gathered, 16) != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
+    SP_HIP_CHECK(hipMemcpy(all.data(), gathered, W * 16, hipMemcpyDeviceToHost));
+    double ag_min = all[0], a2a_min = all[1];
+    for (uint64_t r = 1; r < W; ++r) { ag_min = std::min(ag_min, all[2 * r]); a2a_min = std::min(a2a_min, all[2 * r + 1]); }
+    c->measured_link[0] = ag_ms; c->measured_link[1] = ag_min; c->measured_link[2] = a2a_ms; c->measured_link[3] = a2a_min;
+    c->measured_link[4] = (double)bytes_per_rank; c->measured_link[5] = (double)W;
+    if (out) for (int i = 0; i < 6; ++i) out[i] = c->measured_link[i];
+    // (the prover reads the figure in setup(): a shape set up under the old one is set up again)
+    delete c->prover_state_deleter_holder;
+    c->prover_state_deleter_holder = nullptr;
+    return SP_OK;
 }
 
 // Exercises the installed transport: every rank contributes rank-stamped blocks to an all-gather and (when an all-to-all hook

@@ -37,7 +37,12 @@ struct sp_ctx {
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
     int opt_shard_interpolation = 2;          // 0 replicated, 1 by column + coefficient all-gather, 2 whichever the link model makes faster
-    double opt_link_gbs = 46.0;               // what one xGMI link delivers per direction (76.8 GB/s x 0.6): the model behind mode 2
+    double opt_link_gbs = 46.0;               // what one xGMI link delivers per direction (76.8 GB/s x 0.6): the model behind mode 2 ...
+    bool opt_link_gbs_explicit = false;       // ... when the caller stated it (SP_OPT_LINK_GBS); otherwise a measurement, when there is one, wins
+    // sp_comm_measure: {all-gather ms, GB/s per link and direction of that all-gather, all-to-all ms, GB/s per link of that all-to-all,
+    // bytes per rank, world}; the rates are the MINIMUM over the ranks, so every rank takes the same decision from them.  0 = not measured.
+    double measured_link[6] = {0, 0, 0, 0, 0, 0};
+    double link_gbs_for_model() const { return opt_link_gbs_explicit ? opt_link_gbs : (measured_link[1] > 0 ? measured_link[1] : opt_link_gbs); }
     uint32_t opt_upload_threads = 24;
     int opt_merkle_backend = SP_MERKLE_KECCAK256;
     bool opt_device_trace = true;             // sp_cairo_prove_run builds the main trace on the device from the run's registers and memory

@@ -138,13 +138,14 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     // Interpolation by column with an all-gather of the coefficients, or on every rank?  A rank saves
     // (1 - 1/G) of the size-n inverse transforms (n log n / 2 butterflies per column at ~1.35e11 / s) and receives (1 - 1/G) of the
     // coefficients (32 n bytes per column over G - 1 links): sharding pays when  64 x 1.35e11 < (G - 1) x link bytes/s x log2 n.
-    // On 46 GB/s per link that needs (G - 1) log2 n > 188 - no shape this prover sees - so mode 2 interpolates everywhere unless the
-    // caller states a faster fabric (SP_OPT_LINK_GBS); an exchange that overlaps the transforms completely (stream-ordered
-    // transport) is worth at most the inverse transforms it replaces, 3 - 5 ms at 2^20 rows.
+    // (sp_model_shard_interpolation.)  On 46 GB/s per link that needs (G - 1) log2 n > 188 - no shape this prover sees - so mode 2
+    // interpolates everywhere unless the fabric is faster: the rate sp_comm_measure found (sp_comm_init_rccl runs it once per
+    // communicator) or the one the caller states (SP_OPT_LINK_GBS wins); an exchange that overlaps the transforms completely
+    // (stream-ordered transport) is worth at most the inverse transforms it replaces, 3 - 5 ms at 2^20 rows.
     shard_interp_ = false;
     if (G_ > 1) {
         if (c_->opt_shard_interpolation == 1) shard_interp_ = true;
-        else if (c_->opt_shard_interpolation == 2) shard_interp_ = 64.0 * 1.35e11 < (double)(G_ - 1) * c_->opt_link_gbs * 1e9 * (double)k;
+        else if (c_->opt_shard_interpolation == 2) shard_interp_ = sp_model_shard_interpolation(c_->link_gbs_for_model(), G_, (uint32_t)k) == 1;
     }
     if (G_ > 1 && N_ < 2ull * G_ * G_) { sp_set_error("setup: the LDE domain is too small for this many ranks"); return SP_E_INVALID_ARG; }
     double _tp = wall_ms();

@@ -153,3 +153,17 @@ def test_host_thread_budget_is_per_host_not_per_context():
     assert probe(LOCAL_WORLD_SIZE="4") == (cpus, max(1, cpus // 4), 4)
     assert probe(LOCAL_WORLD_SIZE="4", SP_HOST_RANKS="2") == (cpus, max(1, cpus // 2), 2)
     assert probe(SP_HOST_RANKS="1000") == (cpus, 1, 1000)
+
+
+def test_interpolation_mode_follows_the_link_rate(hip_lib):
+    """SP_OPT_SHARD_INTERPOLATION = 2: by column when 64 x 1.35e11 < (G - 1) x link x log2 n - injected rates on both
+    sides of the threshold, for the shapes BASELINE.json names.  sp_comm_measure feeds the rule a measured rate (GPU tests)."""
+    rule = api.model_shard_interpolation
+    threshold = lambda groups, logn: 64 * 1.35e11 / ((groups - 1) * logn) / 1e9      # GB/s per link and direction
+    for groups, logn in ((8, 20), (4, 19), (8, 24), (2, 19), (8, 10)):
+        t = threshold(groups, logn)
+        assert rule(t * 0.99, groups, logn) == 0 and rule(t * 1.01, groups, logn) == 1, (groups, logn, t)
+    assert rule(46.0, 8, 20) == 0 and rule(46.0, 4, 19) == 0           # the assumed 76.8 x 0.6: interpolate everywhere (DESIGN section 9)
+    assert rule(76.8, 8, 20) == 1                                      # a link at its nominal rate would flip configs[2] x 8 ...
+    assert rule(76.8, 4, 19) == 0                                      # ... but not configs[3] x 4 (threshold 151.6 GB/s)
+    assert rule(1e6, 1, 20) == 0 and rule(0.0, 8, 20) == 0 and rule(-1.0, 8, 20) == 0

@@ -354,3 +354,28 @@ def test_sharded_program_air(world, n, options, oracle):
         p.join(timeout=60)
     for r in range(world):
         assert got[r] == want, (r, got[r][:400])
+
+
+def test_link_rate_decides_the_interpolation_mode_null_transport():
+    """Mode 2 of SP_OPT_SHARD_INTERPOLATION on rank 0's share of 8 ranks (timing-only transport): the assumed 46 GB/s interpolates
+    everywhere, a stated faster fabric (SP_OPT_LINK_GBS) shards by column, and sp_comm_measure's figures - here of the null
+    transport, i.e. of HBM memsets - replace the assumption when the caller stated nothing."""
+    from lambdaworks_cairo_prover_amd import api
+    run = api.CairoRun.fibonacci(2000)          # 2^14 rows
+    opt = api.ProofOptions(8, 4, 3, 2)
+    with api.Context(device=0) as ctx:
+        ctx.init_null(8, 0)
+        assert ctx.comm_measure(0)["allgather_gbs_per_link"] == 0.0          # nothing measured yet
+        ctx.cairo_prove_run(run, opt)
+        assert ctx.last_proof_info()["interpolation_sharded"] == 0
+        m = ctx.comm_measure(64 << 20)                                       # "links" that are memsets: far beyond the threshold
+        assert m["world"] == 8 and m["allgather_ms"] > 0 and m["alltoall_ms"] > 0
+        expect = api.model_shard_interpolation(m["allgather_gbs_per_link"], 8, 14)
+        ctx.cairo_prove_run(run, opt)
+        assert ctx.last_proof_info()["interpolation_sharded"] == expect == 1, m
+        ctx.set_option(api.SP_OPT_LINK_GBS, 46)                              # the caller's word beats the measurement
+        ctx.cairo_prove_run(run, opt)
+        assert ctx.last_proof_info()["interpolation_sharded"] == 0
+        ctx.set_option(api.SP_OPT_LINK_GBS, 10000)
+        ctx.cairo_prove_run(run, opt)
+        assert ctx.last_proof_info()["interpolation_sharded"] == 1
