@@ -1,0 +1,154 @@
+"""Extract the inputs and expected outputs of the reference's remaining unit tests on the Cairo path into a JSON fixture
+(tests/golden/reference_unit_vectors.json).  Run in the build container only - /root/reference does not travel; the fixture does.
+
+Sources (numbers only: every FE::from(..) / FE::from_hex(..) / range literal of the test bodies):
+  /root/reference/src/cairo/execution_trace.rs
+      :637-659    test_rc_decompose                               (decompose_rc_values_into_trace_columns, :604-624)
+      :1164-1185  test_fill_range_check_values                    (get_rc_holes, :136-173)
+      :1187-1221  test_add_missing_values_to_offsets_column       (fill_rc_holes, :176-185)
+      :1223-1282  test_get_memory_holes_{no_codelen,inside_program_section,outside_program_section}   (get_memory_holes, :195-222)
+      :1284-1311  test_fill_memory_holes                          (fill_memory_holes, :227-255)
+  /root/reference/src/cairo/air.rs
+      :1246-1303  test_build_auxiliary_trace_add_program_in_public_input_section_works                (add_pub_memory_in_public_input_section, :475-494)
+      :1305-1374  test_build_auxiliary_trace_add_program_with_output_in_public_input_section_works
+      :1376-1409  test_build_auxiliary_trace_sort_columns_by_memory_address                           (sort_columns_by_memory_address, :519-523)
+
+Usage: python tests/golden/make_unit_test_vectors.py
+"""
+import json
+import os
+import re
+
+REF = "/root/reference/src/cairo"
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+VALUE = re.compile(r'(?:FE|FieldElement)::zero\(\)|(?:FE|FieldElement)::one\(\)|(?:FE|FieldElement)::from\(\s*(\d+)\s*\)|(?:FE|FieldElement)::from_hex\(\s*"([0-9a-fA-F]+)"\s*\)')
+
+
+def values(text):
+    out = []
+    for m in VALUE.finditer(text):
+        t = m.group(0)
+        if "zero()" in t:
+            out.append(0)
+        elif "one()" in t:
+            out.append(1)
+        elif m.group(1) is not None:
+            out.append(int(m.group(1)))
+        else:
+            out.append(int(m.group(2), 16))
+    return out
+
+
+def body_of(src, name):
+    start = src.index(f"fn {name}()")
+    nxt = src.find("#[test]", start)
+    return src[start:nxt if nxt > 0 else len(src)]
+
+
+def bracket(text, start):
+    """text of the vec![ ... ] that opens at or after `start` (balanced)."""
+    i = text.index("vec![", start) + 4
+    depth, j = 0, i
+    while True:
+        if text[j] == "[":
+            depth += 1
+        elif text[j] == "]":
+            depth -= 1
+            if depth == 0:
+                return text[i + 1:j], j
+        j += 1
+
+
+def let_vec(body, var):
+    m = re.search(rf"let (?:mut )?{var}(?::[^=]+)? = ", body)
+    txt, _ = bracket(body, m.end() - 1)
+    return values(txt)
+
+
+def main():
+    et = open(os.path.join(REF, "execution_trace.rs")).read()
+    air = open(os.path.join(REF, "air.rs")).read()
+    out = {}
+
+    # --- test_rc_decompose: three 128-bit values, eight 16-bit limb columns (least significant first)
+    b = body_of(et, "test_rc_decompose")
+    vals = [int(h, 16) for h in re.findall(r'let \w+ = FE::from_hex\("([0-9A-Fa-f]+)"\)', b)]
+    assert len(vals) == 3
+    row01 = [int(h, 16) for h in re.findall(r'assert_eq!\(row\[\d\], FE::from_hex\("([0-9A-Fa-f]+)"\)', b)]
+    col2 = {int(c): int(h, 16) for c, h in re.findall(r'assert_eq!\(decomposition_columns\[(\d)\]\[2\], FE::from_hex\("([0-9A-Fa-f]+)"\)', b)}
+    assert len(row01) == 2 and sorted(col2) == list(range(8))
+    out["rc_decompose"] = {"values": [hex(v) for v in vals], "columns": [[row01[0], row01[1], col2[c]] for c in range(8)]}
+
+    # --- test_fill_range_check_values
+    b = body_of(et, "test_fill_range_check_values")
+    cols = [(int(v), int(k)) for v, k in re.findall(r"vec!\[FieldElement::from\((\d+)\); (\d+)\]", b)]
+    out["fill_range_check_values"] = {"columns": [[v] * k for v, k in cols], "expected_col": let_vec(b, "expected_col"),
+                                      "rc_min": int(re.search(r"assert_eq!\(rc_min, (\d+)\)", b).group(1)),
+                                      "rc_max": int(re.search(r"assert_eq!\(rc_max, (\d+)\)", b).group(1))}
+
+    # --- test_add_missing_values_to_offsets_column: appended rows are zeros except the three offset columns
+    b = body_of(et, "test_add_missing_values_to_offsets_column")
+    off_dst = int(re.search(r"pub const OFF_DST: usize = (\d+);", open(os.path.join(REF, "air.rs")).read()).group(1))
+    off_op1 = int(re.search(r"pub const OFF_OP1: usize = (\d+);", open(os.path.join(REF, "air.rs")).read()).group(1))
+    n_cols = int(re.search(r"n_cols: (\d+),", b).group(1))
+    missing = let_vec(b, "missing_values")
+    rows = int(re.search(r"assert_eq!\(main_trace\.table\.len\(\), (\d+) \* (\d+)\)", b).group(2))
+    appended = re.findall(r"expected\.append\(&mut vec!\[\s*((?:FieldElement::from\(\d+\),?\s*)+)\]\);", b)
+    out["add_missing_values_to_offsets_column"] = {"n_cols": n_cols, "off_dst": off_dst, "off_op1": off_op1, "missing": missing, "rows_after": rows,
+                                                   "appended_offsets": [values(a) for a in appended]}
+
+    # --- get_memory_holes x 3
+    for name in ("no_codelen", "inside_program_section", "outside_program_section"):
+        b = body_of(et, f"test_get_memory_holes_{name}")
+        addrs = []
+        for lo, hi in re.findall(r"\((\d+)\.\.(\d+)\)\.map\(FE::from\)", b):
+            addrs += list(range(int(lo), int(hi)))
+        codelen = int(re.search(r"let codelen = (\d+);", b).group(1))
+        m = re.search(r"let expected_memory_holes(?::[^=]+)? = ", b)
+        rest = b[m.end():b.index(";", m.end())]
+        expected = [] if "Vec::new()" in rest else values(rest)
+        out[f"get_memory_holes_{name}"] = {"sorted_addrs": addrs, "codelen": codelen, "expected": expected}
+
+    # --- test_fill_memory_holes
+    b = body_of(et, "test_fill_memory_holes")
+    cells = {(c, int(r)): values(v)[0] for c, r, v in re.findall(r"trace_cols\[(FRAME_\w+)\]\[(\d)\] = ([^;]+);", b)}
+    holes = let_vec(b, "memory_holes")
+    asserts = {(c, int(r)): values(v)[0] for c, r, v in re.findall(r"assert_eq!\((\w+)\[(\d)\], ([^;]+)\);", b)}
+    names = {"frame_pc": "FRAME_PC", "dst_addr": "FRAME_DST_ADDR", "op0_addr": "FRAME_OP0_ADDR", "op1_addr": "FRAME_OP1_ADDR"}
+    out["fill_memory_holes"] = {"rows": [[cells[(c, r)] for c in ("FRAME_PC", "FRAME_DST_ADDR", "FRAME_OP0_ADDR", "FRAME_OP1_ADDR")] for r in (0, 1)],
+                                "holes": holes,
+                                "asserted_rows": [[asserts[(k, r)] for k in ("frame_pc", "dst_addr", "op0_addr", "op1_addr")] for r in (0, 1)]}
+    assert all(names[k] for k, _ in asserts)
+
+    # --- add_pub_memory_in_public_input_section x 2
+    for key, name in (("add_program", "test_build_auxiliary_trace_add_program_in_public_input_section_works"),
+                      ("add_program_with_output", "test_build_auxiliary_trace_add_program_with_output_in_public_input_section_works")):
+        b = body_of(air, name)
+        pm_txt = b[b.index("public_memory: HashMap::from(["):b.index("]),", b.index("public_memory: HashMap::from(["))]
+        pm = values(pm_txt)
+        pm = [[pm[i], pm[i + 1]] for i in range(0, len(pm), 2)]
+        seg = re.search(r"MemorySegment::Output, (\d+)\.\.(\d+)", b)
+        a, v = let_vec(b, "a"), let_vec(b, "v")
+        m1 = b.index("assert_eq!(\n            ap,")
+        ap, j = bracket(b, m1)
+        m2 = b.index("assert_eq!(\n            vp,")
+        vp, _ = bracket(b, m2)
+        out[key] = {"public_memory": pm, "output_range": [int(seg.group(1)), int(seg.group(2))] if seg else None, "a": a, "v": v,
+                    "ap": values(ap), "vp": values(vp)}
+
+    # --- sort_columns_by_memory_address
+    b = body_of(air, "test_build_auxiliary_trace_sort_columns_by_memory_address")
+    a, v = let_vec(b, "a"), let_vec(b, "v")
+    ap, _ = bracket(b, b.index("assert_eq!(\n            ap,"))
+    vp, _ = bracket(b, b.index("assert_eq!(\n            vp,"))
+    out["sort_columns_by_memory_address"] = {"a": a, "v": v, "ap": values(ap), "vp": values(vp)}
+
+    with open(os.path.join(HERE, "reference_unit_vectors.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    for k, v in out.items():
+        print(k, json.dumps(v)[:200])
+
+
+if __name__ == "__main__":
+    main()

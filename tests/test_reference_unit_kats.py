@@ -1,0 +1,238 @@
+"""The reference's remaining unit tests on the Cairo path, mirrored (VERDICT r4 "missing" item 2): vectors extracted from the Rust
+test bodies by tests/golden/make_unit_test_vectors.py (tests/golden/reference_unit_vectors.json), checked against
+
+* the product's host trace builder (csrc/cairo_host.cpp: plan_main_trace / fill_main_trace) through sp_cairo_run_from_arrays - the
+  entry point that takes cairo-vm's relocated registers, memory and builtin segments - on runs crafted so that the helper under
+  test sees exactly the reference test's input: decompose_rc_values_into_trace_columns (execution_trace.rs:604-624), get_rc_holes /
+  fill_rc_holes (:136-185), get_memory_holes (:195-222), fill_memory_holes (:227-255);
+* the CPU oracle (oracle/cairo_air.hpp): add_pub_memory_in_public_input_section and sort_columns_by_memory_address
+  (air.rs:475-523) through oracle_cairo_aux_trace, and the limb order of the range-check-builtin constraint (air.rs:1141-1160)
+  through oracle_cairo_transition on a frame that holds the reference's decomposition.
+tests/test_gpu_reference_unit_kats.py runs the same runs through the DEVICE trace builder and the device auxiliary trace."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from lambdaworks_cairo_prover_amd import api
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P = api.P
+FP0 = 32768          # with fp = 2^15 a raw (biased) offset IS the address it reaches: addr = fp + off - 2^15
+# dst, op0 and op1 all fp-relative (flag bits dst_reg, op0_reg, op1_fp), res = op1, nothing else: decodes, touches three cells
+FLAGS_FP = (1 << 0) | (1 << 1) | (1 << 3)
+PC, DST_ADDR, OP0_ADDR, OP1_ADDR = 19, 20, 21, 22
+OFF_DST, OFF_OP0, OFF_OP1 = 27, 28, 29
+
+
+def vectors():
+    with open(os.path.join(GOLDEN, "reference_unit_vectors.json")) as f:
+        return json.load(f)
+
+
+def inst(off_dst, off_op0, off_op1, flags=FLAGS_FP):
+    return off_dst | (off_op0 << 16) | (off_op1 << 32) | (flags << 48)
+
+
+def crafted_run(steps, program_size, extra_cells=(), segments=(), fp=FP0):
+    """steps: [(pc, (dst_addr, op0_addr, op1_addr))] - one instruction per step whose three operands sit at the given addresses.
+    The registers are inputs (nothing replays the program): ap = fp for every state.  Memory: the instruction words at their pcs, a
+    distinct value in every operand cell, zeros in the rest of the program section, `extra_cells` on top."""
+    mem = {}
+    for a in range(1, program_size + 1):
+        mem[a] = 0
+    for pc, (d, o0, o1) in steps:
+        mem[pc] = inst(d - fp + 32768, o0 - fp + 32768, o1 - fp + 32768)
+    for pc, ops in steps:
+        for a in ops:
+            mem.setdefault(a, 1000 + a)
+    mem.update(dict(extra_cells))
+    addrs = np.array(sorted(mem), dtype=np.uint64)
+    vals = api.felts_to_bytes([mem[int(a)] for a in addrs])
+    regs = np.array([(fp, fp, pc) for pc, _ in steps], dtype=np.uint64)
+    return api.CairoRun.from_arrays(regs, addrs, vals, program_size, segments)
+
+
+def ints(trace, rows, col):
+    return api.bytes_to_felts(np.ascontiguousarray(trace[rows, col]))
+
+
+# ---------------------------------------------------------------------------------------------------------------- crafted runs
+def rc_decompose_run():
+    v = vectors()["rc_decompose"]
+    values = [int(h, 16) for h in v["values"]]
+    # three steps that touch 4, 7, 10; the range-check builtin segment [20, 23) holds the three values of the reference test
+    steps = [(1, (4, 7, 10)), (2, (4, 7, 10)), (3, (4, 7, 10))]
+    return crafted_run(steps, 3, extra_cells=[(20 + i, x) for i, x in enumerate(values)], segments=[(0, 20, 23)]), v, values
+
+
+def rc_holes_run():
+    v = vectors()["fill_range_check_values"]
+    offs = [c[0] for c in v["columns"]]                       # 1, 4, 7: every step has exactly these three offsets
+    assert all(len(c) == 3 and len(set(c)) == 1 for c in v["columns"])
+    steps = [(pc, tuple(offs)) for pc in (1, 2, 3)]           # (fp = 2^15: the offsets are the addresses)
+    return crafted_run(steps, 3), v
+
+
+def missing_offsets_run():
+    v = vectors()["add_missing_values_to_offsets_column"]
+    lo, hi = min(v["missing"]) - 1, max(v["missing"]) + 1     # offsets 0 and 7 only: exactly 1..6 are missing, no padding
+    assert v["missing"] == list(range(lo + 1, hi))
+    fp = FP0 + 16                                              # (offset 0 must reach a positive address: addr = off + 16)
+    steps = [(1, (lo + 16, lo + 16, hi + 16)), (2, (lo + 16, hi + 16, hi + 16))]
+    return crafted_run(steps, 2, fp=fp), v
+
+
+def memory_holes_run(name):
+    v = vectors()[f"get_memory_holes_{name}"]
+    addrs = v["sorted_addrs"]
+    data = [a for a in addrs if a > 3]
+    assert addrs[:3] == [1, 2, 3]
+    # three steps at pc = 1, 2, 3 whose nine operand slots cover the remaining addresses (the last one repeated)
+    slots = (data + [data[-1]] * 9)[:9]
+    steps = [(pc, tuple(slots[3 * i:3 * i + 3])) for i, pc in enumerate((1, 2, 3))]
+    # get_memory_holes skips what lies in the program section; the reference calls it with codelen = 0 in one test, which no run
+    # can have (pc = 1 is a program cell) - codelen 3 gives the same answer there because no gap lies at or below 3
+    codelen = max(v["codelen"], 3)
+    assert all(h > codelen for h in v["expected"])
+    return crafted_run(steps, codelen), v
+
+
+def fill_memory_holes_run():
+    v = vectors()["fill_memory_holes"]
+    steps = [(r[0], tuple(r[1:])) for r in v["rows"]]          # pc = 1 and pc = 6; program section = cells 1..3
+    return crafted_run(steps, 3), v
+
+
+# ------------------------------------------------------------------------------------------------------------------ the checks
+def check_rc_decompose(trace, v, values):
+    assert trace.shape[1] == 43
+    for c in range(8):
+        assert ints(trace, slice(0, 3), 34 + c) == v["columns"][c], c
+    assert ints(trace, slice(0, 3), 42) == values
+    assert not np.any(trace[3:, 34:43])                         # resized with zeros behind the values (execution_trace.rs:369-377)
+
+
+def check_rc_holes(run, trace, v):
+    pi = run.public_inputs_c
+    assert (pi.range_check_min, pi.range_check_max) == (v["rc_min"], v["rc_max"])
+    rows = len(v["expected_col"]) // 3
+    got = [x for r in range(3, 3 + rows) for x in (ints(trace, r, OFF_DST)[0], ints(trace, r, OFF_OP0)[0], ints(trace, r, OFF_OP1)[0])]
+    assert got == v["expected_col"]
+
+
+def check_missing_offsets(trace, v):
+    steps = 2
+    for k, want in enumerate(v["appended_offsets"]):
+        row = [int.from_bytes(bytes(trace[steps + k, c]), "big") for c in range(v["n_cols"])]
+        assert row[v["off_dst"]:v["off_op1"] + 1] == want
+        assert not any(row[:v["off_dst"]]) and not any(row[v["off_op1"] + 1:])      # zeros_left, zeros_right (execution_trace.rs:177-178)
+
+
+def hole_rows(run, trace, n_holes):
+    """the address columns of the rows fill_memory_holes appended: behind the steps and the range-check-hole rows"""
+    steps = run.num_steps
+    r = steps
+    while r < trace.shape[0] and not np.any(trace[r, :OFF_DST]) and not np.any(trace[r, OFF_OP1 + 1:34]):   # rc-hole rows: zeros but the offsets
+        r += 1
+    rows = (n_holes + 3) // 4
+    flat = [int.from_bytes(bytes(trace[r + k, c]), "big") for k in range(rows) for c in (PC, DST_ADDR, OP0_ADDR, OP1_ADDR)]
+    return r, flat
+
+
+def check_memory_holes(run, trace, v):
+    expected = v["expected"]
+    r, flat = hole_rows(run, trace, len(expected))
+    assert flat[:len(expected)] == expected
+    # no further hole row: the next row is the first public-memory dummy access, whose address columns are zero (execution_trace.rs:89-96)
+    nxt = r + (len(expected) + 3) // 4
+    assert [int.from_bytes(bytes(trace[nxt, c]), "big") for c in (PC, DST_ADDR, OP0_ADDR, OP1_ADDR)] == [0, 0, 0, 0]
+
+
+def check_fill_memory_holes(run, trace, v):
+    for r, want in enumerate(v["asserted_rows"]):               # what the reference test asserts: the steps' rows are untouched
+        assert [int.from_bytes(bytes(trace[r, c]), "big") for c in (PC, DST_ADDR, OP0_ADDR, OP1_ADDR)] == want
+    _, flat = hole_rows(run, trace, len(v["holes"]))            # ... and where fill_memory_holes puts the holes (:243-250): column by column
+    assert flat[:len(v["holes"])] == v["holes"]
+
+
+# ------------------------------------------------------------------------------------------------- host builder (no GPU needed)
+def test_rc_decompose_host_builder(hip_lib):
+    run, v, values = rc_decompose_run()
+    check_rc_decompose(run.main_trace(), v, values)
+
+
+def test_fill_range_check_values_host_builder(hip_lib):
+    run, v = rc_holes_run()
+    check_rc_holes(run, run.main_trace(), v)
+
+
+def test_add_missing_values_to_offsets_column_host_builder(hip_lib):
+    run, v = missing_offsets_run()
+    check_missing_offsets(run.main_trace(), v)
+
+
+@pytest.mark.parametrize("name", ["no_codelen", "inside_program_section", "outside_program_section"])
+def test_get_memory_holes_host_builder(hip_lib, name):
+    run, v = memory_holes_run(name)
+    check_memory_holes(run, run.main_trace(), v)
+
+
+def test_fill_memory_holes_host_builder(hip_lib):
+    run, v = fill_memory_holes_run()
+    check_fill_memory_holes(run, run.main_trace(), v)
+
+
+# ------------------------------------------------------------------------------------------------------------------- the oracle
+def aux_inputs(a, v, public_memory, output_range):
+    """A main trace whose flattened (pc, dst, op0, op1) address and (inst, dst, op0, op1) value columns are a and v (air.rs:664-670),
+    and the public inputs of the reference test."""
+    assert len(a) % 4 == 0
+    n = len(a) // 4
+    trace = np.zeros((n, 34, 32), dtype=np.uint8)
+    for i in range(n):
+        for k in range(4):
+            trace[i, PC + k] = np.frombuffer(int(a[4 * i + k]).to_bytes(32, "big"), dtype=np.uint8)
+            trace[i, 23 + k] = np.frombuffer(int(v[4 * i + k]).to_bytes(32, "big"), dtype=np.uint8)
+    segments = [(1, output_range[0], output_range[1])] if output_range else []
+    return trace, (0, 0, 0, 0, 0, 0, 0, [tuple(x) for x in public_memory], 1, segments)
+
+
+RAP = (15, 12345678901234567890, 987654321)      # alpha, z, z_rc: any values that keep z - (a + alpha v) away from zero
+
+
+@pytest.mark.parametrize("key", ["add_program", "add_program_with_output", "sort_columns_by_memory_address"])
+def test_oracle_public_memory_section_and_sort(oracle, key):
+    v = vectors()[key]
+    a, val, ap, vp = list(v["a"]), list(v["v"]), list(v["ap"]), list(v["vp"])
+    if len(a) % 4:      # six entries in the reference test; a trace has four per row: two more (1, 1) accesses IN FRONT - the section is the tail
+        pad = 4 - len(a) % 4
+        a, val, ap, vp = [1] * pad + a, [1] * pad + val, [1] * pad + ap, [1] * pad + vp
+    trace, pub_args = aux_inputs(a, val, v.get("public_memory", []), v.get("output_range"))
+    pub, keep = oracle.make_public_inputs(*pub_args)
+    aux = oracle.cairo_aux_trace(trace, pub, RAP)
+    got_a = [int.from_bytes(bytes(aux[i, 3 + k]), "big") for i in range(aux.shape[0]) for k in range(4)]
+    got_v = [int.from_bytes(bytes(aux[i, 7 + k]), "big") for i in range(aux.shape[0]) for k in range(4)]
+    # the oracle sorts what add_pub_memory_in_public_input_section returns; the reference test states that function's output UNSORTED
+    # (and, for the sort test, the sorted columns themselves): a stable sort of the stated output is what must come out
+    order = sorted(range(len(ap)), key=lambda i: ap[i])
+    assert got_a == [ap[i] for i in order] and got_v == [vp[i] for i in order]
+    if key == "sort_columns_by_memory_address":
+        assert got_a == v["ap"] and got_v == v["vp"]
+
+
+def test_oracle_rc_builtin_constraint_takes_the_reference_limb_order(oracle):
+    """Constraint 50 (air.rs:1141-1160) on a frame whose builtin columns hold test_rc_decompose's decomposition: zero; with the limbs
+    in the opposite order: not zero for the value whose limbs differ (0x0001...0008), still zero for the palindromic ones."""
+    v = vectors()["rc_decompose"]
+    values = [int(h, 16) for h in v["values"]]
+    for row, value in enumerate(values):
+        limbs = [v["columns"][c][row] for c in range(8)]
+        for order, expect_zero in ((limbs, True), (limbs[::-1], limbs == limbs[::-1])):
+            frame = np.zeros((2, 61, 32), dtype=np.uint8)
+            for c in range(8):
+                frame[0, 34 + c] = np.frombuffer(order[c].to_bytes(32, "big"), dtype=np.uint8)
+            frame[0, 42] = np.frombuffer(value.to_bytes(32, "big"), dtype=np.uint8)
+            out = oracle.cairo_transition(frame, RAP, has_rc_builtin=True)
+            assert (not np.any(out[49])) == expect_zero, (row, order)
