@@ -533,6 +533,9 @@ def compact_line(full):
             q = pj.get(key)
             if isinstance(q, dict) and "best" in q:
                 summ.setdefault("projected_not_measured", {})[f"{name}x{q.get('ranks')}"] = q["best"]
+    c5 = full.get("cfg5_projected")
+    if isinstance(c5, dict):
+        summ["cfg5_projected"] = dict(c5.get("summary") or {"error": str(c5.get("error"))[:160]}, projection=True)
     pp = full.get("proof_poseidon")
     if isinstance(pp, dict) and "proof_gen_ms" in pp:
         summ["cfg3_poseidon_ms"] = _r(pp["proof_gen_ms"], 1)
@@ -949,6 +952,8 @@ def main():
     ap.add_argument("--cold-path", type=str, default="rows", help=argparse.SUPPRESS)
     ap.add_argument("--no-poseidon", action="store_true", help="skip the proof with Poseidon Merkle trees (the optional backend of configs[4])")
     ap.add_argument("--no-cold-start", action="store_true", help="skip the first-proof-of-a-fresh-process measurements")
+    ap.add_argument("--project-cfg5", action="store_true", help="N = 1 only: also run ONE rank's share of BASELINE configs[4] at its own size (2^24 rows, blowup 16, 8 ranks; "
+                    "Keccak and Poseidon; ~169 GB of HBM, ~40 s) over the timing-only transport -> summary.cfg5_projected (a projection; tools/project_cfg5.py)")
     ap.add_argument("--project-ranks", type=int, default=8, help="N = 1 only: also PROJECT (not measure) an N-rank sharded proof from rank 0's share on this GPU (0: off)")
     args = ap.parse_args()
     if args.cpu_proof_child:
@@ -1101,6 +1106,15 @@ def main():
                                                                   out[key].get("proof_gen_ms_from_host_buffer"), out[key].get("proof_gen_ms_from_run"))
                         except Exception as e:
                             out["projected"][key] = {"error": repr(e)}
+                if args.project_cfg5:
+                    try:
+                        sys.path.insert(0, os.path.join(ROOT, "tools"))
+                        import project_cfg5
+                        ctx.close()                                   # (the share needs the GPU's memory to itself: 169 of 288 GB)
+                        out["cfg5_projected"] = project_cfg5.project(api)
+                        ctx = api.Context(device=dev_index)
+                    except Exception as e:
+                        out["cfg5_projected"] = {"error": repr(e)}
                 if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
                     for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
                         order = ["run", "rows", "run+prewarm", "rows+prewarm", "run+ctx+prewarm"]

@@ -331,8 +331,12 @@ int sp_comm_measure(sp_ctx* c, uint64_t bytes_per_rank, double out[6]) {
     uint8_t* gathered = small.as<uint8_t>() + 16;
     if (c->allgather(c->allgather_user, small.p, gathered, 16) != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
     SP_HIP_CHECK(hipMemcpy(all.data(), gathered, W * 16, hipMemcpyDeviceToHost));
-    double ag_min = all[0], a2a_min = all[1];
-    for (uint64_t r = 1; r < W; ++r) { ag_min = std::min(ag_min, all[2 * r]); a2a_min = std::min(a2a_min, all[2 * r + 1]); }
+    // (a zero is "no figure": what the timing-only transport delivers for the ranks that do not exist - a rank that measured has > 0)
+    double ag_min = mine[0], a2a_min = mine[1];
+    for (uint64_t r = 0; r < W; ++r) {
+        if (all[2 * r] > 0) ag_min = std::min(ag_min, all[2 * r]);
+        if (all[2 * r + 1] > 0) a2a_min = std::min(a2a_min, all[2 * r + 1]);
+    }
     c->measured_link[0] = ag_ms; c->measured_link[1] = ag_min; c->measured_link[2] = a2a_ms; c->measured_link[3] = a2a_min;
     c->measured_link[4] = (double)bytes_per_rank; c->measured_link[5] = (double)W;
     if (out) for (int i = 0; i < 6; ++i) out[i] = c->measured_link[i];

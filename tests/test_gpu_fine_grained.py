@@ -119,12 +119,19 @@ class _HipBuffer:
 
 @pytest.mark.parametrize("k,batch", [(10, 1), (13, 5), (22, 1)])
 def test_ntt_dev_batched_device_entry_point(hip_ctx, oracle, k, batch):
-    """sp_ntt_dev (the entry point bench.py times): asynchronous, batched, device layout in place - same values as
-    sp_ntt on host buffers, which the tests above pin to the oracle; the event timers return plausible durations."""
+    """sp_ntt_dev (the entry point bench.py times): asynchronous, batched, device layout in place - the CPU oracle's values element
+    for element, at 2^22 on full-range residues with a block at p - 1 ... p - 2^16; the event timers return plausible durations."""
     n = 1 << k
     rng = random.Random(100 + k)
-    cols = [api.felts_to_bytes([rng.randrange(api.P) for _ in range(n)]) if k <= 13 else
-            api.felts_to_bytes(np.random.default_rng(k + v).integers(0, 2**62, size=n).tolist()) for v in range(batch)]
+    def full_range(seed):
+        """uniform residues below 2^251 as raw big-endian bytes, and - the values a lazy reduction is most likely to get wrong - a block
+        of 2^16 elements counting down from p - 1 (this entry point used to see values below 2^62 at this size)"""
+        raw = np.random.default_rng(seed).integers(0, 256, size=(n, 32), dtype=np.uint8)
+        raw[:, 0] &= 0x07
+        top = np.frombuffer(b"".join((api.P - 1 - i).to_bytes(32, "big") for i in range(1 << 16)), dtype=np.uint8).reshape(-1, 32)
+        raw[n // 2:n // 2 + (1 << 16)] = top
+        return raw
+    cols = [api.felts_to_bytes([rng.randrange(api.P) for _ in range(n)]) if k <= 13 else full_range(k + v) for v in range(batch)]
     dev_layout = np.ascontiguousarray(np.concatenate([api.fe_to_device(c) for c in cols]))
     d = _HipBuffer(dev_layout)
     try:
@@ -135,8 +142,7 @@ def test_ntt_dev_batched_device_entry_point(hip_ctx, oracle, k, batch):
         hip_ctx.sync()
         got = api.fe_from_device(d.to_host().reshape(-1, 32)).reshape(batch, n, 32)
         for v in range(batch):
-            want = hip_ctx.ntt(cols[v]) if k > 13 else oracle.ntt(cols[v])
-            assert np.array_equal(got[v], want)
+            assert np.array_equal(got[v], oracle.ntt(cols[v]))      # the oracle itself, at every size (2^22: the size bench.py times)
         assert 0.0 < call_ms <= region_ms * 1.5 + 0.05
         hip_ctx.ntt_dev(d.ptr.value, n, batch, inverse=True)   # the inverse restores the input
         hip_ctx.sync()
