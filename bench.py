@@ -244,6 +244,36 @@ def cpu_proof_cfg4(args, device_proof):
     return base
 
 
+# The two FULL runs of the CPU oracle that exist on one and the same host (the build container, 8 cores, OMP_NUM_THREADS=8,
+# tools/oracle_config3.py): configs[2] (2^20 rows, blowup 8) 460 s - tests/golden/README_config3.md - and configs[3] (the 70k program,
+# 2^19 rows, blowup 4) 84 s.  Their ratio carries the first to whatever host timed the second.
+CFG3_OVER_CFG4_SAME_HOST = 460.0 / 84.0
+
+
+def extrapolate_cfg3_cpu(c4, p3, p4):
+    """configs[2] itself takes the oracle minutes (460 s on the build container's 8 cores), beyond what a default run may spend.  Two
+    estimates from the FULL configs[3] run this process just made on this host's CPUs, both labelled:
+      * cpu_ms - that run x the measured same-host ratio of the two full runs (460 s / 84 s = 5.48: what the bigger shape really costs the
+        oracle, memory effects included);
+      * cpu_ms_by_round_laws - each round of that run scaled by its own law: rounds 1, 2 and 4 are dominated by the
+        size-N transforms per column / per FRI layer (N log2 N, N = LDE points), round 3 evaluates the trace polynomials at the
+        out-of-domain points (rows x columns); 52 columns and 80 queries in both shapes."""
+    import math
+    pts3, pts4 = p3["trace_rows"] * p3["blowup"], p4["trace_rows"] * p4["blowup"]
+    nlogn = pts3 * math.log2(pts3) / (pts4 * math.log2(pts4))
+    rows = p3["trace_rows"] / p4["trace_rows"]
+    rounds = c4.get("cpu_round_ms") or []
+    by_law = None
+    if len(rounds) == 4:
+        scaled = [rounds[0] * nlogn, rounds[1] * nlogn, rounds[2] * rows, rounds[3] * nlogn]
+        by_law = sum(scaled) + max(0.0, c4["cpu_ms"] - sum(rounds)) * nlogn
+    return {"kind": "extrapolated", "cpu_ms": c4["cpu_ms"] * CFG3_OVER_CFG4_SAME_HOST, "cores": c4.get("cores"), "scale": CFG3_OVER_CFG4_SAME_HOST,
+            "cpu_ms_by_round_laws": by_law, "round_laws": {"rounds_1_2_4": nlogn, "round_3": rows},
+            "full_runs_same_host": {"host": "build container, 8 cores", "cfg3_s": 460, "cfg4_s": 84},
+            "from": "cpu_baseline.proof_cfg4 (a full run of the CPU oracle on this host's CPUs, identical bytes) x the ratio of the two full "
+                    "oracle runs made on one host (460 s / 84 s, 8 cores); cpu_ms_by_round_laws: every round of that run by its own scaling law"}
+
+
 def cold_child(args):
     """Child of cold_start: a fresh process proves once - context, setup, upload pipeline and all (the reference CLI proves once
     per process, src/main.rs:85-108) - then twice more; result as JSON on a file."""
@@ -524,7 +554,8 @@ def compact_line(full):
             summ["cfg4"].update(cpu_ms=_r(c4["cpu_ms"], 0), cpu_round_ms=c4.get("cpu_round_ms"), cpu_cores=c4.get("cores"), cpu_identical=c4.get("identical_bytes"))
         c3 = cb.get("proof_cfg3_extrapolated")
         if isinstance(c3, dict) and "cpu_ms" in c3 and "cfg3" in summ:
-            summ["cfg3"].update(cpu_ms_extrapolated=_r(c3["cpu_ms"], 0), cpu_cores=c3.get("cores"))
+            summ["cfg3"].update(cpu_ms_extrapolated=_r(c3["cpu_ms"], 0), cpu_ms_by_round_laws=_r(c3.get("cpu_ms_by_round_laws"), 0), cpu_cores=c3.get("cores"),
+                                cpu_full_run_elsewhere="460 s on 8 cores of the build container (84 s for cfg4 there)")
     if isinstance(rm, dict) and "frac" in rm:
         summ["merkle"] = {"frac": _r(rm["frac"], 4), "gbs": _r(rm.get("achieved"), 0), "ms": _r(rm.get("avg_launch_ms"), 3), "keccak_valu_frac": _r(rm.get("valu_frac"), 3)}
     pj = full.get("projected")
@@ -1157,16 +1188,7 @@ def main():
                 out["cpu_baseline"]["proof_cfg4"] = {"error": repr(e)}
             c4, p3, p4 = out["cpu_baseline"]["proof_cfg4"], out.get("proof"), out.get("proof_cfg4")
             if isinstance(c4, dict) and "cpu_ms" in c4 and isinstance(p3, dict) and isinstance(p4, dict) and "trace_rows" in p3 and "trace_rows" in p4:
-                # configs[2] itself takes the oracle ~8 minutes on these CPUs (tests/golden/README_config3.md: 460 s on 8 cores), beyond
-                # what a default run may spend: scaled from the FULL configs[3] run of this very process by LDE points x log2(points) -
-                # the transforms, leaf hashes and per-point constraint evaluations all grow that way (52 columns and 80 queries in both)
-                import math
-                pts3, pts4 = p3["trace_rows"] * p3["blowup"], p4["trace_rows"] * p4["blowup"]
-                scale = pts3 * math.log2(pts3) / (pts4 * math.log2(pts4))
-                out["cpu_baseline"]["proof_cfg3_extrapolated"] = {
-                    "kind": "extrapolated", "cpu_ms": c4["cpu_ms"] * scale, "cores": c4.get("cores"), "scale": scale,
-                    "from": "cpu_baseline.proof_cfg4 (a full run of the CPU oracle in this process' host, identical bytes) x "
-                            "(N3 log2 N3) / (N4 log2 N4), N = LDE points; a one-off full run took 460 s on 8 cores"}
+                out["cpu_baseline"]["proof_cfg3_extrapolated"] = extrapolate_cfg3_cpu(c4, p3, p4)
     if rank == 0:
         print_final(compact_line(out))
     if guard is not None:
