@@ -12,6 +12,20 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """The driver runs `pytest -m gpu -x`: the first failure ends the run.  The cases that need one GPU PER RANK (RCCL on distinct
+    devices) have never executed on hardware - the development box has one GPU, where they skip - so they go LAST: on a multi-GPU
+    box a failure there cannot hide the result of any test that has a record."""
+    def needs_distinct_devices(item):
+        return "transport=rccl" in item.nodeid or "rccl_on_distinct_devices" in item.nodeid
+    def world_of(item):      # smallest worlds first among them: a two-GPU box gets as far as it can
+        import re
+        m = re.search(r"\[(\d+)-transport=rccl", item.nodeid)
+        return int(m.group(1)) if m else 0
+    last = sorted((i for i in items if needs_distinct_devices(i)), key=world_of)
+    items[:] = [i for i in items if not needs_distinct_devices(i)] + last
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle_lib
