@@ -38,8 +38,8 @@ VALU_BUTTERFLY_CEILING = 1.72e11
 MAD_ISSUE_NS = 2.299
 MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
 VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_ntt22_traffic.json")
-MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_merkle_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_ntt22_traffic.json")
+MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_merkle_traffic.json")
 
 
 def ntt_source_sha16():
