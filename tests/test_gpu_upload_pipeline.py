@@ -105,3 +105,44 @@ def test_shape_changes_on_one_context_with_flag_bitmaps():
     assert len(res) == 6
     bad = [c for c in res if not (c["same_bytes"] and c["kind"].startswith("row-major host buffer, gathered"))]
     assert not bad, bad
+
+
+BUDGET_CHILD = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import oracle_lib as oracle
+from lambdaworks_cairo_prover_amd import api
+out = {"cpus": api.host_cpus(), "budget": api.host_cpu_budget()}
+run = api.CairoRun.fibonacci(4000)
+options = (4, 5, 3, 2)
+want = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, options)
+with api.Context(device=0) as ctx:
+    before = len(os.listdir("/proc/self/task"))
+    out["rows"] = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options)) == want
+    out["pool_threads"] = len(os.listdir("/proc/self/task")) - before
+    out["run"] = ctx.cairo_prove_run(run, api.ProofOptions(*options)) == want
+    ctx.set_option(api.SP_OPT_HOST_RANKS, 1)            # the option beats the environment; the pool follows at the next upload
+    out["budget_after_option"] = api.host_cpu_budget()
+    out["rows_again"] = ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options)) == want
+    out["pool_threads_after_option"] = len(os.listdir("/proc/self/task")) - before
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("ranks", ["8", "1000"])
+def test_per_host_thread_budget_on_the_rows_path(ranks):
+    """SP_HOST_RANKS = 8: this rank's share of the CPUs sizes the gather pool; = 1000 (more ranks than CPUs): one worker, every wait
+    blocks instead of polling (common.h sp_stream_wait_polling) and the orchestrating thread yields when idle - same bytes either way."""
+    e = dict(os.environ, SP_UPLOAD_MIN_MB="0", SP_HOST_RANKS=ranks)
+    e.pop("LOCAL_WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, "-c", BUDGET_CHILD, ROOT], env=e, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert r.returncode == 0 and lines, r.stderr[-2000:]
+    res = json.loads(lines[-1][7:])
+    assert res["rows"] and res["run"] and res["rows_again"], res
+    cpus = res["cpus"]
+    assert res["budget"] == [max(1, cpus // int(ranks)), int(ranks)]
+    want_pool = max(2, min(24, 2 * max(1, cpus // int(ranks)))) - 1
+    assert res["pool_threads"] >= want_pool and res["pool_threads"] <= want_pool + 6, res        # (+ the runtime's own helper threads of a first proof)
+    assert res["budget_after_option"] == [cpus, 1]
+    assert res["pool_threads_after_option"] >= max(2, min(24, 2 * cpus)) - 1, res
