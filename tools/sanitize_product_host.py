@@ -71,3 +71,19 @@ for pos in range(0, len(p), 3):
     bad = bytearray(p); bad[pos] ^= 1 << (pos % 8)
     assert not api.cairo_verify(bytes(bad), run.public_inputs_c, OPT, 0)
 print("product host code under ASan: ok")
+# round 5: the reference unit-test vectors through the host builder (crafted runs of tests/test_reference_unit_kats.py), duplicate and
+# conflicting memory cells through sp_cairo_run_from_arrays (flat-array and sparse paths), the verifier's refusal reasons
+import test_reference_unit_kats as K
+run, v, values = K.rc_decompose_run(); K.check_rc_decompose(run.main_trace(), v, values)
+run, v = K.rc_holes_run(); K.check_rc_holes(run, run.main_trace(), v)
+run, v = K.missing_offsets_run(); K.check_missing_offsets(run.main_trace(), v)
+for name in ("no_codelen", "inside_program_section", "outside_program_section"):
+    run, v = K.memory_holes_run(name); K.check_memory_holes(run, run.main_trace(), v)
+run, v = K.fill_memory_holes_run(); K.check_fill_memory_holes(run, run.main_trace(), v)
+import test_dump_reader_fuzz as F
+F.test_conflicting_duplicate_address_is_an_error()
+import test_product_verifier as V
+V.test_padding_the_reference_deserializer_tolerates_is_refused(lib, O)
+print("budget", api.host_cpu_budget(), "rule", api.model_shard_interpolation(70.0, 8, 20))
+print("sanitize_product_host round-5 additions ok")
+
