@@ -77,6 +77,7 @@ def _worker(rank, world, port, case, options, knobs, q):
         if knobs.get("async"):   # stream-ordered all-gather: the coefficient exchange of a segment goes in column blocks beside the transforms
             ctx.set_collective_async(api.StagedAsyncAllGather(alltoall=knobs.get("async_a2a", True)))
         ctx.comm_selftest(4096)  # rank-stamped blocks through every installed primitive (blocking and stream-ordered)
+        link = ctx.comm_measure(1 << 16) if knobs.get("measure") else None   # sp_comm_measure through a transport that really exchanges
         if "fri_min_log" in knobs:
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
@@ -91,6 +92,7 @@ def _worker(rank, world, port, case, options, knobs, q):
         stats["composition_path"] = ctx.last_proof_info()["composition_path"]
         stats["interpolation_sharded"] = ctx.last_proof_info()["interpolation_sharded"]
         stats["upload_kind"] = ctx.last_upload_stats()["kind"]
+        stats["link"] = link
         q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE", stats))
         ctx.close()
     except Exception:
@@ -379,3 +381,27 @@ def test_link_rate_decides_the_interpolation_mode_null_transport():
         ctx.set_option(api.SP_OPT_LINK_GBS, 10000)
         ctx.cairo_prove_run(run, opt)
         assert ctx.last_proof_info()["interpolation_sharded"] == 1
+
+
+@pytest.mark.parametrize("world,knobs", [(2, {"measure": True}), (4, {"measure": True, "async": True})], ids=["blocking-hooks", "stream-ordered-hooks"])
+def test_link_rate_measurement_agrees_across_ranks(world, knobs, oracle, hip_ctx):
+    """sp_comm_measure over transports that really move bytes between processes (the host-staged gloo hooks: blocking, and with the
+    stream-ordered forms installed): every rank ends up with the SAME figures - the minimum over ranks, exchanged through the transport
+    itself - so every rank takes the same interpolation-mode decision from them; the proof that follows has the single-rank bytes."""
+    from lambdaworks_cairo_prover_amd import api
+    run = api.CairoRun.fibonacci(300)
+    options = (4, 4, 3, 2)
+    want = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+    results = _run_world(world, FIB(300), options, knobs)
+    links = []
+    for r in range(world):
+        proof, stats = results[r]
+        assert proof == want, (r, proof[:300])
+        links.append(stats["link"])
+    first = links[0]
+    assert first["world"] == world and first["bytes_per_rank"] == 1 << 16
+    assert first["allgather_gbs_per_link"] > 0 and first["alltoall_gbs_per_link"] > 0
+    for other in links[1:]:          # the rates (a minimum over ranks) are identical everywhere; the local milliseconds need not be
+        assert other["allgather_gbs_per_link"] == first["allgather_gbs_per_link"]
+        assert other["alltoall_gbs_per_link"] == first["alltoall_gbs_per_link"]
+        assert stats["interpolation_sharded"] == results[0][1]["interpolation_sharded"]
