@@ -575,6 +575,9 @@ def compact_line(full):
         summ["air_prove"] = {k: _r(ap.get(k)) for k in ("air", "rows", "blowup", "ms")}
     if isinstance(full.get("rccl"), dict):
         lk = full["rccl"].get("link") or {}
+        pf = full["rccl"].get("preflight")
+        if isinstance(pf, dict) and not pf.get("ok"):
+            summ["rccl_preflight_failed"] = pf.get("failures") or True
         summ["rccl"] = dict({k: full["rccl"].get(k) for k in ("world", "backend", "devices_shared", "interpolation_sharded")}, selftest=full.get("transport_selftest"),
                             link_gbs=[_r(lk.get("allgather_gbs_per_link"), 1), _r(lk.get("alltoall_gbs_per_link"), 1)], link_ms=[_r(lk.get("allgather_ms"), 3), _r(lk.get("alltoall_ms"), 3)])
     line["summary"] = summ
@@ -792,10 +795,86 @@ def proof_child(args):
     dist.destroy_process_group()
 
 
+def rccl_preflight_child(args):
+    """Child of rccl_preflight: the library's RCCL communicator is built, checked (rank-stamped 1 MB blocks through every primitive) and
+    timed in a process of its own; every rank writes {"ok": …} to its own file."""
+    import torch
+    from lambdaworks_cairo_prover_amd import api
+    rank, local_rank, world = int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"]), int(os.environ["WORLD_SIZE"])
+    dev_index, transport, shared = _placement(local_rank, world)
+    torch.cuda.set_device(dev_index)
+    dist = _init_control_plane(INIT_TIMEOUT_S)
+    res = {"ok": False}
+    try:
+        ctx = api.Context(device=dev_index)
+        ctx.init_rccl()
+        ctx.comm_selftest(1 << 20)
+        res = {"ok": True, "link": ctx.comm_measure(0)}
+        ctx.close()
+    except Exception as e:
+        res["error"] = repr(e)[:300]
+    with open(args.rccl_preflight, "w") as f:
+        json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def _spawn_rank_child(flag, path, rank, local_rank, world, port, extra_args=(), extra_env=None):
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.update(extra_env or {})
+    err = tempfile.TemporaryFile()
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), flag, path, *extra_args], env=env, stdout=subprocess.DEVNULL, stderr=err)
+    return child, err
+
+
+def _wait_child(child, timeout):
+    try:
+        rc = child.wait(timeout=timeout)
+        return "ok" if rc == 0 else f"child exit code {rc}"
+    except subprocess.TimeoutExpired:
+        child.kill()          # exactly the process started above
+        child.wait()
+        return f"timeout after {timeout:.0f} s"
+
+
+def rccl_preflight(rank, local_rank, world, dist, timeout=150.0):
+    """Before the proofs go over RCCL for the first time on this box: a throw-away child per rank builds the communicator and runs the
+    selftest under a short time limit.  The ranks agree on the outcome (minimum over ranks on the control plane): "rccl", or - a failure or
+    a hang anywhere - "gloo-staged", the host-staged hooks on the same devices, so that the N-GPU proof figures and their byte parity
+    exist whatever the fabric does (reported as such)."""
+    import torch
+    box = [None]
+    if rank == 0:
+        box = [_free_port()]
+    dist.broadcast_object_list(box, src=0)
+    fd, path = tempfile.mkstemp(prefix=f"sp_preflight_{rank}_", suffix=".json")
+    os.close(fd)
+    os.unlink(path)
+    child, err = _spawn_rank_child("--rccl-preflight", path, rank, local_rank, world, box[0])
+    status = _wait_child(child, timeout)
+    res = {"ok": False, "error": status}
+    try:
+        with open(path) as f:
+            res = json.load(f)
+        os.unlink(path)
+    except Exception:
+        err.seek(0)
+        res["stderr_tail"] = err.read().decode(errors="replace")[-300:]
+    ok = torch.tensor([1 if res.get("ok") else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    reasons = [None] * world
+    dist.all_gather_object(reasons, None if res.get("ok") else (res.get("error") or "failed"))
+    return ("rccl" if int(ok.item()) == 1 else "gloo-staged"), {"ok": bool(ok.item()), "rank0": res, "failures": {str(r): x for r, x in enumerate(reasons) if x}}
+
+
 def proof_isolated(args, rank, local_rank, world, dist):
     """Whole-proof timing for N > 1 GPUs.  The sharded prover exchanges digests and coefficients through the library's RCCL
     communicator; every rank runs it in a CHILD process under a time limit, so that a failure or a hang of that path cannot
     take the headline measurement with it.  Returns the child's result (rank 0) or an error object."""
+    _, transport, _ = _placement(local_rank, world)
+    preflight = None
+    if transport == "rccl" and dist is not None and os.environ.get("SP_BENCH_NO_PREFLIGHT") is None:
+        transport, preflight = rccl_preflight(rank, local_rank, world, dist)
     box = [None, None]
     if rank == 0:
         fd, path = tempfile.mkstemp(prefix="sp_proof_", suffix=".json")
@@ -805,21 +884,10 @@ def proof_isolated(args, rank, local_rank, world, dist):
     if dist is not None:
         dist.broadcast_object_list(box, src=0)
     port, path = box
-    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
-    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-    cmd = [sys.executable, os.path.abspath(__file__), "--proof-child", path, "--proof-fib", str(args.proof_fib),
-           "--proof-blowup", str(args.proof_blowup), "--cfg4-fib", str(args.cfg4_fib), "--cfg4-blowup", str(args.cfg4_blowup)]
-    err = tempfile.TemporaryFile()
-    child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=err)
-    status = "ok"
-    try:
-        rc = child.wait(timeout=args.proof_timeout)
-        if rc != 0:
-            status = f"child exit code {rc}"
-    except subprocess.TimeoutExpired:
-        child.kill()          # exactly the process started above
-        child.wait()
-        status = f"timeout after {args.proof_timeout} s"
+    child, err = _spawn_rank_child("--proof-child", path, rank, local_rank, world, port,
+                                   ["--proof-fib", str(args.proof_fib), "--proof-blowup", str(args.proof_blowup), "--cfg4-fib", str(args.cfg4_fib),
+                                    "--cfg4-blowup", str(args.cfg4_blowup)], {"SP_BENCH_TRANSPORT": transport})
+    status = _wait_child(child, args.proof_timeout)
     if rank != 0:
         return None
     try:
@@ -828,11 +896,13 @@ def proof_isolated(args, rank, local_rank, world, dist):
         os.unlink(path)
         if status != "ok" and isinstance(res, dict):
             res["child_status"] = status
+        if preflight is not None and isinstance(res, dict):
+            res.setdefault("rccl", {})["preflight"] = preflight
         return res
     except Exception:
         err.seek(0)
         tail = err.read().decode(errors="replace")[-600:]
-        return {"error": f"sharded proof child: {status}", "stderr_tail": tail}
+        return {"error": f"sharded proof child: {status}", "stderr_tail": tail, "rccl": {"preflight": preflight}}
 
 
 BENCH_DEADLINE_S = float(os.environ.get("SP_BENCH_DEADLINE_S", "1500"))          # the whole N > 1 job (the driver's own limit is 1800 s)
@@ -971,6 +1041,7 @@ def main():
     ap.add_argument("--proof", type=int, default=-1, help="also time whole-proof generation (default: on; N > 1 in child processes)")
     ap.add_argument("--proof-timeout", type=int, default=360, help="seconds the child processes of the N > 1 proof timing may take")
     ap.add_argument("--proof-child", type=str, default=None, help=argparse.SUPPRESS)
+    ap.add_argument("--rccl-preflight", type=str, default=None, help=argparse.SUPPRESS)
     ap.add_argument("--proof-fib", type=int, default=149000, help="fibonacci index of the proved Cairo program (149000 -> 2^20 rows)")
     ap.add_argument("--proof-blowup", type=int, default=8)
     ap.add_argument("--cfg4-fib", type=int, default=70000, help="configs[3]: the 70k program of benches/criterion_prover_70k.rs (2^19 rows)")
@@ -991,6 +1062,8 @@ def main():
         return cpu_proof_child(args)
     if args.cold_child:
         return cold_child(args)
+    if args.rccl_preflight:
+        return rccl_preflight_child(args)
     if args.proof_child:
         return proof_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
