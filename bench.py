@@ -1078,204 +1078,216 @@ def main():
             time.sleep(1e6)
         sys.exit(3)
 
-    import torch
-    from lambdaworks_cairo_prover_amd import api
+    def body():
+        import torch
+        from lambdaworks_cairo_prover_amd import api
 
-    dist = None
-    dev_index, transport, shared = _placement(local_rank, world)
-    if world > 1:
-        guard.stage = "rendezvous"
-        try:
-            dist = _init_control_plane(INIT_TIMEOUT_S)
-        except Exception as e:
-            guard.fail(f"rendezvous of the {world} ranks failed: {e!r}")
-        os.environ.setdefault("SP_HOST_RANKS", os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # the library's host-thread budget (sp_set_option SP_OPT_HOST_RANKS)
-        guard.stage = "setup"
-    torch.cuda.set_device(dev_index)
-    dev = torch.device(f"cuda:{dev_index}")
-
-    # one process per GPU, kept on the CPUs of its GPU's NUMA node (what `numactl --cpunodebind` does for a deployment on these
-    # two-socket hosts): the tables this process builds are then first-touched beside the page-locked staging of the library
-    numa_node = -1
-    if os.environ.get("SP_BENCH_NO_NUMA_BIND") is None:
-        try:
-            numa_node = api.host_bind_to_device(dev_index)
-        except Exception:
-            numa_node = -1
-    n = 1 << args.log_n
-    # synthetic input: uniformly random residues < 2^251 (< p), written directly in the device layout
-    # (8 x u32 little-endian Montgomery limbs) so that the timed region starts with the data resident in HBM.
-    g = torch.Generator(device="cpu").manual_seed(0x5EED0000 + rank)
-    host = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
-    host2 = torch.randint(0, 2, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
-    host = host | (host2 << 31)
-    host[:, 7] &= 0x07FFFFFF
-    data = host.to(dev).contiguous()
-    ctx = api.Context(device=dev_index)
-
-    def barrier(stage="barrier"):
-        """cuda synchronize + barrier; returns the moment THIS rank's device work was done (before it waited for the others)."""
-        torch.cuda.synchronize()
-        ctx.sync()
-        t_synced = time.perf_counter()
-        if dist is not None:
-            import datetime
-            guard.stage = stage
-            try:        # bounded: names the rank that did not arrive instead of waiting for it for ever
-                dist.monitored_barrier(timeout=datetime.timedelta(seconds=BARRIER_TIMEOUT_S))
-            except Exception as e:
-                guard.fail(f"{stage}: {e!r}"[:600])
-        return t_synced
-
-    self_warm = warm_until(ctx, lambda: ctx.ntt_dev(data.data_ptr(), n))   # clock ramp, independent of --warmup
-    for _ in range(args.warmup):
-        ctx.ntt_dev(data.data_ptr(), n)
-    barrier("barrier before the timed region")
-    t0 = time.perf_counter()
-    ctx.timer_start()                    # HIP events on the context stream bracket the timed region
-    for _ in range(args.steps):
-        ctx.ntt_dev(data.data_ptr(), n)  # asynchronous launches, back to back on the context stream
-    kernel_ms = [ctx.timer_stop() / args.steps]
-    # each rank's K steps end when ITS device is idle; the closing barrier's own latency (a gloo round over N ranks, ~1 ms beside a
-    # 7 ms region at --steps 20) is not NTT time.  The figure reported is the MAX of these over the ranks.
-    dt = barrier("barrier behind the timed region") - t0
-    if dist is not None:
-        guard.stage = "max over ranks"
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        guard.stage = "proofs"
-
-    # HBM bytes per NTT from the committed PMC passes of this very kernel source (tools/profile_round.sh); a profile taken
-    # from other sources is reported as stale instead of being passed off as a measurement of this build
-    traffic, traffic_note = None, "no PMC profile committed for this size"
-    try:
-        tj = json.load(open(TRAFFIC_FILE))
-        if tj.get("log_n") == args.log_n:
-            if tj.get("ntt_source_sha16") == ntt_source_sha16():
-                traffic, traffic_note = tj["traffic_bytes_per_ntt"], os.path.relpath(TRAFFIC_FILE, ROOT)
-            else:
-                traffic_note = f"stale: {os.path.relpath(TRAFFIC_FILE, ROOT)} was taken from other kernel sources ({tj.get('traffic_bytes_per_ntt')} B)"
-    except Exception:
-        pass
-    butterflies = (n // 2) * args.log_n
-    value = butterflies * args.steps * world / dt
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
-    algo_bytes = 64.0 * n  # read once + write once (SURVEY.md §8(d))
-    achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-    rate = butterflies / (avg_ms * 1e-3)
-    out = {
-        "metric": "stark252_ntt_field_ops_per_s", "value": value, "unit": "butterflies/s", "n_gpus": world,
-        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
-        "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
-                   "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)",
-                   "self_warmup_steps": self_warm, "devices_shared": shared,
-                   "host_numa_node": numa_node},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic, "traffic_source": traffic_note,
-                     "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
-                     "mulmod_per_s": rate,
-                     # the pass kernels are VALU-issue bound (DESIGN.md section 4).  Two ceilings: the multiplier alone (72
-                     # v_mad_u64_u32 per product at that instruction's measured issue time - independent of this code), and
-                     # the sustained rate of a registers-only chain of this code's butterfly (lazy mul + add + sub)
-                     "mul_issue_ceiling_per_s": MUL_ISSUE_CEILING, "mul_issue_frac": rate / MUL_ISSUE_CEILING,
-                     "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING, "valu_frac": rate / VALU_BUTTERFLY_CEILING},
-    }
-    if rank == 0:
-        try:
-            out["roofline_merkle"] = merkle_roofline(torch, ctx, dev)
-        except Exception as e:
-            out["roofline_merkle"] = {"error": repr(e)}
-    if args.proof != 0:
-        try:
-            if world == 1:
-                out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
-                out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
-                if not args.no_poseidon:
-                    try:
-                        out["proof_poseidon"] = poseidon_benchmark(api, torch, args.proof_fib, args.proof_blowup)
-                    except Exception as e:
-                        out["proof_poseidon"] = {"error": repr(e)}
-                try:
-                    out["air_prove"] = air_prove_benchmark(api, ctx)
-                except Exception as e:
-                    out["air_prove"] = {"error": repr(e)}
-                if args.project_ranks > 1:
-                    out["projected"] = {}
-                    for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
-                        try:
-                            # (more ranks than LDE cosets only replicate roles: project blowup-many ranks at most)
-                            out["projected"][key] = project_ranks(api, fib, blowup, min(args.project_ranks, blowup), out[key].get("proof_gen_ms"),
-                                                                  out[key].get("proof_gen_ms_from_host_buffer"), out[key].get("proof_gen_ms_from_run"))
-                        except Exception as e:
-                            out["projected"][key] = {"error": repr(e)}
-                if args.project_cfg5:
-                    try:
-                        sys.path.insert(0, os.path.join(ROOT, "tools"))
-                        import project_cfg5
-                        ctx.close()                                   # (the share needs the GPU's memory to itself: 169 of 288 GB)
-                        out["cfg5_projected"] = project_cfg5.project(api)
-                        ctx = api.Context(device=dev_index)
-                    except Exception as e:
-                        out["cfg5_projected"] = {"error": repr(e)}
-                if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
-                    for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
-                        order = ["run", "rows", "run+prewarm", "rows+prewarm", "run+ctx+prewarm"]
-                        if key == "proof":
-                            # (a GPU that has idled for seconds - the projection's host work just did that - costs the next fresh process
-                            # ~0.5 s once, whatever it runs: a throw-away child takes that instead of the first measured one)
-                            out[key]["first_child_after_idle_ms"] = cold_start(args, fib, blowup, "run").get("context_to_first_proof_ms")
-                        runs = {path: dict(cold_start(args, fib, blowup, path), path=path) for path in order}
-                        out[key]["first_call_ms"] = runs["rows"].get("first_call_ms")
-                        pw = runs["run+prewarm"]
-                        out[key]["prewarmed_first_call_ms"] = pw.get("first_call_ms")
-                        out[key]["prewarmed_child_warm_ms"] = pw.get("third_call_ms")
-                        # sp_ctx_create -> VM -> first proof's bytes: everything in sequence / pre-warm beside the VM / context and pre-warm beside the VM
-                        out[key]["one_shot_ms"] = [runs[p].get("context_to_first_proof_ms") for p in ("run", "run+prewarm", "run+ctx+prewarm")]
-                        out[key]["first_call"] = dict(runs, note=(
-                            "fresh child processes, one entry point each (rows: sp_cairo_prove on a pageable row-major table, run: "
-                            "sp_cairo_prove_run); '+prewarm': sp_prewarm on a thread of its own while the front-end runs the program, then "
-                            "the proof - prewarm_ms is that call alone, front_end_and_prewarm_ms the two together, third_call_ms the warm "
-                            "proof of the same child.  first_call_ms = the rows child without a pre-warm"))
-            else:
-                res = proof_isolated(args, rank, local_rank, world, dist)
-                if rank == 0:
-                    for key in ("proof", "proof_cfg4", "rccl", "transport_selftest"):
-                        if isinstance(res, dict) and key in res:
-                            out[key] = res[key]
-                    if not isinstance(res, dict) or "proof" not in res:
-                        out["proof"] = res
-        except Exception as e:  # the headline metric must survive a failure of the secondary one
-            out["proof"] = {"error": repr(e)}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline()
-        try:
-            out["cpu_baseline"]["proof"] = cpu_proof_sample(api, ctx)
-        except Exception as e:
-            out["cpu_baseline"]["proof"] = {"error": repr(e)}
-        if args.cpu_proof_budget > 0 and args.proof != 0:
+        dist = None
+        dev_index, transport, shared = _placement(local_rank, world)
+        if world > 1:
+            guard.stage = "rendezvous"
             try:
-                out["cpu_baseline"]["proof_cfg4"] = cpu_proof_cfg4(args, out.get("proof_cfg4"))
+                dist = _init_control_plane(INIT_TIMEOUT_S)
             except Exception as e:
-                out["cpu_baseline"]["proof_cfg4"] = {"error": repr(e)}
-            c4, p3, p4 = out["cpu_baseline"]["proof_cfg4"], out.get("proof"), out.get("proof_cfg4")
-            if isinstance(c4, dict) and "cpu_ms" in c4 and isinstance(p3, dict) and isinstance(p4, dict) and "trace_rows" in p3 and "trace_rows" in p4:
-                out["cpu_baseline"]["proof_cfg3_extrapolated"] = extrapolate_cfg3_cpu(c4, p3, p4)
-    if rank == 0:
-        print_final(compact_line(out))
-    if guard is not None:
-        guard.stage = "shutdown"
-    ctx.close()
-    if dist is not None:
+                guard.fail(f"rendezvous of the {world} ranks failed: {e!r}")
+            os.environ.setdefault("SP_HOST_RANKS", os.environ.get("LOCAL_WORLD_SIZE", str(world)))   # the library's host-thread budget (sp_set_option SP_OPT_HOST_RANKS)
+            guard.stage = "setup"
+        torch.cuda.set_device(dev_index)
+        dev = torch.device(f"cuda:{dev_index}")
+
+        # one process per GPU, kept on the CPUs of its GPU's NUMA node (what `numactl --cpunodebind` does for a deployment on these
+        # two-socket hosts): the tables this process builds are then first-touched beside the page-locked staging of the library
+        numa_node = -1
+        if os.environ.get("SP_BENCH_NO_NUMA_BIND") is None:
+            try:
+                numa_node = api.host_bind_to_device(dev_index)
+            except Exception:
+                numa_node = -1
+        n = 1 << args.log_n
+        # synthetic input: uniformly random residues < 2^251 (< p), written directly in the device layout
+        # (8 x u32 little-endian Montgomery limbs) so that the timed region starts with the data resident in HBM.
+        g = torch.Generator(device="cpu").manual_seed(0x5EED0000 + rank)
+        host = torch.randint(0, 2**31 - 1, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
+        host2 = torch.randint(0, 2, (n, 8), dtype=torch.int64, generator=g).to(torch.int32)
+        host = host | (host2 << 31)
+        host[:, 7] &= 0x07FFFFFF
+        data = host.to(dev).contiguous()
+        ctx = api.Context(device=dev_index)
+
+        def barrier(stage="barrier"):
+            """cuda synchronize + barrier; returns the moment THIS rank's device work was done (before it waited for the others)."""
+            torch.cuda.synchronize()
+            ctx.sync()
+            t_synced = time.perf_counter()
+            if dist is not None:
+                import datetime
+                guard.stage = stage
+                try:        # bounded: names the rank that did not arrive instead of waiting for it for ever
+                    dist.monitored_barrier(timeout=datetime.timedelta(seconds=BARRIER_TIMEOUT_S))
+                except Exception as e:
+                    guard.fail(f"{stage}: {e!r}"[:600])
+            return t_synced
+
+        self_warm = warm_until(ctx, lambda: ctx.ntt_dev(data.data_ptr(), n))   # clock ramp, independent of --warmup
+        for _ in range(args.warmup):
+            ctx.ntt_dev(data.data_ptr(), n)
+        barrier("barrier before the timed region")
+        t0 = time.perf_counter()
+        ctx.timer_start()                    # HIP events on the context stream bracket the timed region
+        for _ in range(args.steps):
+            ctx.ntt_dev(data.data_ptr(), n)  # asynchronous launches, back to back on the context stream
+        kernel_ms = [ctx.timer_stop() / args.steps]
+        # each rank's K steps end when ITS device is idle; the closing barrier's own latency (a gloo round over N ranks, ~1 ms beside a
+        # 7 ms region at --steps 20) is not NTT time.  The figure reported is the MAX of these over the ranks.
+        dt = barrier("barrier behind the timed region") - t0
+        if dist is not None:
+            guard.stage = "max over ranks"
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+            guard.stage = "proofs"
+
+        # HBM bytes per NTT from the committed PMC passes of this very kernel source (tools/profile_round.sh); a profile taken
+        # from other sources is reported as stale instead of being passed off as a measurement of this build
+        traffic, traffic_note = None, "no PMC profile committed for this size"
         try:
-            dist.monitored_barrier(timeout=__import__("datetime").timedelta(seconds=BARRIER_TIMEOUT_S))   # nobody leaves while a peer may still need the store
-            dist.destroy_process_group()
+            tj = json.load(open(TRAFFIC_FILE))
+            if tj.get("log_n") == args.log_n:
+                if tj.get("ntt_source_sha16") == ntt_source_sha16():
+                    traffic, traffic_note = tj["traffic_bytes_per_ntt"], os.path.relpath(TRAFFIC_FILE, ROOT)
+                else:
+                    traffic_note = f"stale: {os.path.relpath(TRAFFIC_FILE, ROOT)} was taken from other kernel sources ({tj.get('traffic_bytes_per_ntt')} B)"
         except Exception:
             pass
-    if guard is not None:
-        guard.done()
-    return 0
+        butterflies = (n // 2) * args.log_n
+        value = butterflies * args.steps * world / dt
+        avg_ms = sum(kernel_ms) / len(kernel_ms)
+        algo_bytes = 64.0 * n  # read once + write once (SURVEY.md §8(d))
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        rate = butterflies / (avg_ms * 1e-3)
+        out = {
+            "metric": "stark252_ntt_field_ops_per_s", "value": value, "unit": "butterflies/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u256 mod p (8 x u32 Montgomery limbs)", "data": "synthetic",
+            "config": {"workload": f"Stark252 forward NTT 2^{args.log_n}, natural order in/out, one vector per GPU (BASELINE configs[1])",
+                       "log_n": args.log_n, "parallelism": f"replicas x{world} (column sharding, no collective)",
+                       "self_warmup_steps": self_warm, "devices_shared": shared,
+                       "host_numa_node": numa_node},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_note,
+                         "kernel": "ntt_pass_kernel chain of one NTT (all passes)", "avg_launch_ms": avg_ms,
+                         "mulmod_per_s": rate,
+                         # the pass kernels are VALU-issue bound (DESIGN.md section 4).  Two ceilings: the multiplier alone (72
+                         # v_mad_u64_u32 per product at that instruction's measured issue time - independent of this code), and
+                         # the sustained rate of a registers-only chain of this code's butterfly (lazy mul + add + sub)
+                         "mul_issue_ceiling_per_s": MUL_ISSUE_CEILING, "mul_issue_frac": rate / MUL_ISSUE_CEILING,
+                         "valu_ceiling_butterflies_per_s": VALU_BUTTERFLY_CEILING, "valu_frac": rate / VALU_BUTTERFLY_CEILING},
+        }
+        if rank == 0:
+            try:
+                out["roofline_merkle"] = merkle_roofline(torch, ctx, dev)
+            except Exception as e:
+                out["roofline_merkle"] = {"error": repr(e)}
+        if args.proof != 0:
+            try:
+                if world == 1:
+                    out["proof"] = proof_benchmark(api, ctx, args.proof_fib, args.proof_blowup, 1, None)
+                    out["proof_cfg4"] = proof_benchmark(api, ctx, args.cfg4_fib, args.cfg4_blowup, 1, None)
+                    if not args.no_poseidon:
+                        try:
+                            out["proof_poseidon"] = poseidon_benchmark(api, torch, args.proof_fib, args.proof_blowup)
+                        except Exception as e:
+                            out["proof_poseidon"] = {"error": repr(e)}
+                    try:
+                        out["air_prove"] = air_prove_benchmark(api, ctx)
+                    except Exception as e:
+                        out["air_prove"] = {"error": repr(e)}
+                    if args.project_ranks > 1:
+                        out["projected"] = {}
+                        for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
+                            try:
+                                # (more ranks than LDE cosets only replicate roles: project blowup-many ranks at most)
+                                out["projected"][key] = project_ranks(api, fib, blowup, min(args.project_ranks, blowup), out[key].get("proof_gen_ms"),
+                                                                      out[key].get("proof_gen_ms_from_host_buffer"), out[key].get("proof_gen_ms_from_run"))
+                            except Exception as e:
+                                out["projected"][key] = {"error": repr(e)}
+                    if args.project_cfg5:
+                        try:
+                            sys.path.insert(0, os.path.join(ROOT, "tools"))
+                            import project_cfg5
+                            ctx.close()                                   # (the share needs the GPU's memory to itself: 169 of 288 GB)
+                            out["cfg5_projected"] = project_cfg5.project(api)
+                            ctx = api.Context(device=dev_index)
+                        except Exception as e:
+                            out["cfg5_projected"] = {"error": repr(e)}
+                    if not args.no_cold_start:   # fresh child processes, one proof path each (this process keeps its own context)
+                        for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
+                            order = ["run", "rows", "run+prewarm", "rows+prewarm", "run+ctx+prewarm"]
+                            if key == "proof":
+                                # (a GPU that has idled for seconds - the projection's host work just did that - costs the next fresh process
+                                # ~0.5 s once, whatever it runs: a throw-away child takes that instead of the first measured one)
+                                out[key]["first_child_after_idle_ms"] = cold_start(args, fib, blowup, "run").get("context_to_first_proof_ms")
+                            runs = {path: dict(cold_start(args, fib, blowup, path), path=path) for path in order}
+                            out[key]["first_call_ms"] = runs["rows"].get("first_call_ms")
+                            pw = runs["run+prewarm"]
+                            out[key]["prewarmed_first_call_ms"] = pw.get("first_call_ms")
+                            out[key]["prewarmed_child_warm_ms"] = pw.get("third_call_ms")
+                            # sp_ctx_create -> VM -> first proof's bytes: everything in sequence / pre-warm beside the VM / context and pre-warm beside the VM
+                            out[key]["one_shot_ms"] = [runs[p].get("context_to_first_proof_ms") for p in ("run", "run+prewarm", "run+ctx+prewarm")]
+                            out[key]["first_call"] = dict(runs, note=(
+                                "fresh child processes, one entry point each (rows: sp_cairo_prove on a pageable row-major table, run: "
+                                "sp_cairo_prove_run); '+prewarm': sp_prewarm on a thread of its own while the front-end runs the program, then "
+                                "the proof - prewarm_ms is that call alone, front_end_and_prewarm_ms the two together, third_call_ms the warm "
+                                "proof of the same child.  first_call_ms = the rows child without a pre-warm"))
+                else:
+                    res = proof_isolated(args, rank, local_rank, world, dist)
+                    if rank == 0:
+                        for key in ("proof", "proof_cfg4", "rccl", "transport_selftest"):
+                            if isinstance(res, dict) and key in res:
+                                out[key] = res[key]
+                        if not isinstance(res, dict) or "proof" not in res:
+                            out["proof"] = res
+            except Exception as e:  # the headline metric must survive a failure of the secondary one
+                out["proof"] = {"error": repr(e)}
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+            try:
+                out["cpu_baseline"]["proof"] = cpu_proof_sample(api, ctx)
+            except Exception as e:
+                out["cpu_baseline"]["proof"] = {"error": repr(e)}
+            if args.cpu_proof_budget > 0 and args.proof != 0:
+                try:
+                    out["cpu_baseline"]["proof_cfg4"] = cpu_proof_cfg4(args, out.get("proof_cfg4"))
+                except Exception as e:
+                    out["cpu_baseline"]["proof_cfg4"] = {"error": repr(e)}
+                c4, p3, p4 = out["cpu_baseline"]["proof_cfg4"], out.get("proof"), out.get("proof_cfg4")
+                if isinstance(c4, dict) and "cpu_ms" in c4 and isinstance(p3, dict) and isinstance(p4, dict) and "trace_rows" in p3 and "trace_rows" in p4:
+                    out["cpu_baseline"]["proof_cfg3_extrapolated"] = extrapolate_cfg3_cpu(c4, p3, p4)
+        if rank == 0:
+            print_final(compact_line(out))
+        if guard is not None:
+            guard.stage = "shutdown"
+        ctx.close()
+        if dist is not None:
+            try:
+                dist.monitored_barrier(timeout=__import__("datetime").timedelta(seconds=BARRIER_TIMEOUT_S))   # nobody leaves while a peer may still need the store
+                dist.destroy_process_group()
+            except Exception:
+                pass
+        if guard is not None:
+            guard.done()
+        return 0
+
+    try:
+        return body()
+    except SystemExit:
+        raise
+    except BaseException as e:      # an N > 1 rank that fails anywhere still leaves the ONE line (rank 0) and a non-zero code
+        if guard is None:
+            raise
+        import traceback
+        traceback.print_exc()
+        guard.fail(f"rank {rank} failed in stage '{guard.stage}': {e!r}"[:600])
 
 
 if __name__ == "__main__":

@@ -77,3 +77,15 @@ def test_under_torchrun_rank_0_still_prints_its_line_when_a_peer_dies():
     assert r.returncode != 0 and took < 150
     line = the_one_line(r.stdout)
     assert line["value"] is None and line["n_gpus"] == 2 and line["error"]
+
+
+def test_a_failure_behind_the_rendezvous_still_leaves_the_line():
+    """No fault injected: on a machine without a GPU both ranks meet, then fail when they touch the device - rank 0's line names the
+    stage and the exception, the code is non-zero (on a GPU box the same command simply succeeds: tests/test_gpu_bench_multirank.py)."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is present: the command succeeds here")
+    r, took = run_bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline")
+    line = the_one_line(r.stdout)
+    assert r.returncode != 0 and took < 120
+    assert line["value"] is None and line["n_gpus"] == 2 and "failed in stage 'setup'" in line["error"], line
