@@ -46,6 +46,17 @@ typedef struct {
     uint64_t coset_offset;
     uint8_t grinding_factor;
 } sp_proof_options;
+/* The presets and checked constructors of the same file (host arithmetic, no device): SecurityLevel (options.rs:5-12),
+ * ProofOptions::new_secure (:35-75; every level: blowup 4, grinding 20, queries 31 / 41 / 55 conjecturable, 80 / 104 / 140 provable),
+ * new_with_checked_security (:78-102) and new_with_checked_provable_security (:107-129) - restated as the reference computes them,
+ * including the latter's use of the u8's LEADING zeros - for a field of `field_bits` bits (252 for Stark252; the reference is generic
+ * over the field: F::field_bit_size()).  InsecureOptionError (errors.rs) comes back as SP_E_INVALID_ARG with sp_last_error() =
+ * "InsecureOptionError::FieldSize" (field_bits <= security_target + 40) or "InsecureOptionError::SecurityBits". */
+typedef enum { SP_SEC_CONJECTURABLE_80 = 0, SP_SEC_CONJECTURABLE_100 = 1, SP_SEC_CONJECTURABLE_128 = 2,
+               SP_SEC_PROVABLE_80 = 3, SP_SEC_PROVABLE_100 = 4, SP_SEC_PROVABLE_128 = 5 } sp_security_level;
+int sp_proof_options_new_secure(int security_level, uint64_t coset_offset, sp_proof_options* out);
+int sp_proof_options_checked(uint8_t blowup_factor, uint64_t fri_number_of_queries, uint64_t coset_offset, uint8_t grinding_factor,
+                             uint8_t security_target, int provable, uint32_t field_bits, sp_proof_options* out);
 
 typedef struct {
     int device;        /* HIP device ordinal */

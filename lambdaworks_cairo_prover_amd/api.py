@@ -41,6 +41,28 @@ class ProofOptions:
     def default_test_options():  # options.rs:144-151
         return ProofOptions(4, 3, 3, 1)
 
+    # SecurityLevel (options.rs:5-12)
+    CONJECTURABLE_80, CONJECTURABLE_100, CONJECTURABLE_128, PROVABLE_80, PROVABLE_100, PROVABLE_128 = range(6)
+
+    @staticmethod
+    def _from_c(c):
+        return ProofOptions(int(c.blowup_factor), int(c.fri_number_of_queries), int(c.coset_offset), int(c.grinding_factor))
+
+    @staticmethod
+    def new_secure(security_level, coset_offset):  # options.rs:35-75 (sp_proof_options_new_secure)
+        out = ProofOptionsC()
+        check(_lib.load().sp_proof_options_new_secure(int(security_level), ctypes.c_uint64(coset_offset), ctypes.byref(out)))
+        return ProofOptions._from_c(out)
+
+    @staticmethod
+    def new_with_checked_security(blowup_factor, fri_number_of_queries, coset_offset, grinding_factor, security_target, field_bits=252, provable=False):
+        """options.rs:78-102 (provable=True: new_with_checked_provable_security, :107-129); raises SpError whose message is the
+        reference's InsecureOptionError variant.  field_bits: F::field_bit_size() (252 for Stark252)."""
+        out = ProofOptionsC()
+        check(_lib.load().sp_proof_options_checked(ctypes.c_uint8(blowup_factor), ctypes.c_uint64(fri_number_of_queries), ctypes.c_uint64(coset_offset),
+                                                   ctypes.c_uint8(grinding_factor), ctypes.c_uint8(security_target), int(bool(provable)), ctypes.c_uint32(field_bits), ctypes.byref(out)))
+        return ProofOptions._from_c(out)
+
     def to_c(self):
         return ProofOptionsC(self.blowup_factor, self.fri_number_of_queries, self.coset_offset, self.grinding_factor)
 

@@ -100,6 +100,33 @@ int sp_host_cpus(int* count_out) {
     return SP_OK;
 }
 
+// ProofOptions::new_secure (reference src/starks/proof/options.rs:35-75)
+int sp_proof_options_new_secure(int security_level, uint64_t coset_offset, sp_proof_options* out) {
+    static const uint64_t queries[6] = {31, 41, 55, 80, 104, 140};
+    if (!out || security_level < 0 || security_level > 5) return SP_E_INVALID_ARG;
+    out->blowup_factor = 4; out->fri_number_of_queries = queries[security_level]; out->coset_offset = coset_offset; out->grinding_factor = 20;
+    return SP_OK;
+}
+
+// new_with_checked_security (options.rs:78-102) / new_with_checked_provable_security (:107-129), check_field_security (:131-141)
+int sp_proof_options_checked(uint8_t blowup_factor, uint64_t fri_number_of_queries, uint64_t coset_offset, uint8_t grinding_factor,
+                             uint8_t security_target, int provable, uint32_t field_bits, sp_proof_options* out) {
+    if (!out) return SP_E_INVALID_ARG;
+    const uint64_t EXTENSION_DEGREE = 1, NUM_BITS_MAX_DOMAIN_SIZE = 40;
+    if ((uint64_t)field_bits * EXTENSION_DEGREE <= (uint64_t)security_target + NUM_BITS_MAX_DOMAIN_SIZE) { sp_set_error("InsecureOptionError::FieldSize"); return SP_E_INVALID_ARG; }
+    bool insecure;
+    if (!provable) {
+        const uint64_t bits = blowup_factor ? (uint64_t)__builtin_ctz((unsigned)blowup_factor) : 8;          // u8::trailing_zeros
+        insecure = (uint64_t)security_target >= (uint64_t)grinding_factor + bits * fri_number_of_queries - 1;   // (wraps like the reference's usize only for 0 queries and grinding 0)
+    } else {
+        const uint64_t bits = blowup_factor ? (uint64_t)(__builtin_clz((unsigned)blowup_factor) - 24) : 8;   // u8::leading_zeros, as the reference has it
+        insecure = (uint64_t)security_target < (uint64_t)grinding_factor + bits * fri_number_of_queries / 2;
+    }
+    if (insecure) { sp_set_error("InsecureOptionError::SecurityBits"); return SP_E_INVALID_ARG; }
+    out->blowup_factor = blowup_factor; out->fri_number_of_queries = fri_number_of_queries; out->coset_offset = coset_offset; out->grinding_factor = grinding_factor;
+    return SP_OK;
+}
+
 int sp_host_cpu_budget(int* budget_out, int* ranks_out) {
     if (!budget_out) return SP_E_INVALID_ARG;
     *budget_out = (int)sp::host_cpu_budget();
