@@ -485,6 +485,12 @@ int sp_air_verify_backend(const uint8_t* proof, uint64_t proof_len, const sp_air
  * the given encoding; mode 0: hash_many(in[0..n)), 1: hash(in[0], in[1]) (n = 2), 2: hash_single(in[0]) (n = 1),
  * 3: the Hades permutation of in[0..3) (n = 3; out receives three elements).  out: 32 bytes (96 for mode 3), same encoding. */
 int sp_poseidon_host(int fe_encoding, int mode, const uint8_t* in, uint64_t n, uint8_t* out);
+/* The reference CLI's `verify` command (src/main.rs:113-143) on the bytes of a proof file - u64_be(len(proof)) || StarkProof::serialize ||
+ * PublicInputs::serialize (src/cairo/air.rs:223-276), read back as PublicInputs::deserialize does (:278-450; bytes behind num_steps are
+ * ignored, public-memory addresses must fit 64 bits): 1 accepted, 0 rejected or malformed, sp_last_error() as for sp_cairo_verify.
+ * benches/proofs/fibonacci_70000.proof - written by the reference itself - is accepted as it is. */
+int sp_proof_file_verify(const uint8_t* file, uint64_t file_len, const sp_proof_options* opt);
+int sp_proof_file_verify_backend(const uint8_t* file, uint64_t file_len, const sp_proof_options* opt, int merkle_backend);
 /* CLI proof file of the reference (src/main.rs:98-102): u64_be(len(proof)) || proof || PublicInputs::serialize
  * (src/cairo/air.rs:223-276). *out is malloc'd; release with sp_free. */
 int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cairo_run* run, uint8_t** out, uint64_t* out_len);

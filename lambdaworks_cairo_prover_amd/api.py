@@ -448,6 +448,13 @@ def poseidon_host(mode, values):
     return r if mode == 3 else r[0]
 
 
+def proof_file_verify(file_bytes, options, merkle_backend=0):
+    """sp_proof_file_verify: the reference CLI's `verify` command (src/main.rs:113-143) on the bytes of a proof file."""
+    lib = _lib.load()
+    opt = options.to_c()
+    return lib.sp_proof_file_verify_backend(file_bytes, ctypes.c_uint64(len(file_bytes)), ctypes.byref(opt), int(merkle_backend)) == 1
+
+
 def proof_file_bytes(proof, run):
     """u64_be(len) || proof || PublicInputs, the file format of the reference CLI (src/main.rs:98-102)."""
     lib = _lib.load()
@@ -720,7 +727,7 @@ Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.comm_measure = _ctx_comm_measure
 Context.set_option = _ctx_set_option
-__all__ += ["cairo_verify", "proof_file_bytes", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
+__all__ += ["cairo_verify", "proof_file_bytes", "proof_file_verify", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS", "SP_OPT_HOST_RANKS", "host_cpu_budget", "last_error", "model_shard_interpolation",
             "SP_MERKLE_KECCAK256", "SP_MERKLE_POSEIDON", "poseidon_host", "host_bind_to_device",
             "SP_PREWARM_KERNELS", "SP_PREWARM_CLOCKS", "SP_PREWARM_HOST_ROWS", "SP_PREWARM_ALL"]

@@ -664,4 +664,62 @@ std::vector<uint8_t> serialize_public_inputs(const PublicInputs& p) {
     return b;
 }
 
+// PublicInputs::deserialize (reference src/cairo/air.rs:278-450): the inverse of the writer above, with the reference's tolerance
+// (bytes behind num_steps are ignored; a HashMap on their side, so a repeated address keeps its last value and the order is free).
+// Throws "malformed: ..." on what the reference answers with a DeserializationError; addresses must fit 64 bits here.
+PublicInputs deserialize_public_inputs(const uint8_t* d, size_t len) {
+    size_t pos = 0;
+    auto need = [&](size_t k) { if (k > len - pos) throw std::runtime_error("malformed: InvalidAmountOfBytes (public inputs)"); };
+    auto u64 = [&]() { need(8); uint64_t v = 0; for (int i = 0; i < 8; ++i) v = (v << 8) | d[pos + i]; pos += 8; return v; };
+    static const uint8_t P_BE[32] = {0x08, 0, 0, 0, 0, 0, 0, 0x11, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0x01};
+    const uint64_t felt_len = u64();
+    if (felt_len != 32) throw std::runtime_error("malformed: element length is not 32 (public inputs)");
+    auto felt = [&]() {
+        need(32);
+        if (std::memcmp(d + pos, P_BE, 32) >= 0) throw std::runtime_error("malformed: field element out of range (public inputs)");
+        const fe x = fe_from_bytes_be(d + pos); pos += 32; return x;
+    };
+    PublicInputs p;
+    p.pc_init = felt(); p.ap_init = felt(); p.fp_init = felt(); p.pc_final = felt(); p.ap_final = felt();
+    auto opt_u16 = [&](bool& has, uint16_t& v) {
+        need(1);
+        const uint8_t tag = d[pos++];
+        if (tag > 1) throw std::runtime_error("malformed: FieldFromBytesError (range-check tag)");
+        has = tag == 1;
+        if (has) { need(2); v = (uint16_t)((d[pos] << 8) | d[pos + 1]); pos += 2; }
+    };
+    opt_u16(p.has_rc_min, p.range_check_min);
+    opt_u16(p.has_rc_max, p.range_check_max);
+    const uint64_t n_seg = u64();
+    if (n_seg > (len - pos) / 17) throw std::runtime_error("malformed: InvalidAmountOfBytes (memory segments)");
+    for (uint64_t i = 0; i < n_seg; ++i) {
+        need(1);
+        const uint8_t type = d[pos++];
+        if (type > 1) throw std::runtime_error("malformed: FieldFromBytesError (memory segment type)");
+        const uint64_t start = u64(), end = u64();
+        bool seen = false;
+        for (auto& sgm : p.memory_segments) if (sgm.type == type) { sgm.start = start; sgm.end = end; seen = true; }   // (a map: the last entry of a type stays)
+        if (!seen) p.memory_segments.push_back(MemorySegment{type, start, end});
+    }
+    const uint64_t n_pm = u64();
+    if (n_pm > (len - pos) / 64) throw std::runtime_error("malformed: InvalidAmountOfBytes (public memory)");
+    std::vector<std::pair<uint64_t, fe>> cells;
+    cells.reserve(n_pm);
+    for (uint64_t i = 0; i < n_pm; ++i) {
+        need(64);
+        for (int k = 0; k < 24; ++k) if (d[pos + k]) throw std::runtime_error("malformed: a public-memory address beyond 64 bits");
+        uint64_t a = 0;
+        for (int k = 24; k < 32; ++k) a = (a << 8) | d[pos + k];
+        pos += 32;
+        cells.emplace_back(a, felt());
+    }
+    std::stable_sort(cells.begin(), cells.end(), [](const auto& x, const auto& y) { return x.first < y.first; });
+    for (size_t i = 0; i < cells.size(); ++i) {
+        if (i + 1 < cells.size() && cells[i + 1].first == cells[i].first) continue;      // the last value of a repeated address
+        p.public_memory.push_back(cells[i]);
+    }
+    p.num_steps = u64();
+    return p;
+}
+
 }  // namespace sp

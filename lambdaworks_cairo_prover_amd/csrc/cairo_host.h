@@ -168,5 +168,6 @@ std::vector<fe> fibonacci_program(uint64_t fib_index);
 
 // air.rs:223-276
 std::vector<uint8_t> serialize_public_inputs(const PublicInputs& p);
+PublicInputs deserialize_public_inputs(const uint8_t* bytes, size_t len);   // air.rs:278-450; throws std::runtime_error("malformed: ...")
 
 }  // namespace sp

@@ -428,6 +428,27 @@ int sp_air_verify(const uint8_t* proof, uint64_t proof_len, const sp_air_desc* d
     } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
 }
 
+// The `verify` command of the reference CLI (src/main.rs:113-143): u64_be(len(proof)) || proof || PublicInputs::serialize, parsed and
+// handed to verify_cairo_proof.  1 = accepted; 0 otherwise, sp_last_error() as for sp_cairo_verify.
+int sp_proof_file_verify_backend(const uint8_t* file, uint64_t file_len, const sp_proof_options* opt, int merkle_backend) {
+    if (!file || !opt) return SP_E_INVALID_ARG;
+    if (merkle_backend != SP_MERKLE_KECCAK256 && merkle_backend != SP_MERKLE_POSEIDON) return SP_E_INVALID_ARG;
+    try {
+        if (file_len < 8) throw std::runtime_error("malformed: InvalidAmountOfBytes (proof file)");
+        uint64_t plen = 0;
+        for (int i = 0; i < 8; ++i) plen = (plen << 8) | file[i];
+        if (plen > file_len - 8) throw std::runtime_error("malformed: the proof length exceeds the file");
+        const sp::PublicInputs pub = sp::deserialize_public_inputs(file + 8 + plen, (size_t)(file_len - 8 - plen));
+        VerifyBackendScope scope(merkle_backend);
+        const int ok = sp::cairo_verify_host(file + 8, (size_t)plen, pub, opt->blowup_factor, opt->fri_number_of_queries, opt->coset_offset, opt->grinding_factor);
+        sp_set_error(ok == 1 ? "" : "rejected: a verification step failed");
+        return ok;
+    } catch (const std::exception& e) { sp_set_error(e.what()); return 0; }
+}
+int sp_proof_file_verify(const uint8_t* file, uint64_t file_len, const sp_proof_options* opt) {
+    return sp_proof_file_verify_backend(file, file_len, opt, SP_MERKLE_KECCAK256);
+}
+
 // CLI proof file of the reference (src/main.rs:98-102): u64_be(len(proof)) || proof || PublicInputs::serialize.
 // *out is malloc'd (sp_free). The public-memory order of the reference is HashMap order; this writer uses address order.
 int sp_proof_file_encode(const uint8_t* proof, uint64_t proof_len, const sp_cairo_run* run, uint8_t** out, uint64_t* out_len) {

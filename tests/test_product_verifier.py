@@ -175,3 +175,55 @@ def test_verdicts_agree_on_mixed_mutations(hip_lib, oracle):
         assert got == want, (i, kind)
         rejected += not got
     assert rejected >= 440          # (a swap of two equal words or a zeroed all-zero word leaves the proof as it was)
+
+
+def test_cli_verify_on_proof_files(hip_lib, oracle):
+    """sp_proof_file_verify = the reference CLI's `verify` (src/main.rs:113-143): the file the reference itself wrote
+    (benches/proofs/fibonacci_70000.proof) is accepted AS IT IS - proof and public inputs both come from its bytes, nothing is
+    re-derived by running the program; the legacy-protocol fixtures are well-formed and rejected; files written by
+    sp_proof_file_encode (rc-builtin and output segments included) round-trip; damage to the file is rejected, malformed or - inside
+    slack the reference's parsers ignore - harmless, never a crash."""
+    golden = open(os.path.join(GOLDEN, "fibonacci_70000.proof"), "rb").read()
+    assert api.proof_file_verify(golden, OPT) and api.last_error() == ""
+    for legacy in ("fibonacci_500.proof", "fibonacci_1000.proof"):
+        assert not api.proof_file_verify(open(os.path.join(GOLDEN, legacy), "rb").read(), OPT) and api.last_error().startswith("rejected:")
+    assert not api.proof_file_verify(golden, api.ProofOptions(8, 3, 3, 1))            # the verifier's options are not the prover's
+    assert api.proof_file_verify(golden + b"\x00" * 5, OPT)                          # PublicInputs::deserialize stops behind num_steps (air.rs:428-450)
+    # truncations: every cut inside the public inputs and a sample inside the proof
+    plen = struct.unpack(">Q", golden[:8])[0]
+    for cut in list(range(8 + plen, len(golden))) + [0, 7, 8, 9, 100, plen // 2, 8 + plen - 1]:
+        assert not api.proof_file_verify(golden[:cut], OPT) and api.last_error().startswith(("malformed:", "non-canonical framing:", "rejected:")), cut
+    # one flipped bit in the public inputs: rejected or malformed - every field is bound by a boundary constraint or by the permutation
+    # product - with ONE exception the reference has too: fp_init appears in no boundary constraint (air.rs:777-849 pins pc and ap at both
+    # ends, the permutation product and the two range-check bounds), so the verifier never looks at it
+    rng = random.Random(5)
+    fp_init = range(8 + plen + 8 + 64, 8 + plen + 8 + 96)
+    # (and num_steps only enters as the exponent of the trace-domain generator, order 2^19 here: its bits from 19 up change nothing -
+    # in the reference neither, boundary.rs evaluates g^step)
+    for _ in range(300):
+        pos, bit = rng.randrange(8 + plen, len(golden)), rng.randrange(8)
+        bad = bytearray(golden)
+        bad[pos] ^= 1 << bit
+        ok = api.proof_file_verify(bytes(bad), OPT)
+        steps_bit = 8 * (len(golden) - 1 - pos) + bit if pos >= len(golden) - 8 else None
+        if pos in fp_init:
+            assert ok or api.last_error().startswith("malformed:"), pos              # (a flip of its top bits can leave the field: >= p)
+        elif steps_bit is not None and steps_bit >= 19:
+            assert ok, (pos, bit)
+        else:
+            assert not ok, (pos, bit)
+    unconstrained = bytearray(golden)
+    unconstrained[fp_init[-1]] ^= 1
+    assert api.proof_file_verify(bytes(unconstrained), OPT)
+    # files of this library's own writer, builtin segments included
+    from test_rc_builtin import run_of
+    for run in (api.CairoRun.fibonacci(10), run_of("rc_program"), run_of("output_and_rc")):
+        proof = oracle.cairo_prove(run.main_trace(), run.public_inputs_c, (4, 3, 3, 1))
+        blob = api.proof_file_bytes(proof, run)
+        assert api.proof_file_verify(blob, OPT)
+        tampered = bytearray(blob)
+        tampered[-1] ^= 1                                                            # num_steps
+        assert not api.proof_file_verify(bytes(tampered), OPT)
+    for _ in range(100):                                                             # junk never crashes
+        junk = bytes(rng.randrange(256) for _ in range(rng.randrange(0, 400)))
+        assert not api.proof_file_verify(junk or b"\x00", OPT)

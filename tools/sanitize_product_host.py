@@ -84,6 +84,7 @@ import test_dump_reader_fuzz as F
 F.test_conflicting_duplicate_address_is_an_error()
 import test_product_verifier as V
 V.test_padding_the_reference_deserializer_tolerates_is_refused(lib, O)
+V.test_cli_verify_on_proof_files(lib, O)
 print("budget", api.host_cpu_budget(), "rule", api.model_shard_interpolation(70.0, 8, 20))
 print("sanitize_product_host round-5 additions ok")
 
