@@ -818,12 +818,26 @@ def rccl_preflight_child(args):
     dist.destroy_process_group()
 
 
+def _die_with_parent(sig):
+    """preexec_fn: the child gets `sig` when the process that started it dies (PR_SET_PDEATHSIG) - no rank or proof child outlives a
+    launcher or a rank that was killed outright."""
+    def fn():
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(sig), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+        except Exception:
+            pass
+    return fn
+
+
 def _spawn_rank_child(flag, path, rank, local_rank, world, port, extra_args=(), extra_env=None):
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.update(extra_env or {})
     err = tempfile.TemporaryFile()
-    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), flag, path, *extra_args], env=env, stdout=subprocess.DEVNULL, stderr=err)
+    import signal
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), flag, path, *extra_args], env=env, stdout=subprocess.DEVNULL, stderr=err,
+                             preexec_fn=_die_with_parent(signal.SIGKILL))
     return child, err
 
 
@@ -984,15 +998,25 @@ def launch_ranks(args):
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+                                      preexec_fn=_die_with_parent(signal.SIGTERM), stdout=out0 if r == 0 else subprocess.DEVNULL))
     t_end = time.monotonic() + BENCH_DEADLINE_S + 30.0       # (the ranks' own deadline comes first and leaves an error line)
     reason = None
+    asked = []                                               # a SIGTERM / SIGINT to the launcher ends the job like a failed rank does
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, lambda signum, frame: asked.append(signum))
+        except ValueError:
+            pass
     while True:
+        if asked and reason is None:
+            reason = f"launcher received signal {asked[0]}"
         codes = [p.poll() for p in procs]
         if all(c is not None for c in codes):
             break
         bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
-        if bad:
+        if reason:
+            pass
+        elif bad:
             reason = f"rank {bad[0][0]} exited with code {bad[0][1]}"
         elif time.monotonic() > t_end:
             reason = f"launcher deadline of {BENCH_DEADLINE_S + 30:.0f} s passed"
@@ -1010,7 +1034,7 @@ def launch_ranks(args):
             break
         time.sleep(0.2)
     codes = [p.wait() for p in procs]
-    rc = next((c for c in codes if c != 0), 0)
+    rc = next((c for c in codes if c != 0), 0) or (1 if asked else 0)
     out0.seek(0)
     text = out0.read().decode(errors="replace")
     line = None

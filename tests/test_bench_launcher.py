@@ -89,3 +89,24 @@ def test_a_failure_behind_the_rendezvous_still_leaves_the_line():
     line = the_one_line(r.stdout)
     assert r.returncode != 0 and took < 120
     assert line["value"] is None and line["n_gpus"] == 2 and "failed in stage 'setup'" in line["error"], line
+
+
+def test_sigterm_to_the_launcher_ends_the_ranks_and_leaves_the_line():
+    """The launcher is told to stop (a driver's timeout sends SIGTERM): it terminates its ranks - they sit in process groups of their own -
+    prints the one line and returns non-zero; and no rank outlives it (PR_SET_PDEATHSIG covers even a SIGKILL of the launcher)."""
+    import signal
+    env = dict(os.environ, SP_BENCH_FAULT_RANK="1", SP_BENCH_FAULT="hang", SP_BENCH_INIT_TIMEOUT_S="600")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--proof", "0", "--no-cpu-baseline"],
+                         env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    time.sleep(6.0)                      # both ranks are up: rank 1 sleeps, rank 0 waits for it in the rendezvous
+    kids = subprocess.run(["pgrep", "-P", str(p.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    out, err = p.communicate(timeout=60)
+    line = the_one_line(out)
+    assert p.returncode != 0 and line["value"] is None and "signal" in (line["error"] + str(line.get("launcher_note", ""))), line
+    time.sleep(0.5)
+    for k in kids:
+        assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
