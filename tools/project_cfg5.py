@@ -28,10 +28,11 @@ def fib_index_for_rows(log_n):
     return int(149000 * (1 << (log_n - 20)) * 1.0025) if log_n >= 20 else 149000 >> (20 - log_n)
 
 
-def share(api, run, opt, ranks, rank, backend, proofs):
+def share(api, run, opt, ranks, rank, backend, proofs, shard_interp=2):
     ctx = api.Context(device=0)
     try:
         ctx.init_null(ranks, rank)
+        ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, shard_interp)
         if backend == "poseidon":
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
         t0 = time.perf_counter()
@@ -58,7 +59,7 @@ def share(api, run, opt, ranks, rank, backend, proofs):
         ctx.close()
 
 
-def project(api, log_n=24, blowup=16, ranks=8, proofs=3, poseidon=True, which_ranks=(0, 7)):
+def project(api, log_n=24, blowup=16, ranks=8, proofs=3, poseidon=True, which_ranks=(0, 7), shard_interp=2):
     t0 = time.perf_counter()
     fib = fib_index_for_rows(log_n)
     run = api.CairoRun.fibonacci(fib)
@@ -72,7 +73,7 @@ def project(api, log_n=24, blowup=16, ranks=8, proofs=3, poseidon=True, which_ra
            "front_end_s": round(front_end_s, 2), "front_end_split": run.timings(), "shares": []}
     for backend in (("keccak", "poseidon") if poseidon else ("keccak",)):
         for r in which_ranks:
-            out["shares"].append(share(api, run, opt, ranks, min(r, ranks - 1), backend, proofs))
+            out["shares"].append(share(api, run, opt, ranks, min(r, ranks - 1), backend, proofs, shard_interp))
     k = [s for s in out["shares"] if s["merkle"] == "keccak"]
     slow = max(k, key=lambda s: s["compute_ms"][0])
     out["summary"] = {"compute_ms": slow["compute_ms"][0], "comm_ms_model": slow["comm_ms_model"], "device_gb": max(s["device_gb"] for s in out["shares"]),
@@ -94,12 +95,13 @@ def main():
     ap.add_argument("--ranks", type=int, default=8)
     ap.add_argument("--proofs", type=int, default=3)
     ap.add_argument("--no-poseidon", action="store_true")
+    ap.add_argument("--shard-interp", type=int, default=2, help="SP_OPT_SHARD_INTERPOLATION: 0 every rank, 1 by column + coefficient all-gather, 2 the link model")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
     import torch
     torch.cuda.init()
     from lambdaworks_cairo_prover_amd import api
-    res = project(api, args.log_n, args.blowup, args.ranks, args.proofs, not args.no_poseidon)
+    res = project(api, args.log_n, args.blowup, args.ranks, args.proofs, not args.no_poseidon, shard_interp=args.shard_interp)
     text = json.dumps(res, indent=1)
     print(text)
     if args.out:
