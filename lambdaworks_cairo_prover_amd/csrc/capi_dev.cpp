@@ -72,8 +72,10 @@ void sp_ctx_destroy(sp_ctx* c) {
 
 int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* user) {
     if (!c || world < 1 || rank < 0 || rank >= world || (world & (world - 1)) || (world > 1 && !fn)) return SP_E_INVALID_ARG;
-    delete c->prover_state_deleter_holder;   // a prover shaped for another world size must not survive
-    c->prover_state_deleter_holder = nullptr;
+    if (world != c->world) {                 // a prover shaped for another world size must not survive; for another RANK of the same world
+        delete c->prover_state_deleter_holder;   // setup() re-carves the arena it already has (the replayed ranks of tools/replay_ranks.py)
+        c->prover_state_deleter_holder = nullptr;
+    }
     c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr; c->allgather_async = nullptr; c->alltoall_async = nullptr;
     return SP_OK;
 }
