@@ -151,6 +151,7 @@ def main():
     ap.add_argument("--queries", type=int, default=80)
     ap.add_argument("--grinding", type=int, default=20)
     ap.add_argument("--poseidon", action="store_true")
+    ap.add_argument("--shard-interp", type=int, default=2, help="SP_OPT_SHARD_INTERPOLATION: 0 every rank, 1 by column + coefficient all-gather, 2 the link model")
     ap.add_argument("--check-oracle", action="store_true", help="small shapes: also compare with the CPU oracle's bytes and the single-rank device proof")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
@@ -171,6 +172,7 @@ def main():
     with api.Context(device=0) as ctx:
         if args.poseidon:
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
+        ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, args.shard_interp)
         proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), args.ranks)
         res.update(stats)
         res["device_gb"] = round(ctx.prover_device_bytes() / 1e9, 2)
