@@ -13,8 +13,9 @@ pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 
 
+@pytest.mark.parametrize("stream_ordered", [False, True], ids=["blocking", "stream-ordered"])
 @pytest.mark.parametrize("fib,blowup,world,poseidon", [(2000, 16, 8, False), (2000, 4, 4, False), (1000, 8, 8, False), (500, 16, 8, True), (300, 2, 8, False)])
-def test_replayed_ranks_give_the_oracle_bytes(oracle, hip_ctx, fib, blowup, world, poseidon):
+def test_replayed_ranks_give_the_oracle_bytes(oracle, hip_ctx, fib, blowup, world, poseidon, stream_ordered):
     from replay_ranks import sharded_proof_by_replay
     run = api.CairoRun.fibonacci(fib)
     options = (blowup, 5, 3, 2)
@@ -27,7 +28,7 @@ def test_replayed_ranks_give_the_oracle_bytes(oracle, hip_ctx, fib, blowup, worl
     with api.Context(device=0) as ctx:
         if poseidon:
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, api.SP_MERKLE_POSEIDON)
-        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), world, log=lambda *_: None)
+        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), world, log=lambda *_: None, stream_ordered=stream_ordered)
         info = ctx.last_proof_info()
     assert sorted(proofs) == list(range(world))
     for r in range(world):

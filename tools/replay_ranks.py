@@ -43,12 +43,41 @@ class Replay:
         self.rank, self.index = 0, 0
         self.cfn = api.ALLGATHER_FN(self._ag)            # (the attribute names Context.set_collective looks for)
         self.a2a_cfn = api.ALLGATHER_FN(self._a2a)
+        # the stream-ordered forms (sp_set_collective_async / sp_set_alltoall_async): the same answers, enqueued on the stream the prover
+        # hands over - with them the prover takes its stream-ordered code path (exchanges between kernels, the FRI commit phase without the host)
+        self.hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        self.hip.hipStreamSynchronize.argtypes = [ctypes.c_void_p]
+        self.async_cfn = api.ALLGATHER_ASYNC_FN(self._ag_async)
+        self.async_a2a_cfn = api.ALLGATHER_ASYNC_FN(self._a2a_async)
+        self.stream = None
         self.h2d_bytes = 0
 
     def _copy(self, dst, src, n, kind):
-        rc = self.hip.hipMemcpy(dst, src, n, kind)
+        if self.stream is not None:
+            if kind == 2:                               # the send block is complete behind everything queued on that stream
+                if self.hip.hipStreamSynchronize(self.stream) != 0:
+                    raise RuntimeError("hipStreamSynchronize failed")
+            rc = self.hip.hipMemcpyAsync(dst, src, n, kind, self.stream)     # (pageable host memory: the runtime stages it, in stream order)
+            if rc == 0 and kind == 2:
+                rc = self.hip.hipStreamSynchronize(self.stream)
+        else:
+            rc = self.hip.hipMemcpy(dst, src, n, kind)
         if rc != 0:
             raise RuntimeError(f"hipMemcpy failed ({rc})")
+
+    def _ag_async(self, user, send, recv, nbytes, stream):
+        self.stream = ctypes.c_void_p(stream)
+        try:
+            return self._serve("ag", send, recv, nbytes)
+        finally:
+            self.stream = None
+
+    def _a2a_async(self, user, send, recv, nbytes, stream):
+        self.stream = ctypes.c_void_p(stream)
+        try:
+            return self._serve("a2a", send, recv, nbytes)
+        finally:
+            self.stream = None
 
     def _serve(self, kind, send, recv, nbytes):
         try:
@@ -103,7 +132,7 @@ class Replay:
         return tot / 1e9
 
 
-def sharded_proof_by_replay(api, ctx, prove, world, log=print, max_collectives=400):
+def sharded_proof_by_replay(api, ctx, prove, world, log=print, max_collectives=400, stream_ordered=False):
     """prove(ctx) -> proof bytes of the context's current rank.  Returns ({rank: proof bytes}, statistics)."""
     rp = Replay(world, api)
     t0 = time.perf_counter()
@@ -112,6 +141,9 @@ def sharded_proof_by_replay(api, ctx, prove, world, log=print, max_collectives=4
     def run_rank(r):
         rp.rank, rp.index = r, 0
         ctx.set_collective(world, r, rp)                 # both hooks; keeps the prover's arena when only the rank changes
+        if stream_ordered:
+            api.check(ctx._lib.sp_set_collective_async(ctx._h, rp.async_cfn))
+            api.check(ctx._lib.sp_set_alltoall_async(ctx._h, rp.async_a2a_cfn))
         try:
             return prove(ctx)
         except api.SpError:
@@ -152,6 +184,7 @@ def main():
     ap.add_argument("--grinding", type=int, default=20)
     ap.add_argument("--poseidon", action="store_true")
     ap.add_argument("--shard-interp", type=int, default=2, help="SP_OPT_SHARD_INTERPOLATION: 0 every rank, 1 by column + coefficient all-gather, 2 the link model")
+    ap.add_argument("--stream-ordered", action="store_true", help="install the stream-ordered hooks too: the prover's stream-ordered code path")
     ap.add_argument("--check-oracle", action="store_true", help="small shapes: also compare with the CPU oracle's bytes and the single-rank device proof")
     ap.add_argument("--out", type=str, default=None)
     args = ap.parse_args()
@@ -173,7 +206,8 @@ def main():
         if args.poseidon:
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
         ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, args.shard_interp)
-        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), args.ranks)
+        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), args.ranks, stream_ordered=args.stream_ordered)
+        res["transport"] = "stream-ordered replay hooks" if args.stream_ordered else "blocking replay hooks"
         res.update(stats)
         res["device_gb"] = round(ctx.prover_device_bytes() / 1e9, 2)
         info = ctx.last_proof_info()
