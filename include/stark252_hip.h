@@ -101,6 +101,8 @@ void sp_ctx_destroy(sp_ctx* ctx);
  * with the same inputs and obtains the same roots / proof bytes. The data-path exchanges are all-gathers of 32-byte leaf
  * digests, composition evaluations and DEEP evaluations; everything else is local. Either install a hook ... */
 int sp_set_collective(sp_ctx* ctx, int world, int rank, sp_allgather_fn fn, void* user);
+/* (Re-installing with the SAME world - another rank, other hooks - keeps the prover's device arena: the next proof re-carves it for the new
+ * rank; a different world releases it.  Every installation resets the optional hooks below: install them again afterwards.) */
 /* ... or let the library own an RCCL communicator (ncclAllGather on the context stream over xGMI): rank 0 obtains a 128-byte
  * id with sp_comm_unique_id and distributes it out of band (e.g. torch.distributed broadcast); every rank then calls
  * sp_comm_init_rccl with it. */
