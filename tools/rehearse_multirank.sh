@@ -25,4 +25,4 @@ except Exception as e:
     print(sys.argv[1], "NOT VALID JSON:", e)
 PY
 done
-tail -5 gpurun_out/r05_bench_4ranks.err gpurun_out/r05_bench_8ranks.err
+tail -n 5 gpurun_out/r05_bench_4ranks.err; tail -n 5 gpurun_out/r05_bench_8ranks.err
