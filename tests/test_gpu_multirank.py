@@ -262,9 +262,15 @@ def test_rccl_on_distinct_devices(oracle, hip_ctx, hip_lib):
     procs = [ctx.Process(target=_rccl_worker, args=(r, world, port, fib_index, options, q)) for r in range(world)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=600) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
+    try:
+        got = [q.get(timeout=300) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()               # exactly the processes started above
+                p.join(timeout=30)
     for r, proof, stats in got:
         assert proof == want, (r, proof[:300])
         assert stats["world"] == world and stats["alltoall_calls"] >= 3
