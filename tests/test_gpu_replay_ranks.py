@@ -41,18 +41,23 @@ def test_replayed_ranks_give_the_oracle_bytes(oracle, hip_ctx, fib, blowup, worl
 SHA_CFG3 = "3b115b1ab0a2d9e2710d2d8a2f4f4a85938bbe574fe7e5ace903c47040ebaa88"     # tests/golden/README_config3.md (a one-off CPU-oracle run)
 
 
-@pytest.mark.parametrize("world,stream_ordered,shard_interp", [(2, False, 2), (4, True, 2), (4, False, 1), (2, True, 1)])
-def test_config3_at_full_size_on_two_and_four_ranks(world, stream_ordered, shard_interp):
+@pytest.mark.parametrize("world,stream_ordered,shard_interp,entry", [(2, False, 2, "run"), (4, True, 2, "run"), (4, False, 1, "run"), (2, True, 1, "run"),
+                                                                     (4, False, 2, "rows"), (2, True, 1, "rows")])
+def test_config3_at_full_size_on_two_and_four_ranks(world, stream_ordered, shard_interp, entry):
     """BASELINE configs[2] (2^20 rows, blowup 8, 80 queries, 20-bit grinding) split over 2 and 4 ranks - four and two LDE cosets per rank:
     the world sizes the driver's scaling run takes between 1 and 8, which the concurrent shared-GPU cases (test_gpu_multirank_fullsize.py)
-    cover at 8 only.  Replayed ranks, blocking and stream-ordered hooks, replicated and by-column interpolation: the pinned digest."""
+    cover at 8 only.  Replayed ranks, blocking and stream-ordered hooks, replicated and by-column interpolation, from the run (the trace
+    built on every rank) and from the reference's row-major host table (every rank uploads its share of the columns, the trace is
+    all-gathered): the pinned digest."""
     import hashlib
     from replay_ranks import sharded_proof_by_replay
     run = api.CairoRun.fibonacci(149000)
     opt = api.ProofOptions(8, 80, 3, 20)
+    trace = run.main_trace() if entry == "rows" else None
+    prove = (lambda c: c.cairo_prove(trace, run.public_inputs_c, opt)) if entry == "rows" else (lambda c: c.cairo_prove_run(run, opt))
     with api.Context(device=0) as ctx:
         ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, shard_interp)
-        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), world, log=lambda *_: None, stream_ordered=stream_ordered)
+        proofs, stats = sharded_proof_by_replay(api, ctx, prove, world, log=lambda *_: None, stream_ordered=stream_ordered)
         info = ctx.last_proof_info()
     assert sorted(proofs) == list(range(world))
     for r in range(world):
