@@ -546,7 +546,7 @@ def compact_line(full):
              "first_call_ms": _r(p.get("first_call_ms")), "prewarmed_first_call_ms": _r(p.get("prewarmed_first_call_ms")),
              "warm_same_child_ms": _r(p.get("prewarmed_child_warm_ms")),
              "one_shot_ms": [_r(x, 0) for x in p["one_shot_ms"]] if isinstance(p.get("one_shot_ms"), list) else None,
-             "sha": (p.get("proof_sha256") or "")[:8]}
+             "comm_ms": p.get("comm_ms_per_proof"), "sha": (p.get("proof_sha256") or "")[:8]}
         summ[name] = {k: v for k, v in s.items() if v is not None}
     if isinstance(cb, dict):
         c4 = cb.get("proof_cfg4")
@@ -771,9 +771,13 @@ def proof_child(args):
             result["transport_selftest"] = repr(e)
         for key, fib, blowup in (("proof", args.proof_fib, args.proof_blowup), ("proof_cfg4", args.cfg4_fib, args.cfg4_blowup)):
             try:
-                before = ctx.comm_stats()
+                before, t_before = ctx.comm_stats(), ctx.comm_time_ms()
                 result[key] = proof_benchmark(api, ctx, fib, blowup, world, dist)
-                after = ctx.comm_stats()
+                after, t_after = ctx.comm_stats(), ctx.comm_time_ms()
+                proofs_run = max(1, result[key].get("proofs_run", 1))
+                # measured, not modelled: what the exchanges occupied their streams for (event pairs; the wait for the slowest peer included)
+                # and the wall time inside blocking hooks, averaged over every proof of this leg (all input forms)
+                result[key]["comm_ms_per_proof"] = {"stream_ordered": round((t_after[0] - t_before[0]) / proofs_run, 3), "blocking": round((t_after[1] - t_before[1]) / proofs_run, 3)}
                 result[key]["collective_bytes_per_proof"] = {k: (after[k] - before[k]) // max(1, result[key].get("proofs_run", 1))
                                                              for k in ("allgather_bytes", "alltoall_bytes", "received_bytes")}
             except Exception as e:

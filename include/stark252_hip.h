@@ -136,6 +136,10 @@ int sp_set_alltoall_async(sp_ctx* ctx, sp_alltoall_async_fn fn);
 /* Collective traffic of this context since creation: out = {world, all-gather calls, bytes contributed to all-gathers,
  * all-to-all calls, bytes sent in all-to-alls, bytes received in all collectives}. */
 int sp_comm_stats(sp_ctx* ctx, uint64_t out[6]);
+/* ... and how long they took, in ms since creation: out = {stream-ordered collectives - an event pair around each on the stream it was
+ * enqueued on, i.e. what the exchange occupied that stream for, the wait for the slowest peer included -, blocking collectives - wall
+ * clock around the hook}.  Synchronizes the device. */
+int sp_comm_time_ms(sp_ctx* ctx, double out[2]);
 /* Checks the installed transport (RCCL or hooks): one all-gather and, if installed, one all-to-all of rank-stamped blocks of
  * bytes_per_block bytes (a multiple of 8); every rank must call it.  0 = both deliver the layout documented above. */
 int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);

@@ -690,6 +690,13 @@ def model_shard_interpolation(link_gbs, groups, log2_rows):
     return int(lib.sp_model_shard_interpolation(float(link_gbs), int(groups), int(log2_rows)))
 
 
+def _ctx_comm_time_ms(self):
+    """sp_comm_time_ms: (ms in stream-ordered collectives, ms in blocking collectives) since the context was created."""
+    out = (ctypes.c_double * 2)()
+    check(self._lib.sp_comm_time_ms(self._h, out))
+    return out[0], out[1]
+
+
 def _ctx_comm_stats(self):
     out = (ctypes.c_uint64 * 6)()
     check(self._lib.sp_comm_stats(self._h, out))
@@ -726,6 +733,7 @@ Context.set_collective_async = _ctx_set_collective_async
 Context.comm_stats = _ctx_comm_stats
 Context.comm_selftest = _ctx_comm_selftest
 Context.comm_measure = _ctx_comm_measure
+Context.comm_time_ms = _ctx_comm_time_ms
 Context.set_option = _ctx_set_option
 __all__ += ["cairo_verify", "proof_file_bytes", "proof_file_verify", "StagedAllGather", "StagedAsyncAllGather", "shard_global_index", "interleave_shards",
             "SP_OPT_FRI_SHARD_MIN_LOG", "SP_OPT_SHARD_INTERPOLATION", "SP_OPT_UPLOAD_THREADS", "SP_OPT_MERKLE_BACKEND", "SP_OPT_MERKLE_ONE_COLUMN_ROWS", "SP_OPT_DEVICE_TRACE", "SP_OPT_LINK_GBS", "SP_OPT_HOST_RANKS", "host_cpu_budget", "last_error", "model_shard_interpolation",

@@ -60,6 +60,7 @@ void sp_ctx_destroy(sp_ctx* c) {
     delete c->prover_state_deleter_holder;
     delete c->comm_holder;
     delete c->ntt;
+    for (hipEvent_t e : c->comm_ev) (void)hipEventDestroy(e);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->tev0) (void)hipEventDestroy(c->tev0);
@@ -95,6 +96,24 @@ int sp_set_alltoall_async(sp_ctx* c, sp_alltoall_async_fn fn) {
 int sp_set_alltoall(sp_ctx* c, sp_alltoall_fn fn) {
     if (!c) return SP_E_INVALID_ARG;
     c->alltoall = fn;
+    return SP_OK;
+}
+
+// Time the collectives of this context took since creation: out[0] the stream-ordered ones (event pairs on the streams they were
+// enqueued on: what each exchange occupied its stream for, the wait for the slowest peer included), out[1] the blocking ones (wall
+// clock around the hook).  Waits for the context's streams (the events of a proof that has returned are complete anyway).
+int sp_comm_time_ms(sp_ctx* c, double out[2]) {
+    if (!c || !out) return SP_E_INVALID_ARG;
+    if (c->comm_ev_used) {
+        SP_HIP_CHECK(hipSetDevice(c->device));
+        SP_HIP_CHECK(hipDeviceSynchronize());        // (the communication stream of the prover is not the context stream)
+        for (size_t i = 0; i + 1 < c->comm_ev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->comm_ev[i], c->comm_ev[i + 1]) == hipSuccess) c->stat_comm_stream_ms += (double)ms;
+        }
+        c->comm_ev_used = 0;
+    }
+    out[0] = c->stat_comm_stream_ms; out[1] = c->stat_comm_blocking_ms;
     return SP_OK;
 }
 

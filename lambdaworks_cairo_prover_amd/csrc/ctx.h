@@ -1,6 +1,7 @@
 // Context object behind the C ABI (one per proof / per caller thread).
 #pragma once
 #include <atomic>
+#include <vector>
 #include "common.h"
 #include "ntt.h"
 #include "merkle.h"
@@ -35,6 +36,21 @@ struct sp_ctx {
     sp_alltoall_async_fn alltoall_async = nullptr;
     void* allgather_user = nullptr;
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
+    // sp_comm_time_ms: how long the collectives took.  Stream-ordered ones are bracketed by two events on the stream they are enqueued on
+    // (what the exchange occupied that stream for, the wait for the slowest peer included), read back when the figure is asked for;
+    // blocking ones by the wall clock around the hook.
+    std::vector<hipEvent_t> comm_ev;          // pairs (begin, end); [0, comm_ev_used) are recorded and not yet read back
+    size_t comm_ev_used = 0;
+    double stat_comm_stream_ms = 0.0, stat_comm_blocking_ms = 0.0;
+    hipEvent_t comm_event() {                  // nullptr beyond 8192 events between two read-backs: that exchange is not timed
+        if (comm_ev_used == comm_ev.size()) {
+            if (comm_ev.size() >= 8192) return nullptr;
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) return nullptr;
+            comm_ev.push_back(e);
+        }
+        return comm_ev[comm_ev_used++];
+    }
     uint32_t opt_fri_shard_min_log = 16;  // sp_set_option
     int opt_shard_interpolation = 2;          // 0 replicated, 1 by column + coefficient all-gather, 2 whichever the link model makes faster
     double opt_link_gbs = 46.0;               // what one xGMI link delivers per direction (76.8 GB/s x 0.6): the model behind mode 2 ...

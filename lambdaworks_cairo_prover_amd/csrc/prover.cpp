@@ -413,15 +413,39 @@ int StarkProver::full_domain_buffer(fe** out) {
 
 // Blocking all-gather through the context hook: every rank contributes bytes_per_rank, recv = [world][bytes_per_rank]
 // (the first G slots are the G distinct roles).
+namespace {
+// brackets one stream-ordered exchange with two events on the stream it is enqueued on (sp_comm_time_ms reads them back)
+struct CommSpan {
+    sp_ctx* c; hipStream_t st; bool on = false;
+    CommSpan(sp_ctx* ctx, hipStream_t stream) : c(ctx), st(stream) {
+        if (c->comm_ev_used + 2 > 8192) return;
+        hipEvent_t e = c->comm_event();
+        if (e && hipEventRecord(e, st) == hipSuccess) on = true; else if (e) --c->comm_ev_used;
+    }
+    ~CommSpan() {
+        if (!on) return;
+        hipEvent_t e = c->comm_event();
+        if (!e || hipEventRecord(e, st) != hipSuccess) c->comm_ev_used -= e ? 2 : 1;      // (an unpaired begin is dropped)
+    }
+};
+struct BlockingSpan {
+    sp_ctx* c; double t0;
+    explicit BlockingSpan(sp_ctx* ctx) : c(ctx), t0(std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count()) {}
+    ~BlockingSpan() { c->stat_comm_blocking_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - t0; }
+};
+}  // namespace
+
 int StarkProver::all_gather(const void* send_dev, void* recv_dev, uint64_t bytes_per_rank, bool stream_ordered) {
     if (stream_ordered && comm_async()) {
-        const int rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, c_->stream);
+        int rc;
+        { CommSpan span(c_, c_->stream); rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, c_->stream); }
         if (rc != 0) { sp_set_error("stream-ordered all-gather failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
         c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
         return SP_OK;
     }
     SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
-    int rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank);
+    int rc;
+    { BlockingSpan span(c_); rc = c_->allgather(c_->allgather_user, send_dev, recv_dev, bytes_per_rank); }
     if (rc != 0) { sp_set_error("all-gather hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
     c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
     return SP_OK;
@@ -437,7 +461,8 @@ int StarkProver::all_gather_begin(const void* send_dev, void* recv_dev, uint64_t
     }
     SP_HIP_CHECK(hipEventRecord(ev_comm_fork_, c_->stream));            // the send block is complete behind this point
     SP_HIP_CHECK(hipStreamWaitEvent(comm_stream_, ev_comm_fork_, 0));
-    const int rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, comm_stream_);
+    int rc;
+    { CommSpan span(c_, comm_stream_); rc = c_->allgather_async(c_->allgather_user, send_dev, recv_dev, bytes_per_rank, comm_stream_); }
     if (rc != 0) { sp_set_error("stream-ordered all-gather failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
     SP_HIP_CHECK(hipEventRecord(ev_comm_done_[slot], comm_stream_));
     c_->stat_ag_calls += 1; c_->stat_ag_bytes += bytes_per_rank; c_->stat_recv_bytes += bytes_per_rank * (world_ - 1);
@@ -453,14 +478,16 @@ int StarkProver::all_gather_end(int slot) {
 // hook exists (every rank is its own role then); otherwise an all-gather of the whole send array and a local selection.
 int StarkProver::exchange_blocks(const void* send_dev, void* recv_dev, uint64_t bytes, bool stream_ordered) {
     if (stream_ordered && comm_async() && c_->alltoall_async && world_ == G_) {
-        const int rc = c_->alltoall_async(c_->allgather_user, send_dev, recv_dev, bytes, c_->stream);
+        int rc;
+        { CommSpan span(c_, c_->stream); rc = c_->alltoall_async(c_->allgather_user, send_dev, recv_dev, bytes, c_->stream); }
         if (rc != 0) { sp_set_error("stream-ordered all-to-all failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
         c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
         return SP_OK;
     }
     if (c_->alltoall && world_ == G_) {   // (also with a stream-ordered all-gather but no such all-to-all: one host round trip beats G times the bytes)
         SP_HIP_CHECK(sp_stream_wait_polling(c_->stream));
-        int rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes);
+        int rc;
+        { BlockingSpan span(c_); rc = c_->alltoall(c_->allgather_user, send_dev, recv_dev, bytes); }
         if (rc != 0) { sp_set_error("all-to-all hook failed (" + std::to_string(rc) + ")"); return SP_E_HIP; }
         c_->stat_a2a_calls += 1; c_->stat_a2a_bytes += bytes * (G_ - 1); c_->stat_recv_bytes += bytes * (G_ - 1);
         return SP_OK;

@@ -93,6 +93,7 @@ def _worker(rank, world, port, case, options, knobs, q):
         stats["interpolation_sharded"] = ctx.last_proof_info()["interpolation_sharded"]
         stats["upload_kind"] = ctx.last_upload_stats()["kind"]
         stats["link"] = link
+        stats["comm_ms"] = ctx.comm_time_ms()
         q.put((rank, proof if proof == proof2 else b"MISMATCH-ON-REUSE", stats))
         ctx.close()
     except Exception:
@@ -407,6 +408,9 @@ def test_link_rate_measurement_agrees_across_ranks(world, knobs, oracle, hip_ctx
     first = links[0]
     assert first["world"] == world and first["bytes_per_rank"] == 1 << 16
     assert first["allgather_gbs_per_link"] > 0 and first["alltoall_gbs_per_link"] > 0
+    for r in range(world):           # sp_comm_time_ms: the blocking hooks' wall time, and - with the stream-ordered ones installed - event time
+        stream_ms, blocking_ms = results[r][1]["comm_ms"]
+        assert blocking_ms > 0 and (stream_ms > 0) == bool(knobs.get("async")), (r, stream_ms, blocking_ms)
     for other in links[1:]:          # the rates (a minimum over ranks) are identical everywhere; the local milliseconds need not be
         assert other["allgather_gbs_per_link"] == first["allgather_gbs_per_link"]
         assert other["alltoall_gbs_per_link"] == first["alltoall_gbs_per_link"]
