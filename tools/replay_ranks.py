@@ -184,6 +184,8 @@ def main():
     ap.add_argument("--grinding", type=int, default=20)
     ap.add_argument("--poseidon", action="store_true")
     ap.add_argument("--shard-interp", type=int, default=2, help="SP_OPT_SHARD_INTERPOLATION: 0 every rank, 1 by column + coefficient all-gather, 2 the link model")
+    ap.add_argument("--entry", choices=["run", "rows"], default="run", help="run: sp_cairo_prove_run (the trace built on every rank); rows: sp_cairo_prove on the "
+                    "reference's row-major host table (every rank uploads its share of the columns, the trace is all-gathered)")
     ap.add_argument("--stream-ordered", action="store_true", help="install the stream-ordered hooks too: the prover's stream-ordered code path")
     ap.add_argument("--check-oracle", action="store_true", help="small shapes: also compare with the CPU oracle's bytes and the single-rank device proof")
     ap.add_argument("--out", type=str, default=None)
@@ -206,7 +208,13 @@ def main():
         if args.poseidon:
             ctx.set_option(api.SP_OPT_MERKLE_BACKEND, backend)
         ctx.set_option(api.SP_OPT_SHARD_INTERPOLATION, args.shard_interp)
-        proofs, stats = sharded_proof_by_replay(api, ctx, lambda c: c.cairo_prove_run(run, opt), args.ranks, stream_ordered=args.stream_ordered)
+        if args.entry == "rows":
+            trace = run.main_trace()
+            prove = lambda c: c.cairo_prove(trace, run.public_inputs_c, opt)
+        else:
+            prove = lambda c: c.cairo_prove_run(run, opt)
+        res["entry"] = args.entry
+        proofs, stats = sharded_proof_by_replay(api, ctx, prove, args.ranks, stream_ordered=args.stream_ordered)
         res["transport"] = "stream-ordered replay hooks" if args.stream_ordered else "blocking replay hooks"
         res.update(stats)
         res["device_gb"] = round(ctx.prover_device_bytes() / 1e9, 2)
