@@ -43,6 +43,21 @@ def test_random_trace_proof_bytes_equal_oracle(hip_ctx, oracle, n, has_rc, optio
     assert not oracle.cairo_verify(got, pub, options)  # a random trace does not satisfy the AIR
 
 
+@pytest.mark.parametrize("n", [2, 4, 8, 16])
+@pytest.mark.parametrize("has_rc", [False, True])
+def test_tiny_traces(hip_ctx, oracle, n, has_rc):
+    """2 .. 16 rows - below anything a Cairo run produces (32 rows) but inside what the ABI admits (a power of two >= 2): transforms of
+    length 2, trees of a handful of leaves, FRI with one or two layers, public memory that fills most of the table - the oracle's bytes."""
+    cols = 43 if has_rc else 34
+    for blowup in (2, 4, 16):
+        rng = random.Random(n * 100 + blowup + has_rc)
+        trace = random_trace(rng, n, cols)
+        pm = [(a, rng.randrange(P)) for a in range(1, min(5, max(1, 4 * n - 3)) + 1)]
+        pub, keep = oracle.make_public_inputs(1, 2, 3, 4, 5, 5, 65000, pm, max(1, n - 1), [(0, 1000, 1002)] if has_rc else [])
+        options = (blowup, 3, 3, 1)
+        assert hip_ctx.cairo_prove(trace, pub, api.ProofOptions(*options)) == oracle.cairo_prove(trace, pub, options), (n, has_rc, blowup)
+
+
 def _pub_from_run(oracle, run, **override):
     pi = run.public_inputs_c
     kw = dict(pc_init=int.from_bytes(bytes(pi.pc_init), "big"), ap_init=int.from_bytes(bytes(pi.ap_init), "big"),
