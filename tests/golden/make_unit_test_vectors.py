@@ -12,6 +12,7 @@ Sources (numbers only: every FE::from(..) / FE::from_hex(..) / range literal of 
       :1246-1303  test_build_auxiliary_trace_add_program_in_public_input_section_works                (add_pub_memory_in_public_input_section, :475-494)
       :1305-1374  test_build_auxiliary_trace_add_program_with_output_in_public_input_section_works
       :1376-1409  test_build_auxiliary_trace_sort_columns_by_memory_address                           (sort_columns_by_memory_address, :519-523)
+      :1197-1216  range_check_eval_works                                                              (evaluate_range_check_builtin_constraint, :1141-1160)
 
 Usage: python tests/golden/make_unit_test_vectors.py
 """
@@ -136,6 +137,14 @@ def main():
         vp, _ = bracket(b, m2)
         out[key] = {"public_memory": pm, "output_range": [int(seg.group(1)), int(seg.group(2))] if seg else None, "a": a, "v": v,
                     "ap": values(ap), "vp": values(vp)}
+
+    # --- range_check_eval_works (air.rs:1197-1216): a 61-column row whose builtin columns satisfy the 50th constraint
+    b = body_of(air, "range_check_eval_works")
+    width = int(re.search(r"for _ in 0\.\.(\d+)", b).group(1))
+    consts = {k: int(v) for k, v in re.findall(r"pub const (RC_\d|RC_VALUE): usize = (\d+);", air)}
+    ones = [consts[k] for k in re.findall(r"row\[super::(RC_\d)\] = FE::one\(\);", b)]
+    value = int(re.search(r'row\[super::RC_VALUE\] = FE::from_hex\("([0-9A-Fa-f]+)"\)', b).group(1), 16)
+    out["range_check_eval_works"] = {"row_width": width, "ones_at": ones, "rc_value_at": consts["RC_VALUE"], "rc_value": hex(value), "expected": 0}
 
     # --- sort_columns_by_memory_address
     b = body_of(air, "test_build_auxiliary_trace_sort_columns_by_memory_address")

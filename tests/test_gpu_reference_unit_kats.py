@@ -71,3 +71,26 @@ def test_aux_trace_root_on_the_reference_unit_inputs(hip_lib, oracle, key, n):
         rap_b = b"".join(int(x).to_bytes(32, "big") for x in K.RAP)
         _lib.check(hip_lib.sp_cairo_commit_aux(ctx._h, rap_b, ctypes.byref(pub), root))
     assert bytes(root) == want
+
+
+def test_domain_constructor_and_lde_edge_case_on_the_device(hip_ctx, oracle):
+    """The same two reference tests (prover.rs:787-835, 865-882) through sp_lde: the device's domain tables (gen_roots_kernel, a18) are
+    the reference's `lde_roots_of_unity_coset`."""
+    P = api.P
+    n, blowup, offset = 8, 2, 3
+    w = oracle.primitive_root(4)
+    x = api.felts_to_bytes([0, 1] + [0] * (n - 2)).reshape(1, n, 32)
+    assert api.bytes_to_felts(hip_ctx.lde(x, blowup, api.felts_to_bytes([offset]))[0]) == [offset * pow(w, i, P) % P for i in range(16)]
+    w32 = oracle.primitive_root(5)
+    x8 = api.felts_to_bytes([0] * 8 + [1] + [0] * 7).reshape(1, 16, 32)
+    assert api.bytes_to_felts(hip_ctx.lde(x8, 2, api.felts_to_bytes([3]))[0]) == [pow(3 * pow(w32, i, P) % P, 8, P) for i in range(32)]
+    for k in (10, 16):                                           # and at sizes that go through the LDS-tiled passes: p(x) = x again
+        n = 1 << k
+        w = oracle.primitive_root(k + 2)
+        x = api.felts_to_bytes([0, 1] + [0] * (n - 2)).reshape(1, n, 32)
+        got = api.bytes_to_felts(hip_ctx.lde(x, 4, api.felts_to_bytes([7]))[0])
+        acc, want = 7, []
+        for _ in range(4 * n):
+            want.append(acc)
+            acc = acc * w % P
+        assert got == want

@@ -236,3 +236,34 @@ def test_oracle_rc_builtin_constraint_takes_the_reference_limb_order(oracle):
             frame[0, 42] = np.frombuffer(value.to_bytes(32, "big"), dtype=np.uint8)
             out = oracle.cairo_transition(frame, RAP, has_rc_builtin=True)
             assert (not np.any(out[49])) == expect_zero, (row, order)
+
+
+def test_oracle_range_check_eval_works(oracle):
+    """range_check_eval_works (air.rs:1197-1216): eight limbs of 1 and the value 0x0001 0001 ... 0001 - the 50th constraint is zero; with one
+    limb changed it is not."""
+    v = vectors()["range_check_eval_works"]
+    assert v["row_width"] == 61
+    frame = np.zeros((2, 61, 32), dtype=np.uint8)
+    for c in v["ones_at"]:
+        frame[0, c, 31] = 1
+    frame[0, v["rc_value_at"]] = np.frombuffer(int(v["rc_value"], 16).to_bytes(32, "big"), dtype=np.uint8)
+    assert not np.any(oracle.cairo_transition(frame, RAP, has_rc_builtin=True)[49])
+    frame[0, v["ones_at"][3], 31] = 2
+    assert np.any(oracle.cairo_transition(frame, RAP, has_rc_builtin=True)[49])
+
+
+def test_oracle_domain_constructor_and_lde_edge_case(oracle):
+    """test_domain_constructor (prover.rs:787-835: lde_roots_of_unity_coset[i] = offset * w^i, w the primitive root of order
+    log2(trace_length * blowup); trace_primitive_root = w^blowup) and test_evaluate_polynomial_on_lde_domain_edge_case (:865-882: the
+    monomial x^8 on the 32 points 3 w_32^i): the LDE of a monomial IS the list of domain points (to that power)."""
+    n, blowup, offset = 8, 2, 3                                     # simple_fibonacci trace of 8 rows, blowup 2, coset offset 3
+    w = oracle.primitive_root((n * blowup).bit_length() - 1)
+    x = api.felts_to_bytes([0, 1] + [0] * (n - 2))                  # p(x) = x
+    got = api.bytes_to_felts(oracle.lde(x, blowup, offset))
+    assert got == [offset * pow(w, i, P) % P for i in range(n * blowup)]
+    assert pow(w, blowup, P) == oracle.primitive_root(n.bit_length() - 1)          # trace_primitive_root
+    # x^8 does not fit 8 coefficients: the reference evaluates it on a doubled transform and keeps every second value (prover.rs:106-123);
+    # 16 coefficients at blowup 2 are the same 32 points
+    w32 = oracle.primitive_root(5)
+    x8 = api.felts_to_bytes([0] * 8 + [1] + [0] * 7)
+    assert api.bytes_to_felts(oracle.lde(x8, 2, 3)) == [pow(3 * pow(w32, i, P) % P, 8, P) for i in range(32)]
