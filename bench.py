@@ -238,6 +238,15 @@ def cpu_proof_cfg4(args, device_proof):
         base["error"] = f"child exit code {rc}"
         return base
     base.update(res)
+    # BASELINE.md section 3's third kernel-level CPU rate: LDE points through round 2 (constraint evaluation on every point, interpolation
+    # of the composition polynomial, its commitment) per second - beside the device's round 2 on the same input, which evaluates 2n of them
+    try:
+        pts = res["trace_rows"] * args.cfg4_blowup
+        base["cpu_round2_lde_points_per_s"] = pts / (res["cpu_round_ms"][1] * 1e-3)
+        if isinstance(device_proof, dict) and device_proof.get("device_round_ms"):
+            base["gpu_round2_lde_points_per_s"] = pts / (device_proof["device_round_ms"][2] * 1e-3)
+    except Exception:
+        pass
     if isinstance(device_proof, dict) and "proof_sha256" in device_proof:
         base["gpu_ms_same_input"] = device_proof.get("proof_gen_ms_from_host_buffer")
         base["identical_bytes"] = device_proof["proof_sha256"] == res["proof_sha256"]
