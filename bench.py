@@ -244,7 +244,15 @@ def cpu_proof_cfg4(args, device_proof):
         pts = res["trace_rows"] * args.cfg4_blowup
         base["cpu_round2_lde_points_per_s"] = pts / (res["cpu_round_ms"][1] * 1e-3)
         if isinstance(device_proof, dict) and device_proof.get("device_round_ms"):
-            base["gpu_round2_lde_points_per_s"] = pts / (device_proof["device_round_ms"][2] * 1e-3)
+            # like for like: the device evaluates the constraints on 2n points when the trace check was clean (composition
+            # path 1 - deg H < 2n), on all N otherwise; the rate counts the points it EVALUATED.  What the CPU figure
+            # is comparable with as a job - all N points' worth of round 2 per second - is the *_equivalent key.
+            path = device_proof.get("composition_path", 1)
+            evaluated = 2 * res["trace_rows"] if path == 1 else pts
+            r2 = device_proof["device_round_ms"][2] * 1e-3
+            base["gpu_round2_lde_points_per_s"] = evaluated / r2
+            base["gpu_round2_lde_points_evaluated"] = evaluated
+            base["gpu_round2_lde_points_equivalent_per_s"] = pts / r2
     except Exception:
         pass
     if isinstance(device_proof, dict) and "proof_sha256" in device_proof:
@@ -446,7 +454,7 @@ def proof_benchmark(api, ctx, fib, blowup, world, dist):
     return {"proof_gen_ms": min(times), "proof_gen_ms_all": times, "device_round_ms": rounds_dev, "trace_rows": run.n_rows,
             "trace_cols": 52, "blowup": blowup, "fri_queries": 80, "grinding": 20, "proof_bytes": len(proof),
             "proof_sha256": hashlib.sha256(proof).hexdigest(), "n_gpus": world,
-            "interpolation_sharded": info.get("interpolation_sharded"), "groups": info.get("groups"),
+            "interpolation_sharded": info.get("interpolation_sharded"), "groups": info.get("groups"), "composition_path": info.get("composition_path"),
             "proof_gen_ms_from_host_buffer": min(host_ms), "proof_gen_ms_from_host_buffer_all": host_ms, "upload": up_rows,
             "proof_gen_ms_from_run": min(run_ms), "proof_gen_ms_from_run_all": run_ms, "upload_run": up_run,
             "proof_gen_ms_from_run_host_table_all": runcols_ms, "proofs_run": calls[0] + 8,
@@ -832,8 +840,11 @@ def rccl_preflight_child(args):
 
 
 def _die_with_parent(sig):
-    """preexec_fn: the child gets `sig` when the process that started it dies (PR_SET_PDEATHSIG) - no rank or proof child outlives a
-    launcher or a rank that was killed outright."""
+    """preexec_fn for children of a process that is single-threaded and has never touched the GPU (the launcher): the child gets `sig`
+    when the process that started it dies (PR_SET_PDEATHSIG) - no rank outlives a launcher that was killed outright.  NOT for children of
+    a rank: between fork and exec the closure runs Python (import, dlopen, allocator) in a copy of a multi-threaded process whose HIP or
+    gloo threads may hold the loader or malloc lock at fork time - CPython documents that as deadlock-prone; those children
+    arm the signal themselves (`_arm_parent_death_signal`)."""
     def fn():
         try:
             import ctypes
@@ -843,14 +854,31 @@ def _die_with_parent(sig):
     return fn
 
 
+def _arm_parent_death_signal():
+    """First statement of a child of a RANK (proof child, RCCL pre-flight child): the parent is multi-threaded and owns a GPU, so nothing
+    may run between its fork and the exec - the child itself asks for SP_BENCH_PDEATHSIG when the process named in SP_BENCH_PARENT_PID
+    dies, and leaves at once if that process is already gone (the window between the exec and this call)."""
+    want = os.environ.get("SP_BENCH_PARENT_PID")
+    if not want:
+        return
+    try:
+        import ctypes
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(os.environ.get("SP_BENCH_PDEATHSIG", "9")), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
+    if os.getppid() != int(want):
+        os._exit(86)
+
+
 def _spawn_rank_child(flag, path, rank, local_rank, world, port, extra_args=(), extra_env=None):
+    import signal
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC")}
-    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               SP_BENCH_PARENT_PID=str(os.getpid()), SP_BENCH_PDEATHSIG=str(int(signal.SIGKILL)))
     env.update(extra_env or {})
     err = tempfile.TemporaryFile()
-    import signal
-    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), flag, path, *extra_args], env=env, stdout=subprocess.DEVNULL, stderr=err,
-                             preexec_fn=_die_with_parent(signal.SIGKILL))
+    # (no preexec_fn: this process has initialised torch, HIP and gloo - see _die_with_parent; close_fds + plain exec only)
+    child = subprocess.Popen([sys.executable, os.path.abspath(__file__), flag, path, *extra_args], env=env, stdout=subprocess.DEVNULL, stderr=err)
     return child, err
 
 
@@ -1100,8 +1128,10 @@ def main():
     if args.cold_child:
         return cold_child(args)
     if args.rccl_preflight:
+        _arm_parent_death_signal()
         return rccl_preflight_child(args)
     if args.proof_child:
+        _arm_parent_death_signal()
         return proof_child(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args)

@@ -70,10 +70,12 @@ typedef struct sp_ctx sp_ctx;
 typedef int (*sp_allgather_fn)(void* user, const void* send_dev, void* recv_dev, uint64_t bytes_per_rank);
 
 const char* sp_version(void);
-/* Layout version of the structures of this header (sp_air_desc, sp_openings, sp_cairo_public_inputs, sp_proof_options): bumped
- * whenever one of them changes.  A binding compares it (and sp_air_desc_size against its own idea of the struct) when it loads
- * the library, so a stale mirror of a struct fails at load time instead of being read with shifted fields. */
-#define SP_ABI_VERSION 3
+/* Version of this header: bumped whenever a structure (sp_air_desc, sp_openings, sp_cairo_public_inputs, sp_proof_options) changes
+ * layout, an entry point or option key is added, or a call changes meaning (4: round 5's sp_comm_measure / sp_comm_time_ms /
+ * sp_proof_options_* / sp_proof_file_verify / SP_OPT_HOST_RANKS family and sp_set_collective keeping the prover across re-installs
+ * of the same world).  A binding compares it (and sp_air_desc_size against its own idea of the struct) when it loads the library, so
+ * a stale build fails at load time with "rebuild the library" instead of with a missing symbol or shifted fields later. */
+#define SP_ABI_VERSION 4
 int sp_abi_version(void);
 uint64_t sp_air_desc_size(void);
 const char* sp_last_error(void);          /* thread-local description of the last failure */
@@ -143,12 +145,18 @@ int sp_comm_time_ms(sp_ctx* ctx, double out[2]);
 /* Checks the installed transport (RCCL or hooks): one all-gather and, if installed, one all-to-all of rank-stamped blocks of
  * bytes_per_block bytes (a multiple of 8); every rank must call it.  0 = both deliver the layout documented above. */
 int sp_comm_selftest(sp_ctx* ctx, uint64_t bytes_per_block);
-/* Times the installed transport - every rank must call it: one all-gather and (if installed) one all-to-all of bytes_per_rank bytes
- * per rank, after an untimed one of each.  out = {all-gather ms, its GB/s per link and direction, all-to-all ms, its GB/s per link
- * and direction, bytes per rank, world}: what a rank received from the others / time / (world - 1) links - the unit of
- * SP_OPT_LINK_GBS - as the MINIMUM over the ranks, so every rank holds the same figures.  SP_OPT_SHARD_INTERPOLATION = 2 decides
- * from the all-gather's rate unless the caller stated SP_OPT_LINK_GBS.  sp_comm_init_rccl runs it once (64 MB per rank; environment
- * SP_COMM_MEASURE_MB, 0 = not at all).  bytes_per_rank = 0: only read the stored figures back (zeros when nothing was measured). */
+/* Times the installed transport - every rank must call it: all-gathers and (if installed) all-to-alls of bytes_per_rank bytes per
+ * rank, one untimed of each and then three timed ones whose MEDIAN counts.  out = {all-gather ms, its GB/s per link and direction,
+ * all-to-all ms, its GB/s per link and direction, bytes per rank, world}: what a rank received from the others / time / (world - 1)
+ * links - the unit of SP_OPT_LINK_GBS - as the MINIMUM over the ranks, so every rank holds the same figures.
+ * SP_OPT_SHARD_INTERPOLATION = 2 decides from the all-gather's rate DIVIDED BY SP_LINK_MEASURED_MARGIN (a measured figure near the
+ * threshold must not flip the mode from run to run) unless the caller stated SP_OPT_LINK_GBS.  sp_comm_init_rccl runs it once
+ * (64 MB per rank; environment SP_COMM_MEASURE_MB, 0 = not at all).  bytes_per_rank = 0: only read the stored figures back (zeros
+ * when nothing was measured).  The outcome is agreed between the ranks: everything local (payload buffers, events) is prepared
+ * before the first collective, a status word per rank goes round on every path, and a rank that could not prepare or could not time
+ * its collectives makes EVERY rank drop the figures and return non-zero - the ranks never end up with different rates, hence never
+ * with different interpolation modes. */
+#define SP_LINK_MEASURED_MARGIN 1.25
 int sp_comm_measure(sp_ctx* ctx, uint64_t bytes_per_rank, double out[6]);
 /* The decision rule of SP_OPT_SHARD_INTERPOLATION = 2 as a pure function: 1 when interpolating a trace segment by column (+ an
  * all-gather of the coefficients) beats interpolating every column on every rank - 64 x 1.35e11 < (groups - 1) x link x log2(rows):

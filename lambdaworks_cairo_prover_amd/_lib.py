@@ -19,7 +19,7 @@ SP_E_ZERO_INVERSE = -6
 SP_E_UNSUPPORTED = -7
 SP_E_PROGRAM = -8
 
-SP_ABI_VERSION = 3   # include/stark252_hip.h
+SP_ABI_VERSION = 4   # include/stark252_hip.h
 
 SP_FE_MONT_LIMBS = 0
 SP_FE_CANON_BE = 1
@@ -48,6 +48,11 @@ class CairoPublicInputsC(ctypes.Structure):
                 ("n_public_memory", ctypes.c_uint64), ("public_memory", ctypes.c_void_p), ("num_steps", ctypes.c_uint64)]
 
 
+# The entry points added most recently, probed at load time beside the version number (api.py binds symbols lazily: a stale build would
+# otherwise fail with AttributeError in the middle of a run instead of with "rebuild the library" here).
+NEWEST_SYMBOLS = ("sp_comm_measure", "sp_comm_time_ms", "sp_model_shard_interpolation", "sp_proof_file_verify", "sp_proof_options_checked",
+                  "sp_host_cpu_budget")
+
 _lib = None
 
 
@@ -65,6 +70,9 @@ def load():
     lib.sp_air_desc_size.restype = ctypes.c_uint64
     if lib.sp_abi_version() != SP_ABI_VERSION:
         raise ImportError(f"{LIB_PATH} has ABI version {lib.sp_abi_version()}, this binding was written for {SP_ABI_VERSION}: rebuild the library")
+    missing = [name for name in NEWEST_SYMBOLS if not hasattr(lib, name)]
+    if missing:
+        raise ImportError(f"{LIB_PATH} lacks {', '.join(missing)}: a stale build under the current ABI number - rebuild the library")
     _lib = lib
     return lib
 

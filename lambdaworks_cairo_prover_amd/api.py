@@ -683,6 +683,9 @@ def _ctx_comm_measure(self, bytes_per_rank=64 << 20):
             "bytes_per_rank": int(out[4]), "world": int(out[5])}
 
 
+LINK_MEASURED_MARGIN = 1.25      # SP_LINK_MEASURED_MARGIN: mode 2 divides a MEASURED all-gather rate by this before it applies the rule
+
+
 def model_shard_interpolation(link_gbs, groups, log2_rows):
     """sp_model_shard_interpolation: the decision rule of SP_OPT_SHARD_INTERPOLATION = 2 (no GPU needed)."""
     lib = _lib.load()

@@ -48,6 +48,7 @@ int sp_ctx_create(sp_ctx** out, const sp_config* cfg) {
     if (hipEventCreate(&c->ev0) != hipSuccess || hipEventCreate(&c->ev1) != hipSuccess ||
         hipEventCreate(&c->tev0) != hipSuccess || hipEventCreate(&c->tev1) != hipSuccess) { sp_ctx_destroy(c); return SP_E_HIP; }
     if (hipMalloc(&c->d_flag, sizeof(int)) != hipSuccess) { sp_ctx_destroy(c); return SP_E_ALLOC; }
+    if (hipMalloc(&c->d_agree, sp_ctx::kAgreeBytes) != hipSuccess) { sp_ctx_destroy(c); return SP_E_ALLOC; }
     sp::hip_runtime_mark_in_use();
     *out = c;
     return SP_OK;
@@ -66,6 +67,7 @@ void sp_ctx_destroy(sp_ctx* c) {
     if (c->tev0) (void)hipEventDestroy(c->tev0);
     if (c->tev1) (void)hipEventDestroy(c->tev1);
     if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_agree) (void)hipFree(c->d_agree);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -78,6 +80,7 @@ int sp_set_collective(sp_ctx* c, int world, int rank, sp_allgather_fn fn, void* 
         c->prover_state_deleter_holder = nullptr;
     }
     c->world = world; c->rank = rank; c->allgather = fn; c->allgather_user = user; c->alltoall = nullptr; c->allgather_async = nullptr; c->alltoall_async = nullptr;
+    c->comm_is_null = false;
     return SP_OK;
 }
 
@@ -252,6 +255,7 @@ int sp_comm_init_null(sp_ctx* c, int world, int rank) {
     delete c->comm_holder;
     c->comm_holder = nc;
     SP_TRY(sp_set_collective(c, world, rank, null_allgather, nc));
+    c->comm_is_null = true;
     SP_TRY(sp_set_collective_async(c, null_allgather_async));
     SP_TRY(sp_set_alltoall_async(c, null_alltoall_async));
     return sp_set_alltoall(c, null_alltoall);
@@ -284,10 +288,9 @@ int sp_comm_init_rccl(sp_ctx* c, const uint8_t id_bytes[128], int world, int ran
     // before the first proof needs them, and gives SP_OPT_SHARD_INTERPOLATION = 2 a measured link rate instead of an assumed one.
     uint64_t mb = 64;
     if (const char* e = std::getenv("SP_COMM_MEASURE_MB")) mb = (uint64_t)std::min(1024, std::max(0, std::atoi(e)));
-    if (world > 1 && mb && sp_comm_measure(c, mb << 20, nullptr) != SP_OK) {
-        // a measurement that fails is not a communicator that fails: the link model keeps its assumed rate (sp_comm_selftest is the check)
-        for (double& x : c->measured_link) x = 0.0;
-    }
+    // A measurement that fails is not a communicator that fails: sp_comm_measure agrees on the outcome across the ranks, so EVERY rank
+    // then keeps the assumed rate (zeroed figures) and takes the same interpolation mode (sp_comm_selftest is the functional check).
+    if (world > 1 && mb) (void)sp_comm_measure(c, mb << 20, nullptr);
     return SP_OK;
 }
 
@@ -299,11 +302,38 @@ int sp_model_shard_interpolation(double link_gbs_per_direction, uint32_t groups,
     return 64.0 * 1.35e11 < (double)(groups - 1) * link_gbs_per_direction * 1e9 * (double)log2_rows ? 1 : 0;
 }
 
-// Times the installed transport: one all-gather and one all-to-all of bytes_per_rank bytes per rank (after an untimed one of each that
-// opens RCCL's channels), HIP events on the context stream around the stream-ordered forms, wall time around the blocking ones.  The
+// Times the installed transport: all-gathers and all-to-alls of bytes_per_rank bytes per rank - one untimed of each, which opens RCCL's
+// channels, then kMeasureReps timed ones whose MEDIAN counts (a single sample at 64 MB sits within the run-to-run spread of the
+// threshold it decides) - HIP events on the context stream around the stream-ordered forms, wall time around the blocking ones.  The
 // rate of a collective is what a rank RECEIVED from the others divided by the time and by the world - 1 links it arrived over (xGMI
-// is point-to-point: GB/s per link and direction, the unit of SP_OPT_LINK_GBS); the minimum over the ranks (one more tiny all-gather)
-// is stored, so that every rank draws the same conclusion from it.  bytes_per_rank = 0 only reads the stored figures back.
+// is point-to-point: GB/s per link and direction, the unit of SP_OPT_LINK_GBS); the minimum over the ranks is stored, so that every
+// rank draws the same conclusion from it.  bytes_per_rank = 0 only reads the stored figures back.
+//
+// Every rank issues the SAME sequence of collectives whatever fails locally: (1) everything local - payload buffers,
+// events - is prepared before the first collective; (2) a 32-byte status word per rank goes round through the slot reserved at
+// sp_ctx_create, on every path: one rank that could not prepare makes EVERY rank skip the timed collectives, zero its figures and
+// return the same error; (3) inside the timed part a local HIP error (an event that cannot be recorded or read) costs the figure, not
+// the collective - the call is still made - and (4) the closing word carries status and rates: a failure anywhere zeroes the figures
+// everywhere, so that mode 2 of SP_OPT_SHARD_INTERPOLATION can never pick different collective sequences on different ranks.  Only a
+// transport that itself reports failure ends the sequence early: its communicator is in an unknown state and nothing sent through it
+// could be trusted (callers bound that case with their own deadline, as they do for sp_comm_selftest).
+namespace {
+constexpr int kMeasureReps = 3;
+// all-gather of one 32-byte word per rank through the reserved slot; all[4 r .. 4 r + 3] = rank r's word
+int agree_words(sp_ctx* c, const double mine[4], std::vector<double>& all) {
+    const uint64_t W = (uint64_t)c->world;
+    all.assign(4 * W, 0.0);
+    uint8_t* slot = static_cast<uint8_t*>(c->d_agree);
+    if (hipMemcpy(slot, mine, 32, hipMemcpyHostToDevice) != hipSuccess) {      // (the peers are owed the collective all the same)
+        (void)hipGetLastError();
+        (void)hipMemset(slot, 0xff, 32);                                       // an all-ones word reads as NaN: "this rank failed"
+    }
+    if (c->allgather(c->allgather_user, slot, slot + 32, 32) != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
+    if (hipMemcpy(all.data(), slot + 32, W * 32, hipMemcpyDeviceToHost) != hipSuccess) { sp_set_error("sp_comm_measure: reading the agreement words back failed"); return SP_E_HIP; }
+    return SP_OK;
+}
+}  // namespace
+
 int sp_comm_measure(sp_ctx* c, uint64_t bytes_per_rank, double out[6]) {
     if (!c || bytes_per_rank % 8) return SP_E_INVALID_ARG;
     if (bytes_per_rank == 0 || c->world < 2) {
@@ -311,55 +341,90 @@ int sp_comm_measure(sp_ctx* c, uint64_t bytes_per_rank, double out[6]) {
         return SP_OK;
     }
     if (!c->allgather) { sp_set_error("sp_comm_measure: no collective installed"); return SP_E_STATE; }
-    SP_HIP_CHECK(hipSetDevice(c->device));
+    if ((uint64_t)c->world > sp_ctx::kAgreeMaxWorld) { sp_set_error("sp_comm_measure: world too large"); return SP_E_INVALID_ARG; }
     const uint64_t W = (uint64_t)c->world, per_pair = std::max<uint64_t>(8, (bytes_per_rank / W) & ~(uint64_t)7);
-    DevBuf send, recv, small;
-    SP_TRY(send.alloc(std::max(bytes_per_rank, W * per_pair)));
-    SP_TRY(recv.alloc(std::max(W * bytes_per_rank, W * per_pair)));
-    SP_TRY(small.alloc(W * 16 + 16));
-    SP_HIP_CHECK(hipMemsetAsync(send.p, 0x5a, std::max(bytes_per_rank, W * per_pair), c->stream));
-    SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+    auto forget = [&]() {
+        for (double& x : c->measured_link) x = 0.0;
+        delete c->prover_state_deleter_holder;      // (a shape set up under the old figure is set up again)
+        c->prover_state_deleter_holder = nullptr;
+    };
+    // (1) local preparation, no collective yet
+    DevBuf send, recv;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    SP_HIP_CHECK(hipEventCreate(&e0));
-    if (hipEventCreate(&e1) != hipSuccess) { (void)hipEventDestroy(e0); return SP_E_HIP; }
-    auto timed = [&](bool a2a, double* ms) -> int {
-        for (int rep = 0; rep < 2; ++rep) {      // the first call of each opens the channels
-            const auto t0 = std::chrono::steady_clock::now();
-            int rc = 0;
-            if (a2a ? (c->alltoall_async != nullptr) : (c->allgather_async != nullptr)) {
-                SP_HIP_CHECK(hipEventRecord(e0, c->stream));
-                rc = a2a ? c->alltoall_async(c->allgather_user, send.p, recv.p, per_pair, c->stream) : c->allgather_async(c->allgather_user, send.p, recv.p, bytes_per_rank, c->stream);
-                SP_HIP_CHECK(hipEventRecord(e1, c->stream));
-                SP_HIP_CHECK(hipStreamSynchronize(c->stream));
-                float f = 0.f;
-                SP_HIP_CHECK(hipEventElapsedTime(&f, e0, e1));
-                *ms = (double)f;
-            } else {
-                rc = a2a ? c->alltoall(c->allgather_user, send.p, recv.p, per_pair) : c->allgather(c->allgather_user, send.p, recv.p, bytes_per_rank);
-                *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            }
-            if (rc != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
-        }
+    auto prepare = [&]() -> int {
+        SP_HIP_CHECK(hipSetDevice(c->device));
+        SP_TRY(send.alloc(std::max(bytes_per_rank, W * per_pair)));
+        SP_TRY(recv.alloc(std::max(W * bytes_per_rank, W * per_pair)));
+        SP_HIP_CHECK(hipMemsetAsync(send.p, 0x5a, std::max(bytes_per_rank, W * per_pair), c->stream));
+        SP_HIP_CHECK(hipStreamSynchronize(c->stream));
+        SP_HIP_CHECK(hipEventCreate(&e0));
+        SP_HIP_CHECK(hipEventCreate(&e1));
         return SP_OK;
     };
+    int local = prepare();
+    if (const char* f = std::getenv("SP_COMM_MEASURE_FAULT_RANK")) if (std::atoi(f) == c->rank) local = SP_E_ALLOC;   // (the tests' fault injection)
+    struct Events { hipEvent_t &a, &b; ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } events_guard{e0, e1};
+    // (2) is every rank ready?
+    std::vector<double> all;
+    const double ready[4] = {local == SP_OK ? 1.0 : 0.0, 0.0, 0.0, 0.0};
+    int rc = agree_words(c, ready, all);
+    if (rc != SP_OK) { forget(); return rc; }
+    for (uint64_t r = 0; r < W; ++r)
+        // (a zero word is also what the timing-only transport delivers for the ranks that do not exist: only a rank that SAYS it failed counts -
+        //  its own word is never zero there)
+        if (!(all[4 * r] == 1.0) && !(all[4 * r] == 0.0 && r != (uint64_t)c->rank && c->comm_is_null)) {
+            forget();
+            if (local != SP_OK) return local;
+            sp_set_error("sp_comm_measure: rank " + std::to_string(r) + " could not prepare its buffers; nothing was measured on any rank");
+            return SP_E_STATE;
+        }
+    // (3) the timed collectives: the same calls on every rank; a local timing error costs the figure only
+    bool figures_ok = true, transport_ok = true;
+    auto timed = [&](bool a2a, double* median_ms) {
+        double ms[kMeasureReps] = {};
+        for (int rep = 0; rep <= kMeasureReps && transport_ok; ++rep) {      // rep 0 opens the channels
+            const auto t0 = std::chrono::steady_clock::now();
+            int trc = 0;
+            double took = 0.0;
+            if (a2a ? (c->alltoall_async != nullptr) : (c->allgather_async != nullptr)) {
+                bool ev = hipEventRecord(e0, c->stream) == hipSuccess;
+                trc = a2a ? c->alltoall_async(c->allgather_user, send.p, recv.p, per_pair, c->stream) : c->allgather_async(c->allgather_user, send.p, recv.p, bytes_per_rank, c->stream);
+                ev = (hipEventRecord(e1, c->stream) == hipSuccess) && ev;
+                ev = (hipStreamSynchronize(c->stream) == hipSuccess) && ev;
+                float f = 0.f;
+                ev = ev && hipEventElapsedTime(&f, e0, e1) == hipSuccess;
+                if (!ev) { (void)hipGetLastError(); figures_ok = false; }
+                took = (double)f;
+            } else {
+                trc = a2a ? c->alltoall(c->allgather_user, send.p, recv.p, per_pair) : c->allgather(c->allgather_user, send.p, recv.p, bytes_per_rank);
+                took = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (trc != 0) transport_ok = false;
+            if (rep > 0) ms[rep - 1] = took;
+        }
+        std::sort(ms, ms + kMeasureReps);
+        *median_ms = ms[kMeasureReps / 2];
+    };
     double ag_ms = 0.0, a2a_ms = 0.0;
-    int rc = timed(false, &ag_ms);
-    if (rc == SP_OK && (c->alltoall || c->alltoall_async)) rc = timed(true, &a2a_ms);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    SP_TRY(rc);
-    double mine[2] = {ag_ms > 0 ? (double)bytes_per_rank / (ag_ms * 1e-3) / 1e9 : 0.0,        // (W - 1) B received over W - 1 links
-                      a2a_ms > 0 ? (double)per_pair / (a2a_ms * 1e-3) / 1e9 : 0.0};
-    // the minimum over the ranks, through the transport itself
-    std::vector<double> all(2 * W, 0.0);
-    SP_HIP_CHECK(hipMemcpy(small.p, mine, 16, hipMemcpyHostToDevice));
-    uint8_t* gathered = small.as<uint8_t>() + 16;
-    if (c->allgather(c->allgather_user, small.p, gathered, 16) != 0) { sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
-    SP_HIP_CHECK(hipMemcpy(all.data(), gathered, W * 16, hipMemcpyDeviceToHost));
-    // (a zero is "no figure": what the timing-only transport delivers for the ranks that do not exist - a rank that measured has > 0)
-    double ag_min = mine[0], a2a_min = mine[1];
+    timed(false, &ag_ms);
+    if (transport_ok && (c->alltoall || c->alltoall_async)) timed(true, &a2a_ms);
+    if (!transport_ok) { forget(); sp_set_error("sp_comm_measure: the transport failed"); return SP_E_HIP; }
+    // (4) status and rates of every rank; the minimum over the ranks
+    const double mine[4] = {figures_ok ? 1.0 : 0.0,
+                            ag_ms > 0 ? (double)bytes_per_rank / (ag_ms * 1e-3) / 1e9 : 0.0,        // (W - 1) B received over W - 1 links
+                            a2a_ms > 0 ? (double)per_pair / (a2a_ms * 1e-3) / 1e9 : 0.0, 0.0};
+    rc = agree_words(c, mine, all);
+    if (rc != SP_OK) { forget(); return rc; }
+    double ag_min = mine[1], a2a_min = mine[2];
     for (uint64_t r = 0; r < W; ++r) {
-        if (all[2 * r] > 0) ag_min = std::min(ag_min, all[2 * r]);
-        if (all[2 * r + 1] > 0) a2a_min = std::min(a2a_min, all[2 * r + 1]);
+        if (all[4 * r] == 0.0 && r != (uint64_t)c->rank && c->comm_is_null) continue;     // a rank that does not exist (timing-only transport)
+        if (!(all[4 * r] == 1.0)) {
+            forget();
+            sp_set_error("sp_comm_measure: rank " + std::to_string(r) + " could not time its collectives; the figures are dropped on every rank");
+            return SP_E_STATE;
+        }
+        if (all[4 * r + 1] > 0) ag_min = std::min(ag_min, all[4 * r + 1]);
+        if (all[4 * r + 2] > 0) a2a_min = std::min(a2a_min, all[4 * r + 2]);
     }
     c->measured_link[0] = ag_ms; c->measured_link[1] = ag_min; c->measured_link[2] = a2a_ms; c->measured_link[3] = a2a_min;
     c->measured_link[4] = (double)bytes_per_rank; c->measured_link[5] = (double)W;

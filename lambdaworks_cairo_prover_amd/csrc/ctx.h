@@ -18,6 +18,10 @@ struct sp_ctx {
     hipEvent_t tev0 = nullptr, tev1 = nullptr;  // sp_timer_start / sp_timer_stop
     bool last_pending = false;
     int* d_flag = nullptr;
+    // 64 KB set aside at creation for the agreement words of sp_comm_measure (32 B per rank, own word first): a rank whose LOCAL
+    // preparation failed - out of memory for the payload, say - can still tell its peers so instead of leaving them in a collective
+    void* d_agree = nullptr;
+    static constexpr uint64_t kAgreeBytes = 64 << 10, kAgreeMaxWorld = kAgreeBytes / 32 - 1;
     void* scratch = nullptr;
     size_t scratch_bytes = 0;
     float last_ms = 0.f;
@@ -35,6 +39,7 @@ struct sp_ctx {
     sp_allgather_async_fn allgather_async = nullptr;
     sp_alltoall_async_fn alltoall_async = nullptr;
     void* allgather_user = nullptr;
+    bool comm_is_null = false;            // the timing-only transport (sp_comm_init_null): the other ranks do not exist and deliver zeros
     uint64_t stat_ag_calls = 0, stat_ag_bytes = 0, stat_a2a_calls = 0, stat_a2a_bytes = 0, stat_recv_bytes = 0;
     // sp_comm_time_ms: how long the collectives took.  Stream-ordered ones are bracketed by two events on the stream they are enqueued on
     // (what the exchange occupied that stream for, the wait for the slowest peer included), read back when the figure is asked for;
@@ -58,7 +63,10 @@ struct sp_ctx {
     // sp_comm_measure: {all-gather ms, GB/s per link and direction of that all-gather, all-to-all ms, GB/s per link of that all-to-all,
     // bytes per rank, world}; the rates are the MINIMUM over the ranks, so every rank takes the same decision from them.  0 = not measured.
     double measured_link[6] = {0, 0, 0, 0, 0, 0};
-    double link_gbs_for_model() const { return opt_link_gbs_explicit ? opt_link_gbs : (measured_link[1] > 0 ? measured_link[1] : opt_link_gbs); }
+    // A MEASURED rate decides with a margin (SP_LINK_MEASURED_MARGIN): the threshold of mode 2 sits where realistic xGMI all-gather rates
+    // are (45 - 60 GB/s per link at G = 8, n = 2^20), and a figure within the run-to-run spread of it must not flip the mode from one
+    // communicator to the next - by-column interpolation has to beat the threshold by the margin; a STATED rate is taken at its word.
+    double link_gbs_for_model() const { return opt_link_gbs_explicit ? opt_link_gbs : (measured_link[1] > 0 ? measured_link[1] / SP_LINK_MEASURED_MARGIN : opt_link_gbs); }
     uint32_t opt_upload_threads = 24;
     int opt_merkle_backend = SP_MERKLE_KECCAK256;
     bool opt_device_trace = true;             // sp_cairo_prove_run builds the main trace on the device from the run's registers and memory

@@ -146,6 +146,13 @@ int StarkProver::setup_impl(uint64_t n, uint32_t main_cols, uint32_t aux_cols, b
     if (G_ > 1) {
         if (c_->opt_shard_interpolation == 1) shard_interp_ = true;
         else if (c_->opt_shard_interpolation == 2) shard_interp_ = sp_model_shard_interpolation(c_->link_gbs_for_model(), G_, (uint32_t)k) == 1;
+        // SP_COMM_LOG: the mode and the rate it was chosen from, once per set-up shape and rank (what a first multi-GPU run is read by)
+        static const bool comm_log = std::getenv("SP_COMM_LOG") != nullptr;
+        if (comm_log)
+            std::fprintf(stderr, "[stark252 rank %u/%u] 2^%d rows, %u groups: interpolation %s (SP_OPT_SHARD_INTERPOLATION = %d; link %.1f GB/s per direction - %s; by column pays above %.1f)\n",
+                         wrank_, world_, k, G_, shard_interp_ ? "by column + coefficient all-gather" : "on every rank", c_->opt_shard_interpolation, c_->link_gbs_for_model(),
+                         c_->opt_link_gbs_explicit ? "stated" : (c_->measured_link[1] > 0 ? "measured all-gather rate / 1.25" : "assumed"),
+                         64.0 * 1.35e11 / ((double)(G_ - 1) * (double)k) / 1e9);
     }
     if (G_ > 1 && N_ < 2ull * G_ * G_) { sp_set_error("setup: the LDE domain is too small for this many ranks"); return SP_E_INVALID_ARG; }
     double _tp = wall_ms();

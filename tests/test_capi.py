@@ -167,3 +167,19 @@ def test_interpolation_mode_follows_the_link_rate(hip_lib):
     assert rule(76.8, 8, 20) == 1                                      # a link at its nominal rate would flip configs[2] x 8 ...
     assert rule(76.8, 4, 19) == 0                                      # ... but not configs[3] x 4 (threshold 151.6 GB/s)
     assert rule(1e6, 1, 20) == 0 and rule(0.0, 8, 20) == 0 and rule(-1.0, 8, 20) == 0
+    # a MEASURED rate reaches the rule divided by SP_LINK_MEASURED_MARGIN (the threshold at G = 8, n = 2^20 - 62 GB/s - is
+    # where real xGMI all-gather rates are; a figure within the spread of it must not flip the mode between communicators)
+    header = open(os.path.join(ROOT, "include", "stark252_hip.h")).read()
+    assert float(re.search(r"#define SP_LINK_MEASURED_MARGIN\s+([0-9.]+)", header).group(1)) == api.LINK_MEASURED_MARGIN == 1.25
+    t = threshold(8, 20)
+    assert rule(t * 1.2 / api.LINK_MEASURED_MARGIN, 8, 20) == 0 and rule(t * 1.3 / api.LINK_MEASURED_MARGIN, 8, 20) == 1
+
+
+def test_abi_version_is_the_headers(hip_lib):
+    """entry points were added under an unchanged SP_ABI_VERSION, so a stale libstark252_hip.so passed the load-time check and
+    failed later with AttributeError.  The header's number, the binding's and the library's agree, and the binding probes the newest
+    entry points when it loads."""
+    header = open(os.path.join(ROOT, "include", "stark252_hip.h")).read()
+    assert int(re.search(r"#define SP_ABI_VERSION\s+(\d+)", header).group(1)) == _lib.SP_ABI_VERSION == hip_lib.sp_abi_version() >= 4
+    for name in _lib.NEWEST_SYMBOLS:
+        assert name in declared_symbols() and hasattr(hip_lib, name)

@@ -78,6 +78,15 @@ def _worker(rank, world, port, case, options, knobs, q):
             ctx.set_collective_async(api.StagedAsyncAllGather(alltoall=knobs.get("async_a2a", True)))
         ctx.comm_selftest(4096)  # rank-stamped blocks through every installed primitive (blocking and stream-ordered)
         link = ctx.comm_measure(1 << 16) if knobs.get("measure") else None   # sp_comm_measure through a transport that really exchanges
+        if "measure_fault" in knobs:     # one rank cannot prepare its payload buffers (the library's fault injection): what do the OTHERS do?
+            os.environ["SP_COMM_MEASURE_FAULT_RANK"] = str(knobs["measure_fault"])
+            try:
+                ctx.comm_measure(1 << 16)
+                raised = None
+            except api.SpError as e:
+                raised = (e.args[0], str(e))
+            os.environ.pop("SP_COMM_MEASURE_FAULT_RANK")
+            link = dict(ctx.comm_measure(0), raised=raised)
         if "fri_min_log" in knobs:
             ctx.set_option(api.SP_OPT_FRI_SHARD_MIN_LOG, knobs["fri_min_log"])
         if "shard_interp" in knobs:
@@ -379,7 +388,7 @@ def test_link_rate_decides_the_interpolation_mode_null_transport():
         assert ctx.last_proof_info()["interpolation_sharded"] == 0
         m = ctx.comm_measure(64 << 20)                                       # "links" that are memsets: far beyond the threshold
         assert m["world"] == 8 and m["allgather_ms"] > 0 and m["alltoall_ms"] > 0
-        expect = api.model_shard_interpolation(m["allgather_gbs_per_link"], 8, 14)
+        expect = api.model_shard_interpolation(m["allgather_gbs_per_link"] / api.LINK_MEASURED_MARGIN, 8, 14)      # a measured rate decides with a margin
         ctx.cairo_prove_run(run, opt)
         assert ctx.last_proof_info()["interpolation_sharded"] == expect == 1, m
         ctx.set_option(api.SP_OPT_LINK_GBS, 46)                              # the caller's word beats the measurement
@@ -415,3 +424,30 @@ def test_link_rate_measurement_agrees_across_ranks(world, knobs, oracle, hip_ctx
         assert other["allgather_gbs_per_link"] == first["allgather_gbs_per_link"]
         assert other["alltoall_gbs_per_link"] == first["alltoall_gbs_per_link"]
         assert stats["interpolation_sharded"] == results[0][1]["interpolation_sharded"]
+
+
+@pytest.mark.parametrize("world,knobs", [(2, {"measure": True, "measure_fault": 1}), (4, {"measure": True, "async": True, "measure_fault": 2})],
+                         ids=["blocking-hooks", "stream-ordered-hooks"])
+def test_link_rate_measurement_fails_on_every_rank_or_on_none(world, knobs, oracle, hip_ctx):
+    """a rank that cannot prepare its measurement (out of memory for the payload, an event that cannot be created) used to
+    return before its peers' first collective - they blocked, or paired that all-gather with the failing rank's next one, and the ranks
+    ended up with different link rates, hence possibly different interpolation modes.  Now everything local is done first, a status word
+    per rank goes round on every path, and ONE failing rank makes EVERY rank skip the timed collectives, drop the figures (a good earlier
+    measurement included) and return non-zero.  That the transport stayed in step is shown by what follows on it: a proof with the
+    single-rank bytes from every rank."""
+    from lambdaworks_cairo_prover_amd import api
+    run = api.CairoRun.fibonacci(300)
+    options = (4, 4, 3, 2)
+    want = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+    results = _run_world(world, FIB(300), options, knobs)
+    for r in range(world):
+        proof, stats = results[r]
+        assert proof == want, (r, proof[:300])
+        link = stats["link"]
+        assert link["raised"] is not None, (r, link)                          # every rank was told
+        code, msg = link["raised"]
+        assert code == (api._lib.SP_E_ALLOC if r == knobs["measure_fault"] else api._lib.SP_E_STATE), (r, link)
+        if r != knobs["measure_fault"]:
+            assert f"rank {knobs['measure_fault']} could not prepare" in msg, msg
+        assert link["allgather_gbs_per_link"] == 0.0 and link["alltoall_gbs_per_link"] == 0.0 and link["world"] == 0, (r, link)
+        assert stats["interpolation_sharded"] == 0                            # the assumed 46 GB/s on every rank

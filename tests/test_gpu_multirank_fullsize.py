@@ -176,7 +176,7 @@ def test_config4_split_equals_the_reference_golden_file(world, knobs):
             link = stats["link"]
             assert link["world"] == world and link["allgather_gbs_per_link"] > 0 and link["alltoall_gbs_per_link"] > 0, link
             if "shard_interp" not in knobs:      # mode 2: the rule on the measured rate (identical on every rank: the minimum over ranks)
-                assert stats["interpolation_sharded"] == api.model_shard_interpolation(link["allgather_gbs_per_link"], min(world, 4), 19)
+                assert stats["interpolation_sharded"] == api.model_shard_interpolation(link["allgather_gbs_per_link"] / api.LINK_MEASURED_MARGIN, min(world, 4), 19)
             else:
                 assert stats["interpolation_sharded"] == knobs["shard_interp"]
         else:
