@@ -84,7 +84,7 @@ def _worker(rank, world, port, case, options, knobs, q):
                 ctx.comm_measure(1 << 16)
                 raised = None
             except api.SpError as e:
-                raised = (e.args[0], str(e))
+                raised = (e.code, str(e))
             os.environ.pop("SP_COMM_MEASURE_FAULT_RANK")
             link = dict(ctx.comm_measure(0), raised=raised)
         if "fri_min_log" in knobs:
