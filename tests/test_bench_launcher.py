@@ -117,3 +117,42 @@ def test_sigterm_to_the_launcher_ends_the_ranks_and_leaves_the_line():
     time.sleep(0.5)
     for k in kids:
         assert not os.path.exists(f"/proc/{k}") or open(f"/proc/{k}/stat").read().split()[2] == "Z", k
+
+
+def test_children_of_a_rank_arm_the_parent_death_signal_themselves():
+    """the proof and pre-flight children are started by a rank that has initialised torch, HIP and gloo - a preexec_fn (Python
+    between fork and exec of a multi-threaded process) can deadlock there.  _spawn_rank_child passes no preexec_fn; the child arms
+    PR_SET_PDEATHSIG as its first statement and leaves at once when the process named in SP_BENCH_PARENT_PID is not its parent any more;
+    a child whose parent is then KILLED goes with it."""
+    import inspect
+    import signal
+    sys.path.insert(0, ROOT)
+    import bench
+    src = inspect.getsource(bench._spawn_rank_child)
+    assert "preexec_fn=" not in src and "SP_BENCH_PARENT_PID" in src
+    # (1) the named parent is gone already: exit code 86 before anything is imported or any device is touched
+    code = "import sys; sys.path.insert(0, %r); import bench; bench._arm_parent_death_signal(); print('armed')" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SP_BENCH_PARENT_PID="1", SP_BENCH_PDEATHSIG=str(int(signal.SIGKILL))),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 86 and "armed" not in r.stdout, (r.returncode, r.stdout, r.stderr[-300:])
+    # (2) the right parent: armed; then the parent is killed outright and the child is gone within moments
+    parent = ("import os, subprocess, sys, time\n"
+              "child = subprocess.Popen([sys.executable, '-c', %r], env=dict(os.environ, SP_BENCH_PARENT_PID=str(os.getpid()), SP_BENCH_PDEATHSIG='9'))\n"
+              "print(child.pid, flush=True)\n"
+              "time.sleep(600)\n") % ("import sys, time; sys.path.insert(0, %r); import bench; bench._arm_parent_death_signal(); print('armed', flush=True); time.sleep(600)" % ROOT)
+    p = subprocess.Popen([sys.executable, "-c", parent], stdout=subprocess.PIPE, text=True)
+    try:
+        kid = int(p.stdout.readline())
+        assert p.stdout.readline().strip() == "armed"
+        p.kill()
+        p.wait()
+        for _ in range(100):
+            if not os.path.exists(f"/proc/{kid}") or open(f"/proc/{kid}/stat").read().split()[2] == "Z":
+                break
+            time.sleep(0.1)
+        else:
+            os.kill(kid, signal.SIGKILL)
+            raise AssertionError("the child outlived its killed parent")
+    finally:
+        if p.poll() is None:
+            p.kill()
