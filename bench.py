@@ -38,8 +38,8 @@ VALU_BUTTERFLY_CEILING = 1.72e11
 MAD_ISSUE_NS = 2.299
 MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
 VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_ntt22_traffic.json")
-MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_merkle_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_ntt22_traffic.json")
+MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_merkle_traffic.json")
 
 
 def ntt_source_sha16():
@@ -941,7 +941,7 @@ def proof_isolated(args, rank, local_rank, world, dist):
     port, path = box
     child, err = _spawn_rank_child("--proof-child", path, rank, local_rank, world, port,
                                    ["--proof-fib", str(args.proof_fib), "--proof-blowup", str(args.proof_blowup), "--cfg4-fib", str(args.cfg4_fib),
-                                    "--cfg4-blowup", str(args.cfg4_blowup)], {"SP_BENCH_TRANSPORT": transport})
+                                    "--cfg4-blowup", str(args.cfg4_blowup)], {"SP_BENCH_TRANSPORT": transport, "SP_COMM_LOG": "1"})
     status = _wait_child(child, args.proof_timeout)
     if rank != 0:
         return None
@@ -951,6 +951,10 @@ def proof_isolated(args, rank, local_rank, world, dist):
         os.unlink(path)
         if status != "ok" and isinstance(res, dict):
             res["child_status"] = status
+        if isinstance(res, dict):      # what the library said it chose and from which rate (SP_COMM_LOG: one line per set-up shape)
+            err.seek(0)
+            said = [l for l in err.read().decode(errors="replace").splitlines() if l.startswith("[stark252 rank")]
+            res.setdefault("rccl", {})["interpolation_decisions"] = said[:8]
         if preflight is not None and isinstance(res, dict):
             res.setdefault("rccl", {})["preflight"] = preflight
         return res
