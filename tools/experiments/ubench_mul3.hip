@@ -109,6 +109,32 @@ __device__ __forceinline__ void mul2_pipelined(const fe& a1, const fe& b1, const
     for (int j = 0; j < 8; ++j) { r1.v[j] = (uint32_t)T[j]; r2.v[j] = (uint32_t)S[j]; }
 }
 
+
+// carry-free limb arithmetic: the carry out of x + y + cin is the top bit of (x & y) | ((x | y) & ~s) - one v_bitop3_b32 and a shift, no
+// lane mask through the scalar operand path.  Four "cheap" VALU instructions per limb instead of one carry instruction.
+__device__ __forceinline__ uint32_t cf_carry(uint32_t x, uint32_t y, uint32_t s) {   // (x & y) | ((x | y) & ~s) >> 31
+    return __builtin_amdgcn_bitop3_b32(x, y, s, 0xd4) >> 31;
+}
+__device__ __forceinline__ uint32_t cf_borrow(uint32_t x, uint32_t y, uint32_t d) {  // (~x & y) | (~(x ^ y) & d) >> 31
+    return __builtin_amdgcn_bitop3_b32(x, y, d, 0x8e) >> 31;
+}
+__device__ __forceinline__ fe cf_add_raw(const fe& a, const fe& b) {
+    fe r; uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint32_t s = a.v[j] + b.v[j] + c; c = cf_carry(a.v[j], b.v[j], s); r.v[j] = s; }
+    return r;
+}
+__device__ __forceinline__ fe cf_sub_add_2p(const fe& a, const fe& b) {   // a - b + 2p
+    fe d; uint32_t br = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint32_t x = a.v[j] - b.v[j] - br; br = cf_borrow(a.v[j], b.v[j], x); d.v[j] = x; }
+    const uint32_t P2[8] = {2u, 0u, 0u, 0u, 0u, 0u, 34u, 0x10000000u};
+    fe r; uint32_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const uint32_t s = d.v[j] + P2[j] + c; c = cf_carry(d.v[j], P2[j], s); r.v[j] = s; }
+    return r;
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
     fe x = in[threadIdx.x & 63], y = in[(threadIdx.x + 7) & 63], x2 = in[(threadIdx.x + 13) & 63], y2 = in[(threadIdx.x + 29) & 63];
@@ -122,6 +148,10 @@ __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
             if (OP == 6) mul2_pipelined<false>(x, y, x2, y2, t, t2); else mul2_pipelined<true>(x, y, x2, y2, t, t2);
             fe u = fe_add_raw(y, t); x = fe_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
             fe u2 = fe_add_raw(y2, t2); x2 = fe_sub_add_2p(y2, t2); y2 = u2; x2.v[7] &= 0x0fffffffu; y2.v[7] &= 0x07ffffffu;
+        }
+        else if (OP == 8) {   // two butterflies, sequential, carry-free add / sub
+            fe t = fe_mul_lazy(x, y); fe u = cf_add_raw(y, t); x = cf_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
+            fe t2 = fe_mul_lazy(x2, y2); fe u2 = cf_add_raw(y2, t2); x2 = cf_sub_add_2p(y2, t2); y2 = u2; x2.v[7] &= 0x0fffffffu; y2.v[7] &= 0x07ffffffu;
         }
         else if (OP == 2) {   // two butterflies, sequential
             fe t = fe_mul_lazy(x, y); fe u = fe_add_raw(y, t); x = fe_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
@@ -157,7 +187,7 @@ int main() {
     for (int i = 0; i < 64; ++i) h[i].v[7] &= 0x07ffffff;
     fe *d_in, *d_out; (void)hipMalloc(&d_in, sizeof(h)); (void)hipMalloc(&d_out, sizeof(fe) * 256 * 8 * 256);
     (void)hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
-    uint32_t s0, s1, s2, s3, s4, s5, s6, s7;
+    uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8;
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("2 x fe_mul_lazy, sequential", d_out, d_in, &s0);
         run<1>("2 x fe_mul_lazy, lockstep", d_out, d_in, &s1);
@@ -167,6 +197,8 @@ int main() {
         run<5>("2 x product, pipelined lockstep, persistent pairs", d_out, d_in, &s5);
         run<6>("2 butterflies, pipelined lockstep", d_out, d_in, &s6);
         run<7>("2 butterflies, pipelined lockstep, persistent pairs", d_out, d_in, &s7);
+        run<8>("2 butterflies, sequential, carry-free add / sub", d_out, d_in, &s8);
+        printf("carry-free %s\n", s8 == s2 ? "MATCH" : "DIFFER");
         printf("results %s\n", (s0 == s1 && s0 == s4 && s0 == s5 && s2 == s3 && s2 == s6 && s2 == s7) ? "MATCH" : "DIFFER");
     }
     return 0;
