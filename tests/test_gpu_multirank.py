@@ -451,3 +451,21 @@ def test_link_rate_measurement_fails_on_every_rank_or_on_none(world, knobs, orac
             assert f"rank {knobs['measure_fault']} could not prepare" in msg, msg
         assert link["allgather_gbs_per_link"] == 0.0 and link["alltoall_gbs_per_link"] == 0.0 and link["world"] == 0, (r, link)
         assert stats["interpolation_sharded"] == 0                            # the assumed 46 GB/s on every rank
+
+
+def test_comm_log_names_the_mode_and_the_rate(oracle, hip_ctx, capfd, monkeypatch):
+    """SP_COMM_LOG ("always log the chosen mode and rate"): every rank prints, once per set-up shape, which interpolation mode
+    it took, from which link rate (stated / measured / 1.25 / assumed) and where the threshold is - the line bench.py carries into its
+    result for N > 1, so that the first run on real links can be read."""
+    from lambdaworks_cairo_prover_amd import api
+    monkeypatch.setenv("SP_COMM_LOG", "1")
+    run = api.CairoRun.fibonacci(300)
+    options = (4, 4, 3, 2)
+    want = hip_ctx.cairo_prove(run.main_trace(), run.public_inputs_c, api.ProofOptions(*options))
+    results = _run_world(2, FIB(300), options, {"measure": True})
+    assert all(results[r][0] == want for r in range(2))
+    err = capfd.readouterr().err
+    lines = [l for l in err.splitlines() if l.startswith("[stark252 rank")]
+    assert {l.split("]")[0] for l in lines} == {"[stark252 rank 0/2", "[stark252 rank 1/2"}, err[-800:]
+    for l in lines:
+        assert "interpolation on every rank" in l and "measured all-gather rate / 1.25" in l and "by column pays above" in l, l
