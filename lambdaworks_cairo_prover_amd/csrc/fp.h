@@ -102,6 +102,29 @@ SP_HD fe fe_sub(const fe& a, const fe& b) {
 
 SP_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
 
+// The reduction tail of a CIOS row on the device, through two multiply-adds (round 6).  After the merge chain a row holds x6, x7, x8 in
+// words 6..8 and owes them m p = m + 17 m 2^192 + m 2^251:  E = 17 m + {x7, x6},  F = 2^27 m + {x8, hi(E)},  t5 = lo(E), t6 = lo(F),
+// t7 = hi(F) + carry(E).  E can overflow 64 bits (x7 is any word); v_mad_u64_u32 reports that in its scalar carry-out, which the compiler
+// does not expose - hence the inline assembly; F cannot (x8 < 2^30 for every operand the prover multiplies, m 2^27 < 2^59).  Instead of one
+// multiply-add and a chain of three carries: a carry instruction (a lane mask through the scalar operand path) costs 0.83 of a multiply-add
+// on gfx950, so - 2 carries + 1 multiply-add pays: 197 -> 211 G products/s, 174 -> 182 G butterflies/s in registers
+// (tools/experiments/ubench_mul3.hip, profiles/r06_mul3_v2_ubench.txt).  The s_nop covers the two wait states gfx950 wants between a VALU
+// write and a VALU read of an SGPR: the hazard recogniser does not look inside inline assembly.  SP_FE_NO_MAD_REDUCTION: the carry-chain
+// form (what the host compiles).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SP_FE_NO_MAD_REDUCTION)
+#define SP_FE_MAD_REDUCTION 1
+__device__ __forceinline__ void sp_row_reduce(uint32_t m, uint32_t x6, uint32_t x7, uint32_t x8, uint32_t& t5, uint32_t& t6, uint32_t& t7) {
+    const uint64_t X = ((uint64_t)x7 << 32) | x6;
+    uint64_t E, cE, F, cF, unused;
+    uint32_t r7;
+    asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(E), "=s"(cE) : "v"(m), "v"(X));
+    const uint64_t Y = ((uint64_t)x8 << 32) | (uint32_t)(E >> 32);
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(F), "=s"(cF) : "v"(m), "s"(0x08000000u), "v"(Y));
+    asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r7), "=s"(unused) : "v"((uint32_t)(F >> 32)), "s"(cE));
+    t5 = (uint32_t)E; t6 = (uint32_t)F; t7 = r7;
+}
+#endif
+
 // Montgomery product, CIOS with the reduction round merged into the accumulate carry chain.
 // Row i:  u = t + a_i * b  (eight v_mad_u64_u32, D_j = a_i b_j + t_j),  m = -u_0 (p = 1 mod 2^32, so -p^-1 = -1),
 //         u += m * p  with  m * p = m + 17 m 2^192 + m 2^251  (one mad and two shifts),  t = u >> 32.
@@ -122,6 +145,13 @@ SP_HD fe fe_mul_lazy(const fe& a, const fe& b) {
         unsigned c = (u0 != 0), c1, c2;  // u0 + m = c * 2^32
 #pragma unroll
         for (int j = 1; j <= 5; ++j) { t[j - 1] = SP_ADDC(D[j], D[j - 1] >> 32, c, c1); c = c1; }
+#ifdef SP_FE_MAD_REDUCTION
+        const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
+        const uint32_t x7 = SP_ADDC(D[7], D[6] >> 32, c1, c1);
+        const uint32_t x8 = SP_ADDC(D[7] >> 32, 0u, c1, c1);
+        (void)c2;
+        sp_row_reduce(m, x6, x7, x8, t[5], t[6], t[7]);
+#else
         const uint64_t m17 = (uint64_t)m * 17u;
         const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
         t[5] = SP_ADDC(x6, m17, 0u, c2);
@@ -130,6 +160,7 @@ SP_HD fe fe_mul_lazy(const fe& a, const fe& b) {
         t[6] = SP_ADDC(x7, k7, c2, c2);
         const uint32_t x8 = SP_ADDC(D[7] >> 32, m >> 5, c1, c1);
         t[7] = SP_ADDC(x8, 0u, c2, c2);
+#endif
     }
     fe r;
 #pragma unroll
@@ -270,6 +301,13 @@ SP_HD fe fe_sqr_lazy(const fe& a) {
         unsigned c = (u0 != 0), c1, c2;  // u0 + m = c * 2^32
 #pragma unroll
         for (int j = 1; j <= 5; ++j) { t[j - 1] = SP_ADDC(D[j], D[j - 1] >> 32, c, c1); c = c1; }
+#ifdef SP_FE_MAD_REDUCTION
+        const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
+        const uint32_t x7 = SP_ADDC(D[7], D[6] >> 32, c1, c1);
+        const uint32_t x8 = SP_ADDC(D[7] >> 32, 0u, c1, c1);
+        (void)c2;
+        sp_row_reduce(m, x6, x7, x8, t[5], t[6], t[7]);
+#else
         const uint64_t m17 = (uint64_t)m * 17u;
         const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1);
         t[5] = SP_ADDC(x6, m17, 0u, c2);
@@ -278,6 +316,7 @@ SP_HD fe fe_sqr_lazy(const fe& a) {
         t[6] = SP_ADDC(x7, k7, c2, c2);
         const uint32_t x8 = SP_ADDC(D[7] >> 32, m >> 5, c1, c1);
         t[7] = SP_ADDC(x8, 0u, c2, c2);
+#endif
     }
     fe r;
 #pragma unroll

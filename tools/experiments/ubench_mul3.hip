@@ -135,6 +135,43 @@ __device__ __forceinline__ fe cf_sub_add_2p(const fe& a, const fe& b) {   // a -
     return r;
 }
 
+
+// Reduction of a row through two multiply-adds (needs the carry-out of v_mad_u64_u32, which only inline assembly exposes):
+//   E = 17 m + {x7, x6} (carry-out cE), F = 2^27 m + {x8, hi(E)}, t5 = lo(E), t6 = lo(F), t7 = hi(F) + cE
+// 10 multiply-adds + 9 carries a row instead of 9 + 11.
+__device__ __forceinline__ fe fe_mul_lazy_v2(const fe& a, const fe& b) {
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) t[j] = 0;
+    const uint32_t two27 = 0x08000000u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t D[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) D[j] = (uint64_t)a.v[i] * b.v[j] + t[j];
+        const uint32_t u0 = (uint32_t)D[0];
+        const uint32_t m = 0u - u0;
+        unsigned c = (u0 != 0), c1;
+#pragma unroll
+        for (int j = 1; j <= 5; ++j) { t[j - 1] = SP_ADDC(D[j], D[j - 1] >> 32, c, c1); c = c1; }
+        const uint32_t x6 = SP_ADDC(D[6], D[5] >> 32, c, c1); c = c1;
+        const uint32_t x7 = SP_ADDC(D[7], D[6] >> 32, c, c1); c = c1;
+        const uint32_t x8 = SP_ADDC(D[7] >> 32, 0u, c, c1);
+        const uint64_t X = ((uint64_t)x7 << 32) | x6;
+        uint64_t E, cE, F, cF;
+        asm("v_mad_u64_u32 %0, %1, %2, 17, %3" : "=v"(E), "=s"(cE) : "v"(m), "v"(X));
+        const uint64_t Y = ((uint64_t)x8 << 32) | (uint32_t)(E >> 32);
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(F), "=s"(cF) : "v"(m), "s"(two27), "v"(Y));
+        uint32_t t7; uint64_t dummy;
+        asm("s_nop 1\n\tv_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(t7), "=s"(dummy) : "v"((uint32_t)(F >> 32)), "s"(cE));
+        t[5] = (uint32_t)E; t[6] = (uint32_t)F; t[7] = t7;
+    }
+    fe r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r.v[j] = t[j];
+    return r;
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
     fe x = in[threadIdx.x & 63], y = in[(threadIdx.x + 7) & 63], x2 = in[(threadIdx.x + 13) & 63], y2 = in[(threadIdx.x + 29) & 63];
@@ -152,6 +189,11 @@ __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
         else if (OP == 8) {   // two butterflies, sequential, carry-free add / sub
             fe t = fe_mul_lazy(x, y); fe u = cf_add_raw(y, t); x = cf_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
             fe t2 = fe_mul_lazy(x2, y2); fe u2 = cf_add_raw(y2, t2); x2 = cf_sub_add_2p(y2, t2); y2 = u2; x2.v[7] &= 0x0fffffffu; y2.v[7] &= 0x07ffffffu;
+        }
+        else if (OP == 9) { x = fe_mul_lazy_v2(x, y); x2 = fe_mul_lazy_v2(x2, y2); x.v[7] &= 0x0fffffffu; x2.v[7] &= 0x0fffffffu; }
+        else if (OP == 10) {
+            fe t = fe_mul_lazy_v2(x, y); fe u = fe_add_raw(y, t); x = fe_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
+            fe t2 = fe_mul_lazy_v2(x2, y2); fe u2 = fe_add_raw(y2, t2); x2 = fe_sub_add_2p(y2, t2); y2 = u2; x2.v[7] &= 0x0fffffffu; y2.v[7] &= 0x07ffffffu;
         }
         else if (OP == 2) {   // two butterflies, sequential
             fe t = fe_mul_lazy(x, y); fe u = fe_add_raw(y, t); x = fe_sub_add_2p(y, t); y = u; x.v[7] &= 0x0fffffffu; y.v[7] &= 0x07ffffffu;
@@ -187,7 +229,7 @@ int main() {
     for (int i = 0; i < 64; ++i) h[i].v[7] &= 0x07ffffff;
     fe *d_in, *d_out; (void)hipMalloc(&d_in, sizeof(h)); (void)hipMalloc(&d_out, sizeof(fe) * 256 * 8 * 256);
     (void)hipMemcpy(d_in, h, sizeof(h), hipMemcpyHostToDevice);
-    uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8;
+    uint32_t s0, s1, s2, s3, s4, s5, s6, s7, s8, s9, s10;
     for (int rep = 0; rep < 2; ++rep) {
         run<0>("2 x fe_mul_lazy, sequential", d_out, d_in, &s0);
         run<1>("2 x fe_mul_lazy, lockstep", d_out, d_in, &s1);
@@ -199,6 +241,9 @@ int main() {
         run<7>("2 butterflies, pipelined lockstep, persistent pairs", d_out, d_in, &s7);
         run<8>("2 butterflies, sequential, carry-free add / sub", d_out, d_in, &s8);
         printf("carry-free %s\n", s8 == s2 ? "MATCH" : "DIFFER");
+        run<9>("2 x product, reduction through two multiply-adds", d_out, d_in, &s9);
+        run<10>("2 butterflies, reduction through two multiply-adds", d_out, d_in, &s10);
+        printf("two-mad reduction %s\n", (s9 == s0 && s10 == s2) ? "MATCH" : "DIFFER");
         printf("results %s\n", (s0 == s1 && s0 == s4 && s0 == s5 && s2 == s3 && s2 == s6 && s2 == s7) ? "MATCH" : "DIFFER");
     }
     return 0;
