@@ -73,9 +73,9 @@ const char* sp_version(void);
 /* Version of this header: bumped whenever a structure (sp_air_desc, sp_openings, sp_cairo_public_inputs, sp_proof_options) changes
  * layout, an entry point or option key is added, or a call changes meaning (4: round 5's sp_comm_measure / sp_comm_time_ms /
  * sp_proof_options_* / sp_proof_file_verify / SP_OPT_HOST_RANKS family and sp_set_collective keeping the prover across re-installs
- * of the same world).  A binding compares it (and sp_air_desc_size against its own idea of the struct) when it loads the library, so
+ * of the same world; 5: sp_fe_mul).  A binding compares it (and sp_air_desc_size against its own idea of the struct) when it loads the library, so
  * a stale build fails at load time with "rebuild the library" instead of with a missing symbol or shifted fields later. */
-#define SP_ABI_VERSION 4
+#define SP_ABI_VERSION 5
 int sp_abi_version(void);
 uint64_t sp_air_desc_size(void);
 const char* sp_last_error(void);          /* thread-local description of the last failure */
@@ -236,6 +236,11 @@ int sp_merkle_build_dev(sp_ctx* ctx, const void* cols_dev, uint64_t n_leaves, ui
 
 /* FieldElement::inplace_batch_inverse (constraints/evaluator.rs:69,171; cairo/air.rs:540,561). */
 int sp_batch_inverse(sp_ctx* ctx, uint8_t* data, uint64_t n);
+/* FieldElement<Stark252PrimeField> Mul / square on the device (src/lib.rs:12-13; every product of the path, e.g. cairo/air.rs:525-572,
+ * constraints/evaluator.rs:142-154): out[i] = a[i] * b[i] for n elements in the context's encoding; b == NULL squares a.  The kernels'
+ * own Montgomery product and square (csrc/fp.h) on caller-chosen operands - what the parity tests drive with adversarial limbs (with
+ * SP_FE_MONT_LIMBS the limbs go to the multiplier as they are). */
+int sp_fe_mul(sp_ctx* ctx, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out);
 
 /* Encoding helpers between the ABI encodings and the device layout (host side, no GPU needed). */
 int sp_fe_to_device(int fe_encoding, const uint8_t* in, uint64_t n, uint8_t* out_device_layout);

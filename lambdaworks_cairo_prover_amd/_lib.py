@@ -19,7 +19,7 @@ SP_E_ZERO_INVERSE = -6
 SP_E_UNSUPPORTED = -7
 SP_E_PROGRAM = -8
 
-SP_ABI_VERSION = 4   # include/stark252_hip.h
+SP_ABI_VERSION = 5   # include/stark252_hip.h
 
 SP_FE_MONT_LIMBS = 0
 SP_FE_CANON_BE = 1
@@ -50,7 +50,7 @@ class CairoPublicInputsC(ctypes.Structure):
 
 # The entry points added most recently, probed at load time beside the version number (api.py binds symbols lazily: a stale build would
 # otherwise fail with AttributeError in the middle of a run instead of with "rebuild the library" here).
-NEWEST_SYMBOLS = ("sp_comm_measure", "sp_comm_time_ms", "sp_model_shard_interpolation", "sp_proof_file_verify", "sp_proof_options_checked",
+NEWEST_SYMBOLS = ("sp_fe_mul", "sp_comm_measure", "sp_comm_time_ms", "sp_model_shard_interpolation", "sp_proof_file_verify", "sp_proof_options_checked",
                   "sp_host_cpu_budget")
 
 _lib = None

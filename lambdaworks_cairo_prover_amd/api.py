@@ -130,6 +130,15 @@ class Context:
         check(self._lib.sp_merkle_build_dev(self._h, ctypes.c_void_p(cols_ptr), ctypes.c_uint64(n_leaves), ctypes.c_uint32(fe_per_leaf),
                                             ctypes.c_uint64(col_stride), ctypes.c_void_p(nodes_ptr)))
 
+    def fe_mul(self, a, b=None):
+        """sp_fe_mul: element-wise products (b None: squares) by the device's own Montgomery routines, in the context's encoding."""
+        x = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, 32)
+        out = np.empty_like(x)
+        y = None if b is None else np.ascontiguousarray(b, dtype=np.uint8).reshape(-1, 32)
+        assert y is None or y.shape == x.shape
+        check(self._lib.sp_fe_mul(self._h, _u8p(x), None if y is None else _u8p(y), ctypes.c_uint64(x.shape[0]), _u8p(out)))
+        return out
+
     def batch_inverse(self, data):
         a = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 32).copy()
         check(self._lib.sp_batch_inverse(self._h, _u8p(a), ctypes.c_uint64(a.shape[0])))

@@ -697,4 +697,21 @@ int sp_batch_inverse(sp_ctx* c, uint8_t* data, uint64_t n) {
     return SP_OK;
 }
 
+int sp_fe_mul(sp_ctx* c, const uint8_t* a, const uint8_t* b, uint64_t n, uint8_t* out) {
+    if (!c || !a || !out) return SP_E_INVALID_ARG;
+    SP_HIP_CHECK(hipSetDevice(c->device));
+    if (n == 0) return SP_OK;
+    DevBuf x, y, r;
+    SP_TRY(x.alloc(n * sizeof(fe)));
+    SP_TRY(r.alloc(n * sizeof(fe)));
+    SP_TRY(upload_decode(c, a, n, x.as<fe>()));
+    if (b) {
+        SP_TRY(y.alloc(n * sizeof(fe)));
+        SP_TRY(upload_decode(c, b, n, y.as<fe>()));
+    }
+    SP_TRY(mul_elements(c->stream, x.as<fe>(), b ? y.as<fe>() : nullptr, n, r.as<fe>()));
+    SP_TRY(encode_download(c, r.as<fe>(), n, out));
+    return SP_OK;
+}
+
 }  // extern "C"

@@ -6,6 +6,8 @@ namespace sp {
 
 // In-place batch inverse of n device elements; scratch = n elements; *zero_flag_dev is set to 1 when an element is 0.
 int batch_inverse(hipStream_t st, fe* data, fe* scratch, uint64_t n, int* zero_flag_dev);
+// out[i] = a[i] * b[i] (b == nullptr: a[i]^2), canonical Montgomery values
+int mul_elements(hipStream_t st, const fe* a, const fe* b, uint64_t n, fe* out);
 // rows_dev: n_rows x n_cols row-major in ABI encoding `enc` (device memory) -> cols[c*col_stride + r] device layout
 int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n_rows, uint32_t n_cols, fe* cols, uint64_t col_stride);
 // dst_dev[0 .. bytes) = src_pinned_host[0 .. bytes) by a kernel reading the page-locked host memory (16-byte aligned, bytes % 16 == 0)

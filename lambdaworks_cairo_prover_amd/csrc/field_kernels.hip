@@ -151,6 +151,20 @@ int rows_to_columns(hipStream_t st, int enc, const uint8_t* rows_dev, uint64_t n
     return SP_OK;
 }
 
+// sp_fe_mul: the product and the square the kernels are built from, on operands the caller chooses
+__global__ void __launch_bounds__(256) mul_elements_kernel(const fe* a, const fe* b, uint64_t n, fe* out) {
+    uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const fe x = fk_ld(a + i);
+    fk_st(out + i, b ? fe_mul(x, fk_ld(b + i)) : fe_sqr(x));
+}
+int mul_elements(hipStream_t st, const fe* a, const fe* b, uint64_t n, fe* out) {
+    if (n == 0) return SP_OK;
+    hipLaunchKernelGGL(mul_elements_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, b, n, out);
+    SP_HIP_CHECK(hipGetLastError());
+    return SP_OK;
+}
+
 // column-major device layout -> column-major ABI encoding (one thread per element)
 template <int ENC>
 __global__ void __launch_bounds__(256) encode_kernel(const fe* in, uint64_t n, uint8_t* out) {

@@ -216,3 +216,104 @@ def test_plain_c_caller_runs_on_the_gpu(hip_ctx, tmp_path):
     out = subprocess.run([_build_c_example(tmp_path)], capture_output=True, text=True)
     assert out.returncode == 0 and "ntt round trip: rc 0, identical" in out.stdout, out.stdout + out.stderr
     assert "cairo proof: rc 0 (ok), 709 steps, 1024 x 34 trace" in out.stdout and "verifier accepts" in out.stdout, out.stdout + out.stderr
+
+
+# ---- sp_fe_mul: the kernels' own Montgomery product and square on operands the test chooses -------------------------------------
+P_ = api.P
+R_ = 1 << 256
+RINV_ = pow(R_, -1, P_)
+
+
+def _to_lw(vals):
+    """Montgomery representatives (integers < p) as lambdaworks' in-memory FieldElement: 4 x u64, most significant limb first."""
+    out = np.empty((len(vals), 32), dtype=np.uint8)
+    for k, v in enumerate(vals):
+        for i in range(4):
+            out[k, 8 * i:8 * i + 8] = np.frombuffer(((v >> (64 * (3 - i))) & (2**64 - 1)).to_bytes(8, "little"), dtype=np.uint8)
+    return out
+
+
+def _from_lw(arr):
+    return [sum(int.from_bytes(bytes(rec[8 * i:8 * i + 8]), "little") << (64 * (3 - i)) for i in range(4)) for rec in arr]
+
+
+def _rows_whose_reduction_overflows(a, b, square=False):
+    """The CIOS rows of csrc/fp.h on Python integers: the rows where E = 17 m + {x7, x6} exceeds 64 bits, i.e. where the device's
+    reduction-through-two-multiply-adds needs v_mad_u64_u32's carry-out (about one row in 2^27 on random operands)."""
+    hits, T = [], 0
+    for i in range(8):
+        ai = (a >> (32 * i)) & 0xFFFFFFFF
+        if square:      # row i of fe_sqr_lazy: the diagonal term once (at column i), every product with a higher limb doubled
+            S = T + ai * ((ai << (32 * i)) + 2 * ((a >> (32 * (i + 1))) << (32 * (i + 1))))
+        else:
+            S = T + ai * b
+        m = (-S) & 0xFFFFFFFF
+        X = ((S + m) >> 192) & (2**64 - 1)
+        if 17 * m + X >= 2**64:
+            hits.append(i)
+        assert (S + m * P_) % 2**32 == 0
+        T = (S + m * P_) >> 32
+    return hits, T
+
+
+def test_fe_mul_matches_python_integers(hip_ctx):
+    """FieldElement Mul / square through sp_fe_mul: random and extreme canonical operands against Python integers."""
+    rng = random.Random(61)
+    edge = [0, 1, 2, P_ - 1, P_ - 2, 2**251, 2**251 - 1, 2**192, 17 * 2**192, 2**64 - 1, 2**128 + 1, (P_ - 1) // 2, 3]
+    a = edge + [rng.randrange(P_) for _ in range(3000)]
+    b = [rng.choice(edge) for _ in edge] + [rng.randrange(P_) for _ in range(3000)]
+    got = api.bytes_to_felts(hip_ctx.fe_mul(api.felts_to_bytes(a), api.felts_to_bytes(b)))
+    assert got == [x * y % P_ for x, y in zip(a, b)]
+    got = api.bytes_to_felts(hip_ctx.fe_mul(api.felts_to_bytes(a)))
+    assert got == [x * x % P_ for x in a]
+
+
+def test_fe_mul_rows_whose_reduction_carries_out():
+    """Round 6: the device reduces a CIOS row through two multiply-adds, E = 17 m + {x7, x6} and F = 2^27 m + {x8, hi(E)}, and takes the
+    overflow of E from v_mad_u64_u32's carry-out (inline assembly, csrc/fp.h sp_row_reduce).  Random operands overflow E about once in 2^27
+    rows - no random test ever walks that path - so the operands are BUILT: lower limbs of a zero, so that row i starts from an empty
+    accumulator, and b = K div a_i with the bits 192..255 of K all ones: x6 = x7 = 0xffffffff in that row.  Every row 0..7 for the product
+    (with junk in the limbs above), row 0 for the square; the Python model of the rows confirms that each case really overflows where
+    it should, and the device's Montgomery limbs must equal a b R^-1 mod p."""
+    rng = random.Random(62)
+    A, B, want, hit_rows = [], [], [], []
+    for i in range(8):
+        for _ in range(40):
+            ai = rng.randrange(1 << 8, 1 << (27 if i == 7 else 32)) | 1
+            j = rng.randrange(0, max(1, ai // 64))
+            K = (((j << 64) | (2**64 - 1)) << 192) | rng.randrange(2**191, 2**192)
+            b = K // ai
+            a = (ai << (32 * i)) | (rng.randrange(2**256) >> (32 * (i + 1)) << (32 * (i + 1)))
+            a &= (1 << 251) - 1
+            a |= ai << (32 * i)
+            if not (b < P_ and a < P_):
+                continue
+            hits, T = _rows_whose_reduction_overflows(a, b)
+            if i not in hits:
+                continue
+            A.append(a); B.append(b); hit_rows.append(i)
+            want.append(a * b * RINV_ % P_)
+            assert T % P_ == want[-1]
+    assert set(hit_rows) == set(range(8)) and len(A) >= 100, (sorted(set(hit_rows)), len(A))
+    # squares: row 0 only (the operand's upper limbs are what is solved for)
+    SQ, sq_want = [], []
+    for _ in range(60):
+        a0 = rng.randrange(1 << 28, 1 << 32) | 1
+        K = (((rng.randrange(0, 4) << 64) | (2**64 - 1)) << 192) | rng.randrange(2**191, 2**192)
+        U = (K - a0 * a0) // (2 * a0 << 32)
+        a = a0 + (U << 32)
+        if a >= P_:
+            continue
+        hits, T = _rows_whose_reduction_overflows(a, a, square=True)
+        if 0 not in hits:
+            continue
+        SQ.append(a); sq_want.append(a * a * RINV_ % P_)
+    assert len(SQ) >= 20
+    with api.Context(device=0, fe_encoding=api.SP_FE_MONT_LIMBS) as ctx:
+        got = _from_lw(ctx.fe_mul(_to_lw(A), _to_lw(B)))
+        bad = [(hit_rows[k], hex(A[k]), hex(B[k])) for k in range(len(A)) if got[k] != want[k]]
+        assert not bad, bad[:3]
+        got = _from_lw(ctx.fe_mul(_to_lw(B), _to_lw(A)))          # the other operand order: no carry-out row, same product
+        assert got == want
+        got = _from_lw(ctx.fe_mul(_to_lw(SQ)))
+        assert got == sq_want

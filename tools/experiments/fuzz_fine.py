@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Ad-hoc: the fine-grained entry points (sp_ntt, sp_lde, sp_merkle_build, sp_batch_inverse) at random sizes - down to one element -
+"""Ad-hoc: the fine-grained entry points (sp_ntt, sp_lde, sp_merkle_build, sp_batch_inverse, sp_fe_mul) at random sizes - down to one element -
 and with random / extreme values against the oracle.  usage: fuzz_fine.py [cases=300] [seed0=0]"""
 import os, random, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,7 +20,7 @@ def vals(rng, n):
 with api.Context(device=0) as ctx:
     for seed in range(seed0, seed0 + cases):
         rng = random.Random(seed)
-        op = rng.choice(["ntt", "intt", "coset", "lde", "merkle", "inv"])
+        op = rng.choice(["ntt", "intt", "coset", "lde", "merkle", "inv", "mul"])
         try:
             if op in ("ntt", "intt", "coset"):
                 n = 1 << rng.randrange(0, 14)
@@ -46,6 +46,13 @@ with api.Context(device=0) as ctx:
                 except Exception: skipped += 1; continue
                 got = ctx.merkle_build(a, want_nodes=True)
                 ok = got[0] == want[0] and np.array_equal(got[1], want[1]); desc = f"merkle leaves {n} width {w}"
+            elif op == "mul":      # the kernels' own product / square against Python integers
+                n = rng.choice([1, 2, 63, 64, 65, 1000, 20000])
+                a, sq = vals(rng, n), rng.random() < 0.3
+                b = None if sq else vals(rng, n)
+                x = api.bytes_to_felts(a); y = x if sq else api.bytes_to_felts(b)
+                got = api.bytes_to_felts(ctx.fe_mul(a, b))
+                ok = got == [u * v % P for u, v in zip(x, y)]; desc = f"fe_mul n {n} square {sq}"
             else:
                 n = rng.choice([1, 2, 3, 5, 64, 255, 256, 257, 1000, 4096, 5000, 70000])
                 a = api.felts_to_bytes([rng.randrange(1, P) for _ in range(n)])
