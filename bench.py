@@ -30,13 +30,16 @@ sys.path.insert(0, ROOT)
 LOG_N = 22
 WARM_MS = 300.0
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
-# registers-only chain of the butterfly the passes execute (fe_mul_lazy + fe_add_raw + fe_sub_add_2p), one MI355X, 25 ms
-# kernels: profiles/r01_mulvar_ubench_long.txt (1.49e11 for the fully reduced butterfly of the first version)
-VALU_BUTTERFLY_CEILING = 1.72e11
-# independent ceiling: the 72 v_mad_u64_u32 of one Montgomery product at the measured issue time of that instruction alone
-# (2.299 ns per wave-instruction, 8 waves per SIMD, profiles/r01_instruction_ubench3.txt) on 1024 SIMDs x 64 lanes
+# registers-only chain of the butterfly the passes execute (fe_mul_lazy + fe_add_raw + fe_sub_add_2p), one MI355X, 47 ms kernels:
+# profiles/r06_mul3_v2_ubench.txt - 1.82e11 since round 6 (a row's reduction through two multiply-adds; 1.74e11 with the carry-chain
+# form of rounds 2 - 5, 1.49e11 for the fully reduced butterfly of the first version)
+VALU_BUTTERFLY_CEILING = 1.82e11
+# independent ceiling: the 80 v_mad_u64_u32 of one Montgomery product (64 of the product, 16 of the reduction; 72 before round 6) at the
+# measured issue time of that instruction alone (2.299 ns per wave-instruction, 8 waves per SIMD, profiles/r01_instruction_ubench3.txt)
+# on 1024 SIMDs x 64 lanes
 MAD_ISSUE_NS = 2.299
-MUL_ISSUE_CEILING = 1024 * 64 / (72 * MAD_ISSUE_NS * 1e-9)
+MADS_PER_PRODUCT = 80
+MUL_ISSUE_CEILING = 1024 * 64 / (MADS_PER_PRODUCT * MAD_ISSUE_NS * 1e-9)
 VALU_KECCAK_CEILING = 1.01e10  # Keccak-f[1600]/s, measured registers-only permutation rate (profiles/r01_keccak_ubench.txt)
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_ntt22_traffic.json")
 MERKLE_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r06_merkle_traffic.json")
