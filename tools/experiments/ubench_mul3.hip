@@ -5,6 +5,7 @@
 //   hipcc -O3 --offload-arch=gfx950 [-mllvm -enable-misched=0] tools/experiments/ubench_mul3.hip -o tools/bin/ubench_mul3
 #include "../../lambdaworks_cairo_prover_amd/csrc/fp.h"
 #include <cstdio>
+#include <cstdlib>
 #ifndef ITERS
 #define ITERS 8192
 #endif
@@ -208,10 +209,11 @@ __global__ void __launch_bounds__(256) k(fe* out, const fe* in) {
     for (int j = 0; j < 8; ++j) r.v[j] = x.v[j] ^ x2.v[j] ^ y.v[j] ^ y2.v[j];
     out[blockIdx.x * 256 + threadIdx.x] = r;
 }
+static int g_waves_per_simd = 8;     // argv[1]: resident waves per SIMD (256-thread blocks: one wave per SIMD each)
 template <int OP>
 void run(const char* name, fe* d_out, fe* d_in, uint32_t* sig) {
     hipDeviceProp_t prop; (void)hipGetDeviceProperties(&prop, 0);
-    dim3 grid(prop.multiProcessorCount * 8), block(256);
+    dim3 grid(prop.multiProcessorCount * g_waves_per_simd), block(256);
     hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL((k<OP>), grid, block, 0, 0, d_out, d_in); (void)hipDeviceSynchronize();
     (void)hipEventRecord(e0);
@@ -223,7 +225,9 @@ void run(const char* name, fe* d_out, fe* d_in, uint32_t* sig) {
     double ops = (double)grid.x * 256 * ITERS * 2;
     printf("%-52s %8.3f ms  %8.2f G ops/s   sig %08x\n", name, ms, ops / ms / 1e6, *sig);
 }
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1) g_waves_per_simd = atoi(argv[1]);
+    printf("== %d waves per SIMD\n", g_waves_per_simd);
     fe h[64];
     for (int i = 0; i < 64; ++i) for (int j = 0; j < 8; ++j) h[i].v[j] = 0x01234567u * (i + 3) + 0x9e3779b9u * j + (j == 7 ? 0 : 0x80000000u);
     for (int i = 0; i < 64; ++i) h[i].v[7] &= 0x07ffffff;
